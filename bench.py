@@ -1,0 +1,167 @@
+#!/usr/bin/env python3
+"""bench.py -- chirp frames/s of the receiver's per-frame DSP on MI355X.
+
+One "step" = one pass of the hot path (uc_process_batch, variant RX_REAL:
+ingest -> window*chirp -> 2048-pt FFT -> windowed peak pick -> up/down symbol)
+over one batch of synthetic frames already resident in HBM.  Workload =
+BASELINE.json configs[1]: 1 Mi x 2048-sample fp32 frames per GPU, orthogonal
+up/down chirp at -10 dB SNR.  Multi-GPU: one process per GPU, the frame index
+space is block-partitioned (weak scaling: 1 Mi frames per GPU), no data-path
+collective; the decoded symbol stream (1 B/frame) is all-gathered over RCCL at
+the end of every step, inside the timed region.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+import torch
+
+N = 2048
+BYTES_PER_FRAME = 8192 + 1          # fp32 frame in + 1 symbol byte out
+HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def make_device_frames(n_frames, device, seed, snr_db=-10.0, amp=1000.0):
+    """Synthetic orthogonal-chirp frames generated on the device (tests/synth.py model)."""
+    import synth
+    up, down = synth.chirp_pair(n=N, amp=amp)
+    tab = torch.tensor(np.stack([down, up]), dtype=torch.float32, device=device)
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    bits = torch.randint(0, 2, (n_frames,), generator=g, device=device, dtype=torch.int64)
+    frames = torch.empty((n_frames, N), dtype=torch.float32, device=device)
+    sigma = amp * 10.0 ** (-snr_db / 20.0)
+    chunk = 1 << 15
+    for s in range(0, n_frames, chunk):
+        e = min(n_frames, s + chunk)
+        frames[s:e] = tab[bits[s:e]]
+        frames[s:e] += sigma * torch.randn((e - s, N), generator=g, device=device)
+    return frames, bits.to(torch.uint8)
+
+
+def cpu_baseline(frames_host, mag_mean):
+    """The CPU restatement (oracle, float32 butterflies like CMSIS-DSP) timed on the
+    host cores of this box on a bounded sample of the same frames."""
+    from oracle import uco
+    o = uco.Oracle(uco.RX_REAL, mag_mean=mag_mean)
+    cores = os.cpu_count() or 1
+    probe = frames_host[:1024]
+    t0 = time.perf_counter()
+    o.process(probe, precision=uco.F32, threads=cores)
+    dt = max(time.perf_counter() - t0, 1e-6)
+    rate = probe.shape[0] / dt
+    n = int(min(frames_host.shape[0], max(2048, rate * 12.0)))
+    t0 = time.perf_counter()
+    o.process(frames_host[:n], precision=uco.F32, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "%d of the same synthetic frames, oracle/uc_oracle.c float32, OpenMP %d threads, %.1f s"
+                      % (n, cores, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU per step")
+    ap.add_argument("--snr", type=float, default=-10.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    import uchirp
+    mag_mean = 1000.0
+    eng = uchirp.Engine(uchirp.RX_REAL, device=local_rank, mag_mean=mag_mean)
+    nf = args.frames
+    frames, bits = make_device_frames(nf, device, seed=1234 + rank, snr_db=args.snr)
+    symbols = torch.empty(nf, dtype=torch.uint8, device=device)
+    gathered = torch.empty(world * nf, dtype=torch.uint8, device=device) if world > 1 else None
+    stream = torch.cuda.current_stream(device)
+
+    def step():
+        eng.process(frames, want_stats=False, symbols_out=symbols, stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, symbols)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+
+    # per-launch kernel time: HIP events on the stream the kernel is launched on
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        ev[k][0].record(stream)
+        eng.process(frames, want_stats=False, symbols_out=symbols, stream=stream.cuda_stream)
+        ev[k][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, symbols)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+    # correctness gate on the measured run: decoded symbols == transmitted bits
+    ber = float((symbols != bits).float().mean().item())
+
+    if rank == 0:
+        total_frames = world * nf * args.steps
+        value = total_frames / elapsed
+        achieved = nf * BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9
+        out = {
+            "metric": "chirp frames/s (2048-pt FFT demod)", "value": value, "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: %d x 2048-sample fp32 frames per GPU, orthogonal up/down-chirp "
+                                   "symbol decision (rx_real), SNR %.0f dB" % (nf, args.snr),
+                       "frames_per_gpu": nf, "frame_len": N, "variant": "rx_real",
+                       "parallelism": "frame-sharded x%d, RCCL all-gather of symbols" % world},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "band_kernel<rx_real,f32>", "kernel_ms": kern_ms,
+                         "bytes_per_frame": BYTES_PER_FRAME},
+            "bit_error_rate": ber,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(frames[: 1 << 16].cpu().numpy(), mag_mean)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,182 @@
+/*
+ * uchirp.h -- C-ABI of the MI355X chirp-demodulation engine (libuchirp.so).
+ *
+ * This is the drop-in boundary for the per-frame DSP path of
+ * araobp/ultrasonic-communication.  The reference has no FFI layer: the path
+ * is a set of file-scope C functions over globals.  Every entry point below
+ * names the reference symbol(s) whose call contract it replaces
+ * (paths relative to the reference checkout).
+ *
+ *   uc_create            <- inline init in main():  receiver/Src/main.c:367-393
+ *                           (fs, bandwidth, idx_left_zero, arm_rfft_fast_init_f32,
+ *                           Hann table) + init_ref_chirp(), receiver/Src/chirp.c:16-45
+ *   uc_process_frame     <- symbol_snr(pos,&h[0],UP) + symbol_snr(pos,&h[1],DOWN)
+ *                           + the bit decision, receiver/Src/main.c:233-236,518-531
+ *   uc_process_batch     <- N x dsp(), receiver/Src/main.c:183-231, with the
+ *                           int32->float ingest cast of the DFSDM ISR fused in,
+ *                           receiver/Src/main.c:659-668
+ *   uc_idx2freq          <- idx2freq(), receiver/Src/main.c:154-160
+ *   uc_get_table         <- the globals up_chirp/down_chirp/hann_window,
+ *                           receiver/Src/chirp.c:13-14, receiver/Src/main.c:99
+ *   uc_destroy           <- (none; the firmware never frees)
+ *
+ * Variants select the sibling pipelines:
+ *   UC_RX_REAL       receiver/Src/main.c:163-231            (shipping receiver)
+ *   UC_SYNC_CPLX     experiments/synchronization/Src/main.c:144-213
+ *   UC_COMPRESS      experiments/chirp_compression_time_domain/Src/chirp.c:78-83
+ *   UC_DECHIRP_DOWN  experiments/chirp_compression_freq_domain/Src/main.c:113-160
+ *   UC_IQ            experiments/iq_modulation/Src/main.c:117-134 + iq_modem.c:55-75
+ *
+ * Conventions: 0 on success, negative errno-style code on failure, never
+ * aborts.  The caller owns every buffer.  `frames`, `mag_mean`, `symbols`
+ * and `stats` of uc_process_batch may each be host or device pointers
+ * (detected with hipPointerGetAttributes); with device pointers the call is
+ * asynchronous on `hip_stream`.  A uc_ctx is not thread-safe; distinct
+ * contexts are independent.  There is NO CPU backend: uc_create fails with
+ * -ENODEV when no HIP device is usable.
+ */
+#ifndef UCHIRP_H_
+#define UCHIRP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define UC_ABI_VERSION 1
+
+/* pipeline variants */
+enum {
+  UC_RX_REAL      = 0,
+  UC_SYNC_CPLX    = 1,
+  UC_COMPRESS     = 2,
+  UC_DECHIRP_DOWN = 3,
+  UC_IQ           = 4,
+  UC_NUM_VARIANTS = 5
+};
+
+/* `typedef enum {DOWN_CHIRP, UP_CHIRP} chirp;`  receiver/Inc/chirp.h:12-14 */
+enum { UC_DOWN_CHIRP = 0, UC_UP_CHIRP = 1 };
+
+/* element type of `frames` */
+enum {
+  UC_DTYPE_I32 = 0, /* raw DFSDM words, cast with (float) -- main.c:664 */
+  UC_DTYPE_F32 = 1  /* already-cast fifo_queue contents -- main.c:94   */
+};
+
+/* symbol_out values */
+#define UC_SYM_DOWN 0u    /* bit low : snr_down >  snr_up  (main.c:523-526) */
+#define UC_SYM_UP   1u    /* bit high: otherwise           (main.c:527-531) */
+#define UC_SYM_NONE 0xFFu /* neither snr >= SNR_THRESHOLD  (main.c:521,539) */
+
+/* flags: each documents a quirk decision of SURVEY.md section 8a */
+#define UC_FLAG_LIBM_TRIG   (1u << 0) /* build tables with exact sin/cos instead of
+                                         the CMSIS-DSP LUT+interpolation restatement */
+#define UC_FLAG_TRUE_DC     (1u << 1) /* Q2 fix: mag[0] = |X0| instead of the packed
+                                         hypot(Re X0, Re X[N/2]) the reference computes */
+#define UC_FLAG_FUSED_TABLE (1u << 2) /* informational: the HIP path always multiplies by
+                                         ONE fp32 table ref*hann (one rounding) where the
+                                         reference rounds (x*ref) then (*hann) */
+
+/* table ids for uc_get_table */
+enum {
+  UC_TABLE_UP        = 0, /* n floats (RX_REAL, DECHIRP_DOWN uses DOWN only) or 2n (re,im) */
+  UC_TABLE_DOWN      = 1,
+  UC_TABLE_HANN      = 2, /* n floats */
+  UC_TABLE_H_UP      = 3, /* COMPRESS: packed RFFT of hann*up chirp, n floats   */
+  UC_TABLE_H_DOWN    = 4, /* COMPRESS: packed RFFT of hann*down chirp, n floats */
+  UC_TABLE_CARRIER_C = 5, /* IQ: n floats */
+  UC_TABLE_CARRIER_S = 6, /* IQ: n floats */
+  UC_TABLE_FIR       = 7  /* IQ: 27 taps */
+};
+
+/* mirrors the compile-time #defines and the derived values of the firmware */
+typedef struct uc_config {
+  uint32_t n;             /* NN 2048            -- receiver/Inc/main.h:97         */
+  float    fs;            /* 78125.0f           -- receiver/Src/main.c:367-369    */
+  float    f0, f1;        /* 16000, 19000       -- receiver/Inc/chirp.h:18-19     */
+  float    time_frame;    /* TIME_FRAME 0.0205f -- receiver/Inc/chirp.h:16 (Q4);
+                             <= 0 selects n/fs, which COMPRESS / DECHIRP_DOWN use */
+  float    phase_deg;     /* -90                -- receiver/Src/chirp.c:43-44     */
+  float    snr_threshold; /* 2.0f               -- receiver/Inc/main.h:98         */
+  float    mag_mean;      /* noise floor used when the per-frame pointer is NULL  */
+  float    carrier;       /* CARRIER 18000 (IQ) -- iq_modulation/Inc/iq_modem.h:10 */
+  int32_t  variant;       /* UC_RX_REAL ...                                       */
+  int32_t  device;        /* HIP device ordinal, >= 0                             */
+  uint32_t flags;         /* UC_FLAG_*                                            */
+} uc_config;
+
+/* = struct history (receiver/Src/main.c:124-136) minus ticks and rank */
+typedef struct uc_stats {
+  float   mag_max;        /* max magnitude in the two windows          */
+  float   mag_max_left;   /* window [n - bandwidth2, n)                */
+  float   mag_max_right;  /* window [0, bandwidth2)                    */
+  int32_t max_freq;       /* idx2freq of the winning peak              */
+  int32_t max_freq_left;
+  int32_t max_freq_right;
+  float   mag_mean;       /* noise floor the snr was computed against  */
+  float   snr;            /* (mag_max - mag_mean) / mag_mean           */
+} uc_stats;
+
+typedef struct uc_ctx uc_ctx;
+
+/* Fill *cfg with the shipping receiver's constants for `variant`. */
+int uc_default_config(int32_t variant, uc_config* cfg);
+
+int uc_create(const uc_config* cfg, uc_ctx** out);
+void uc_destroy(uc_ctx* ctx);
+
+/*
+ * One frame: n raw DFSDM words in, one symbol out.
+ * st (nullable) receives st[0] = up-chirp history, st[1] = down-chirp history
+ * (history[0] / history[1] of main(), receiver/Src/main.c:518-519).
+ * For the single-reference variants (COMPRESS, DECHIRP_DOWN, IQ) only st[0]
+ * is written and *symbol_out is UC_SYM_NONE.
+ */
+int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
+                     uint8_t* symbol_out, uc_stats st[2]);
+
+/*
+ * n_frames frames, frame i starting at element i*stride_elems of `frames`
+ * (stride_elems < n expresses the overlapping FIFO reads of the firmware,
+ * receiver/Src/main.c:447-451; stride_elems == 0 means n).
+ * mag_mean : NULL (cfg.mag_mean for all) or 2 floats per frame {up, down}.
+ * symbols  : n_frames bytes, nullable.
+ * stats    : 2 uc_stats per frame {up, down} for RX_REAL / SYNC_CPLX,
+ *            1 per frame otherwise; nullable.
+ * UC_IQ reads 26 samples of FIR history in front of every frame: frames must
+ * point 26 elements into the buffer (see uc_iq_halo()).
+ */
+int uc_process_batch(uc_ctx* ctx, const void* frames, int dtype,
+                     size_t n_frames, size_t stride_elems,
+                     const float* mag_mean, uint8_t* symbols, uc_stats* stats,
+                     void* hip_stream);
+
+/* number of uc_stats records uc_process_batch writes per frame (1 or 2) */
+int uc_stats_per_frame(const uc_ctx* ctx);
+
+/* samples of history UC_IQ needs in front of frame 0 (26), 0 for the others */
+int uc_iq_halo(const uc_ctx* ctx);
+
+/* copy a host copy of a reference table; returns the element count or <0 */
+int uc_get_table(const uc_ctx* ctx, int table_id, float* out, size_t cap);
+
+/* derived integers of main(): bandwidth, bandwidth2, idx_left_zero */
+int uc_get_windows(const uc_ctx* ctx, uint32_t* bandwidth, uint32_t* bandwidth2,
+                   uint32_t* idx_left_zero);
+
+/* idx2freq(), integer arithmetic -- receiver/Src/main.c:154-160 */
+int32_t uc_idx2freq(const uc_ctx* ctx, uint32_t idx);
+
+/* human-readable text of the last error on this thread ("" if none) */
+const char* uc_last_error(void);
+
+/* UC_ABI_VERSION of the loaded library */
+int uc_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* UCHIRP_H_ */

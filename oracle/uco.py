@@ -1,0 +1,197 @@
+"""ctypes binding of the CPU oracle (oracle/libuc_oracle.so).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg -- never from the product package.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "libuc_oracle.so")
+
+RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ = range(5)
+DTYPE_I32, DTYPE_F32 = 0, 1
+F32, F64 = 32, 64
+FLAG_LIBM_TRIG, FLAG_TRUE_DC = 1, 2
+TABLE_UP, TABLE_DOWN, TABLE_HANN, TABLE_H_UP, TABLE_H_DOWN, TABLE_CARRIER_C, TABLE_CARRIER_S, TABLE_FIR = range(8)
+
+
+class Config(C.Structure):
+    _fields_ = [("n", C.c_uint32), ("fs", C.c_float), ("f0", C.c_float), ("f1", C.c_float),
+                ("time_frame", C.c_float), ("phase_deg", C.c_float), ("snr_threshold", C.c_float),
+                ("mag_mean", C.c_float), ("carrier", C.c_float), ("variant", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+STATS_DTYPE = np.dtype([("mag_max", "<f4"), ("mag_max_left", "<f4"), ("mag_max_right", "<f4"),
+                        ("max_freq", "<i4"), ("max_freq_left", "<i4"), ("max_freq_right", "<i4"),
+                        ("mag_mean", "<f4"), ("snr", "<f4")])
+assert STATS_DTYPE.itemsize == 32
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("uc_oracle.c", "uc_oracle.h")]
+    if (not force and os.path.exists(_LIB)
+            and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in src)):
+        return _LIB
+    subprocess.check_call(["make", "-C", _HERE, "-B", "libuc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _LIB
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB)
+        L.uco_default_config.argtypes = [C.c_int32, C.POINTER(Config)]
+        L.uco_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        L.uco_destroy.argtypes = [C.c_void_p]
+        L.uco_destroy.restype = None
+        L.uco_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t,
+                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.uco_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+        L.uco_stats_per_frame.argtypes = [C.c_void_p]
+        L.uco_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.uco_get_windows.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 3
+        L.uco_idx2freq.argtypes = [C.c_void_p, C.c_uint32]
+        L.uco_idx2freq.restype = C.c_int32
+        L.uco_arm_cos_f32.argtypes = [C.c_float]
+        L.uco_arm_cos_f32.restype = C.c_float
+        L.uco_arm_sin_cos_f32.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        L.uco_arm_sin_cos_f32.restype = None
+        L.uco_arm_max_f32.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_float), C.POINTER(C.c_uint32)]
+        L.uco_arm_max_f32.restype = None
+        L.uco_rfft_fast_f32.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.uco_rfft_fast_f32.restype = None
+        L.uco_hann_periodic.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+        L.uco_hann_periodic.restype = None
+        _lib = L
+    return _lib
+
+
+def default_config(variant, **over):
+    cfg = Config()
+    rc = lib().uco_default_config(variant, C.byref(cfg))
+    if rc:
+        raise ValueError("uco_default_config rc=%d" % rc)
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Oracle:
+    """CPU restatement of the reference path for one variant/config."""
+
+    def __init__(self, variant=RX_REAL, **over):
+        self.cfg = default_config(variant, **over)
+        h = C.c_void_p()
+        rc = lib().uco_create(C.byref(self.cfg), C.byref(h))
+        if rc:
+            raise ValueError("uco_create rc=%d" % rc)
+        self._h = h
+        self.n = self.cfg.n
+        self.spf = lib().uco_stats_per_frame(h)
+        bw, bw2, ilz = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib().uco_get_windows(h, C.byref(bw), C.byref(bw2), C.byref(ilz))
+        self.bandwidth, self.bandwidth2, self.idx_left_zero = bw.value, bw2.value, ilz.value
+
+    def close(self):
+        if self._h:
+            lib().uco_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def table(self, tid):
+        buf = np.zeros(4 * self.n, np.float32)
+        cnt = lib().uco_get_table(self._h, tid, _ptr(buf), buf.size)
+        if cnt < 0:
+            raise ValueError("uco_get_table rc=%d" % cnt)
+        return buf[:cnt].copy()
+
+    def idx2freq(self, idx):
+        return lib().uco_idx2freq(self._h, int(idx))
+
+    def process(self, frames, n_frames=None, stride=0, mag_mean=None, precision=F64, threads=0,
+                halo=0):
+        """frames: 1-D or 2-D contiguous int32/float32 array.  Returns (symbols, stats)."""
+        a = np.ascontiguousarray(frames)
+        if a.dtype == np.int32:
+            dt = DTYPE_I32
+        elif a.dtype == np.float32:
+            dt = DTYPE_F32
+        else:
+            raise TypeError("frames must be int32 or float32")
+        flat = a.reshape(-1)
+        st = stride or self.n
+        if n_frames is None:
+            n_frames = (flat.size - halo - self.n) // st + 1 if flat.size >= self.n + halo else 0
+        if n_frames and halo + (n_frames - 1) * st + self.n > flat.size:
+            raise ValueError("frames buffer too small")
+        sym = np.empty(n_frames, np.uint8)
+        stats = np.zeros((n_frames, self.spf), STATS_DTYPE)
+        mm = None
+        if mag_mean is not None:
+            mm = np.ascontiguousarray(mag_mean, np.float32).reshape(n_frames, 2)
+        base = flat.ctypes.data + 4 * halo
+        rc = lib().uco_process_batch(self._h, C.c_void_p(base), dt, n_frames, st,
+                                     _ptr(mm) if mm is not None else None, _ptr(sym), _ptr(stats),
+                                     precision, threads)
+        if rc:
+            raise RuntimeError("uco_process_batch rc=%d" % rc)
+        return sym, stats
+
+    def spectrum(self, frame, precision=F64, halo=0):
+        a = np.ascontiguousarray(frame).reshape(-1)
+        dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
+        if a.dtype not in (np.int32, np.float32):
+            raise TypeError("frame must be int32 or float32")
+        out = np.zeros(self.n * (2 if self.spf == 2 else 1), np.float64)
+        rc = lib().uco_spectrum(self._h, C.c_void_p(a.ctypes.data + 4 * halo), dt, precision, _ptr(out))
+        if rc:
+            raise RuntimeError("uco_spectrum rc=%d" % rc)
+        return out.reshape(-1, self.n)
+
+
+def arm_cos(x):
+    return float(lib().uco_arm_cos_f32(float(x)))
+
+
+def arm_sin_cos(theta_deg):
+    s, c = C.c_float(), C.c_float()
+    lib().uco_arm_sin_cos_f32(float(theta_deg), C.byref(s), C.byref(c))
+    return s.value, c.value
+
+
+def arm_max(v):
+    v = np.ascontiguousarray(v, np.float32)
+    m, i = C.c_float(), C.c_uint32()
+    lib().uco_arm_max_f32(_ptr(v), v.size, C.byref(m), C.byref(i))
+    return m.value, i.value
+
+
+def rfft_fast(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().uco_rfft_fast_f32(_ptr(x), _ptr(out), x.size)
+    return out
+
+
+def hann_periodic(n, libm=False):
+    w = np.empty(n, np.float32)
+    lib().uco_hann_periodic(_ptr(w), n, 1 if libm else 0)
+    return w

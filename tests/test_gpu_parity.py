@@ -1,0 +1,255 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle.
+
+Bars (BASELINE.md section 4 / SURVEY.md section 8d):
+  * integer outputs (symbols, peak frequencies) bit-exact, except on frames
+    the ORACLE itself marks as near-ties (decision margin < 1e-3, or two window
+    bins within the magnitude tolerance of each other);
+  * window magnitudes within MAG_TOL = 2e-5 x the frame's peak magnitude of a
+    float64 evaluation of the same float32 inputs.
+"""
+import numpy as np
+import pytest
+
+import synth
+from oracle import uco
+
+pytestmark = pytest.mark.gpu
+
+MAG_TOL = 2e-5       # relative to the frame's largest window magnitude (float64 oracle)
+MARGIN = 1e-3        # decision margin below which a symbol is a declared near-tie
+
+
+@pytest.fixture(scope="module")
+def uchirp():
+    import uchirp as m
+    m.lib()
+    return m
+
+
+def _inv_freq(o, freqs):
+    """idx2freq is injective on the window bins: map frequencies back to indices."""
+    n = o.n
+    cand = list(range(0, o.bandwidth2 + 1)) + list(range(n - o.bandwidth2 - 1, n))
+    lut = {o.idx2freq(i): i for i in cand}
+    return np.array([lut[int(f)] for f in freqs])
+
+
+def _check_hist(o, frames, g, r, label):
+    """g, r: STATS arrays (n_frames,) of one history from GPU / oracle(f64)."""
+    scale = np.maximum(np.maximum(r["mag_max_left"], r["mag_max_right"]).astype(np.float64), 1e-30)
+    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+        err = np.abs(g[fld].astype(np.float64) - r[fld].astype(np.float64)) / scale
+        assert np.nanmax(err) <= MAG_TOL, "%s %s: rel err %.3g" % (label, fld, np.nanmax(err))
+    bad = np.nonzero((g["max_freq"] != r["max_freq"]) | (g["max_freq_left"] != r["max_freq_left"])
+                     | (g["max_freq_right"] != r["max_freq_right"]))[0]
+    return bad
+
+
+def _assert_peaks_are_ties(o, frames, bad, g, hist, label):
+    """An index mismatch is legal only if the oracle's float64 spectrum has the
+    GPU's bin within MAG_TOL of the oracle's own maximum (a genuine near-tie)."""
+    for f in bad:
+        spec = o.spectrum(frames[f])[0 if hist == 0 else 1]
+        for fld, lo, hi in (("max_freq_right", 0, o.bandwidth2), ("max_freq_left", o.idx_left_zero, o.n)):
+            gi = _inv_freq(o, [g[fld][f]])[0]
+            win = spec[lo:hi]
+            assert win.max() - spec[gi] <= MAG_TOL * win.max(), \
+                "%s frame %d %s: GPU bin %d is not a near-tie" % (label, f, fld, gi)
+
+
+@pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX])
+@pytest.mark.parametrize("snr_db", [None, 0.0, -10.0])
+def test_symbol_decision_matches_oracle(uchirp, variant, snr_db):
+    n_frames = 768
+    frames, bits = synth.make_frames(n_frames, seed=1234, snr_db=snr_db)
+    o = uco.Oracle(variant, mag_mean=1000.0)
+    e = uchirp.Engine(variant, mag_mean=1000.0)
+    assert (e.bandwidth, e.bandwidth2, e.idx_left_zero) == (o.bandwidth, o.bandwidth2, o.idx_left_zero)
+    rs, rst = o.process(frames, precision=uco.F64)
+    gs, gst = e.process(frames)
+    # symbols: bit-exact wherever the oracle's decision margin is >= MARGIN
+    su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+    margin = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30)
+    thr_close = (np.abs(su - 2.0) < 1e-3 * np.abs(su)) | (np.abs(sd - 2.0) < 1e-3 * np.abs(sd))
+    clear = (margin >= MARGIN) & ~thr_close
+    assert clear.sum() >= 0.98 * n_frames, "too many near-ties: %d" % (~clear).sum()
+    assert np.array_equal(gs[clear], rs[clear])
+    if snr_db is None or snr_db >= -10.0:
+        # the decoded bits are the transmitted bits (BER 0 at these SNRs for the
+        # pre-aligned per-frame decision)
+        assert (gs[clear] == bits[clear]).mean() > 0.97
+    for h in (0, 1):
+        bad = _check_hist(o, frames, gst[:, h], rst[:, h], "hist%d" % h)
+        assert len(bad) <= 0.02 * n_frames
+        _assert_peaks_are_ties(o, frames, bad, gst[:, h], h, "hist%d" % h)
+        np.testing.assert_array_equal(gst[:, h]["mag_mean"], rst[:, h]["mag_mean"])
+        snr_err = np.abs(gst[:, h]["snr"].astype(np.float64) - rst[:, h]["snr"]) / np.maximum(np.abs(rst[:, h]["snr"]), 1.0)
+        assert snr_err.max() < 1e-4
+
+
+def test_config1_single_up_chirp_frame(uchirp):
+    """BASELINE config 1: one noiseless up-chirp frame -> symbol 1, peak at bin 0."""
+    o = uco.Oracle(uco.RX_REAL)
+    x = (1000.0 * o.table(uco.TABLE_UP)).astype(np.float32)  # A*sin(theta_up), the reference's own table
+    e = uchirp.Engine(uchirp.RX_REAL)
+    gs, gst = e.process(x[None, :])
+    rs, rst = o.process(x[None, :])
+    assert gs[0] == rs[0] == uchirp.SYM_UP
+    assert gst[0, 0]["max_freq"] == rst[0, 0]["max_freq"] == 0
+    assert abs(gst[0, 0]["mag_max"] - rst[0, 0]["mag_max"]) <= MAG_TOL * rst[0, 0]["mag_max"]
+
+
+def test_tables_bit_identical_to_oracle(uchirp):
+    for variant in (uco.RX_REAL, uco.SYNC_CPLX, uco.DECHIRP_DOWN):
+        for flags in (0, uco.FLAG_LIBM_TRIG):
+            o = uco.Oracle(variant, flags=flags)
+            e = uchirp.Engine(variant, flags=flags)
+            for tid in (uco.TABLE_UP, uco.TABLE_DOWN, uco.TABLE_HANN):
+                a, b = e.table(tid), o.table(tid)
+                assert a.shape == b.shape and np.array_equal(a.view(np.uint32), b.view(np.uint32)), (variant, flags, tid)
+            for idx in (0, 1, 3, 155, 156, 1023, 1024, 1892, 2047):
+                assert e.idx2freq(idx) == o.idx2freq(idx)
+
+
+def test_int32_ingest_and_process_frame(uchirp):
+    frames, bits = synth.make_frames(64, seed=7, snr_db=0.0, dtype=np.int32)
+    assert frames.dtype == np.int32 and (frames % 256 == 0).all()
+    o = uco.Oracle(uco.RX_REAL, mag_mean=1e5)
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1e5)
+    rs, rst = o.process(frames)
+    gs, gst = e.process(frames)
+    assert np.array_equal(gs, rs)
+    assert np.array_equal(gs, bits)
+    assert len(_check_hist(o, frames, gst[:, 0], rst[:, 0], "i32")) == 0
+    # the one-frame entry point preserves process_frame(pcm_in -> symbol_out)
+    for f in (0, 5, 63):
+        sym, st = e.process_frame(frames[f], mag_mean=1e5)
+        assert sym == rs[f]
+        assert st[0]["max_freq"] == rst[f, 0]["max_freq"] and st[1]["max_freq"] == rst[f, 1]["max_freq"]
+        assert st[0]["mag_max"] == gst[f, 0]["mag_max"]
+
+
+def test_overlapping_fifo_reads_stride_256(uchirp):
+    """stride_elems < n reproduces dsp(sync_position) over the FIFO (main.c:447-451)."""
+    frames, _ = synth.make_frames(6, seed=3, snr_db=5.0)
+    stream = frames.reshape(-1)
+    o = uco.Oracle(uco.RX_REAL, mag_mean=500.0)
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=500.0)
+    for stride in (256, 512, 1):
+        nf = (stream.size - 2048) // stride + 1
+        nf = min(nf, 64)
+        rs, rst = o.process(stream, n_frames=nf, stride=stride)
+        gs, gst = e.process(stream, n_frames=nf, stride=stride)
+        su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+        clear = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30) >= MARGIN
+        assert np.array_equal(gs[clear], rs[clear])
+        bad = _check_hist(o, None, gst[:, 0], rst[:, 0], "stride%d" % stride)
+        assert len(bad) <= 2
+
+
+def test_per_frame_mag_mean(uchirp):
+    frames, _ = synth.make_frames(32, seed=11, snr_db=0.0)
+    rng = np.random.default_rng(5)
+    mm = rng.uniform(100.0, 1e6, size=(32, 2)).astype(np.float32)
+    o = uco.Oracle(uco.RX_REAL)
+    e = uchirp.Engine(uchirp.RX_REAL)
+    rs, rst = o.process(frames, mag_mean=mm)
+    gs, gst = e.process(frames, mag_mean=mm)
+    np.testing.assert_array_equal(gst["mag_mean"], mm)
+    np.testing.assert_array_equal(gst["mag_mean"], rst["mag_mean"])
+    su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+    clear = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30) >= MARGIN
+    assert np.array_equal(gs[clear], rs[clear])
+
+
+def test_edge_frames_zero_nan_inf_and_empty(uchirp):
+    o = uco.Oracle(uco.RX_REAL, mag_mean=1.0)
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1.0)
+    z = np.zeros((3, 2048), np.float32)
+    z[1, :] = np.nan
+    z[2, 100] = np.inf
+    rs, rst = o.process(z)
+    gs, gst = e.process(z)
+    assert np.array_equal(gs, rs)
+    # all-zero frame: every magnitude ties at 0 -> first index of each window wins
+    assert gst[0, 0]["max_freq_right"] == rst[0, 0]["max_freq_right"] == 0
+    assert gst[0, 0]["max_freq_left"] == rst[0, 0]["max_freq_left"] == o.idx2freq(o.idx_left_zero)
+    assert gst[0, 0]["mag_max"] == 0.0 and gst[0, 0]["snr"] == rst[0, 0]["snr"] == -1.0
+    assert gs[0] == uchirp.SYM_NONE
+    assert gs[1] == uchirp.SYM_NONE and np.isnan(gst[1, 0]["mag_max"]) and np.isnan(rst[1, 0]["mag_max"])
+    assert gst[1, 0]["max_freq_right"] == rst[1, 0]["max_freq_right"]
+    assert gst[1, 0]["max_freq_left"] == rst[1, 0]["max_freq_left"]
+    # empty batch is a no-op
+    s0, st0 = e.process(np.zeros((0, 2048), np.float32), n_frames=0)
+    assert s0.size == 0
+    with pytest.raises(uchirp.UchirpError):
+        uchirp._check(uchirp.lib().uc_process_batch(e._h, None, 1, 4, 0, None, None, None, None), "null frames")
+    with pytest.raises(uchirp.UchirpError):
+        uchirp._check(uchirp.lib().uc_process_batch(e._h, z.ctypes.data, 7, 1, 0, None, None, None, None), "bad dtype")
+
+
+def test_true_dc_flag_and_q2_default(uchirp):
+    """Q2: default mag[0] = hypot(X0, X[n/2]) as the packed RFFT gives; the flag selects |X0|."""
+    x = np.ones((1, 2048), np.float32)  # all the energy lands in the window around DC
+    x[0, ::2] += 0.5                    # and some at Nyquist
+    for flags in (0, uco.FLAG_TRUE_DC):
+        o = uco.Oracle(uco.RX_REAL, flags=flags)
+        e = uchirp.Engine(uchirp.RX_REAL, flags=flags)
+        rs, rst = o.process(x)
+        gs, gst = e.process(x)
+        assert len(_check_hist(o, x, gst[:, 0], rst[:, 0], "dc")) == 0
+        assert len(_check_hist(o, x, gst[:, 1], rst[:, 1], "dc")) == 0
+
+
+def test_dechirp_down_variant(uchirp):
+    o = uco.Oracle(uco.DECHIRP_DOWN)
+    e = uchirp.Engine(uchirp.DECHIRP_DOWN)
+    assert e.spf == o.spf == 1 and e.bandwidth2 == o.bandwidth2 == 160
+    frames, _ = synth.make_frames(96, seed=21, snr_db=0.0, fs=100000.0, f0=17000.0, f1=18000.0)
+    rs, rst = o.process(frames)
+    gs, gst = e.process(frames)
+    assert (gs == uchirp.SYM_NONE).all()
+    r, g = rst[:, 0], gst[:, 0]
+    scale = np.maximum(r["mag_max"].astype(np.float64), 1e-30)
+    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+        assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL
+    same = (g["max_freq_right"] == r["max_freq_right"]) & (g["max_freq_left"] == r["max_freq_left"])
+    assert same.mean() >= 0.98
+
+
+def test_device_tensors_async_and_properties_at_scale(uchirp):
+    """Size-independent properties on a large device-resident batch:
+    decode == transmitted bits, exact x2 linearity, shard-invariance."""
+    import torch
+    dev = torch.device("cuda:0")
+    n_frames = 1 << 16
+    up, down = synth.chirp_pair()
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)
+    bits = torch.randint(0, 2, (n_frames,), generator=g, device=dev, dtype=torch.int32)
+    tab = torch.tensor(np.stack([down, up]), dtype=torch.float32, device=dev)
+    frames = tab[bits.long()] + 1000.0 * torch.randn((n_frames, 2048), generator=g, device=dev)
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+    sym, st = e.process(frames)
+    torch.cuda.synchronize()
+    assert sym.dtype == torch.uint8 and sym.shape == (n_frames,)
+    assert (sym.int() == bits).float().mean().item() > 0.999
+    # linearity: doubling the input doubles every magnitude exactly (power of two)
+    sym2, st2 = e.process(frames * 2.0)
+    torch.cuda.synchronize()
+    a, b = uchirp.stats_from_tensor(st), uchirp.stats_from_tensor(st2)
+    np.testing.assert_array_equal(b["mag_max"], 2.0 * a["mag_max"])
+    np.testing.assert_array_equal(b["max_freq"], a["max_freq"])
+    # shard invariance: two halves == the whole (what the multi-GPU path relies on)
+    h = n_frames // 2
+    s_lo, _ = e.process(frames[:h])
+    s_hi, _ = e.process(frames[h:])
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([s_lo, s_hi]), sym)
+    # oracle spot-check on a slice of the same device-generated data
+    o = uco.Oracle(uco.RX_REAL, mag_mean=1000.0)
+    sl = frames[:256].cpu().numpy()
+    rs, rst = o.process(sl)
+    su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+    clear = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30) >= MARGIN
+    assert np.array_equal(sym[:256].cpu().numpy()[clear], rs[clear])

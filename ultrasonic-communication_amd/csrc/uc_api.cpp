@@ -1,0 +1,380 @@
+// uc_api.cpp -- the C-ABI of include/uchirp.h on top of the gfx950 kernels.
+// No CPU compute path exists here: without a usable HIP device uc_create fails.
+#include <errno.h>
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/uchirp.h"
+#include "uc_kernels.hpp"
+#include "uc_tables.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+int hip_fail(hipError_t e, const char* what) {
+  return fail(-EIO, "%s: %s", what, hipGetErrorString(e));
+}
+
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return 0;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    size_t want = bytes + bytes / 4 + 256;
+    hipError_t e = hipMalloc(&p, want);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(staging)");
+    cap = want;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+};
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  memset(&attr, 0, sizeof(attr));
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();  // clear the sticky "invalid value" of a plain host pointer
+    return false;
+  }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+
+}  // namespace
+
+struct uc_ctx {
+  uc_config cfg;
+  uc::Tables tab;
+  int device = 0;
+  int num_cu = 256;
+  // device-resident tables
+  float2* d_tab0 = nullptr;
+  float2* d_tab1 = nullptr;
+  float2* d_tw = nullptr;
+  float* d_aux = nullptr;  // variant-specific (COMPRESS: H_down packed; IQ: carrier/fir/...)
+  // staging for host-pointer calls
+  DevBuf s_frames, s_mm, s_sym, s_stats;
+  int band_blocks_per_cu[2] = {0, 0};
+};
+
+extern "C" {
+
+int uc_abi_version(void) { return UC_ABI_VERSION; }
+
+const char* uc_last_error(void) { return g_err.c_str(); }
+
+int uc_default_config(int32_t variant, uc_config* cfg) {
+  if (!cfg) return fail(-EINVAL, "uc_default_config: cfg is NULL");
+  memset(cfg, 0, sizeof(*cfg));
+  cfg->n = 2048;              // receiver/Inc/main.h:97
+  cfg->phase_deg = -90.0f;    // receiver/Src/chirp.c:43-44
+  cfg->snr_threshold = 2.0f;  // receiver/Inc/main.h:98
+  cfg->mag_mean = 1.0f;
+  cfg->carrier = 18000.0f;    // experiments/iq_modulation/Inc/iq_modem.h:10
+  cfg->variant = variant;
+  switch (variant) {
+    case UC_RX_REAL:
+    case UC_SYNC_CPLX:
+      cfg->fs = 78125.0f;  // 80 MHz / 32 / 32 / 1: receiver/Src/main.c:367-369, dfsdm.c:60-61,69
+      cfg->f0 = 16000.0f;  // receiver/Inc/chirp.h:18-19
+      cfg->f1 = 19000.0f;
+      cfg->time_frame = 0.0205f;  // receiver/Inc/chirp.h:16
+      return 0;
+    case UC_COMPRESS:
+    case UC_DECHIRP_DOWN:
+      cfg->fs = 100000.0f;  // Divider 25: experiments/chirp_compression_*/Src/dfsdm.c:73
+      cfg->f0 = 17000.0f;   // experiments/chirp_compression_*/Inc/chirp.h (F1, F2)
+      cfg->f1 = 18000.0f;
+      cfg->time_frame = 0.0f;  // n / fs
+      return 0;
+    case UC_IQ:
+      cfg->fs = 100000.0f;
+      cfg->f0 = 16000.0f;
+      cfg->f1 = 19000.0f;
+      cfg->time_frame = 0.0205f;
+      return 0;
+    default:
+      return fail(-EINVAL, "uc_default_config: unknown variant %d", (int)variant);
+  }
+}
+
+static int upload(void** dst, const void* src, size_t bytes) {
+  hipError_t e = hipMalloc(dst, bytes);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(table)");
+  e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(table)");
+  return 0;
+}
+
+int uc_create(const uc_config* cfg, uc_ctx** out) {
+  if (!cfg || !out) return fail(-EINVAL, "uc_create: NULL argument");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(-ENODEV, "uc_create: no HIP device (%s); this library has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  }
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(-ENODEV, "uc_create: device %d out of range [0,%d)", (int)cfg->device, ndev);
+  if (cfg->n != (uint32_t)uc::kN)
+    return fail(-ENOTSUP, "uc_create: n=%u unsupported (kernels are specialised for n=%d)", cfg->n, uc::kN);
+
+  uc_ctx* c = new (std::nothrow) uc_ctx();
+  if (!c) return fail(-ENOMEM, "uc_create: out of memory");
+  c->cfg = *cfg;
+  c->device = cfg->device;
+  int rc = uc::build_tables(*cfg, c->tab);
+  if (rc) {
+    delete c;
+    return fail(rc, "uc_create: invalid configuration (rc=%d)", rc);
+  }
+  if (cfg->variant != UC_IQ && cfg->variant != UC_COMPRESS && c->tab.bandwidth2 > 255) {
+    delete c;
+    return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 255-bin window the kernel evaluates",
+                c->tab.bandwidth2);
+  }
+  e = hipSetDevice(c->device);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail(e, "hipSetDevice");
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->num_cu = prop.multiProcessorCount;
+
+  const uint32_t n = cfg->n;
+  std::vector<float> tw;
+  uc::build_twiddles(n, tw);
+  rc = upload((void**)&c->d_tw, tw.data(), tw.size() * sizeof(float));
+
+  std::vector<float> t0(2 * (size_t)n, 0.0f), t1(2 * (size_t)n, 0.0f);
+  const uc::Tables& T = c->tab;
+  switch (cfg->variant) {
+    case UC_RX_REAL:
+      for (uint32_t i = 0; i < n; i++) {
+        t0[2 * i] = T.up[i] * T.hann[i];
+        t0[2 * i + 1] = T.down[i] * T.hann[i];
+      }
+      break;
+    case UC_DECHIRP_DOWN:
+      for (uint32_t i = 0; i < n; i++) t0[2 * i] = T.down[i] * T.hann[i];
+      break;
+    case UC_SYNC_CPLX:
+      for (uint32_t i = 0; i < n; i++) {
+        t0[2 * i] = T.up[2 * i] * T.hann[i];
+        t0[2 * i + 1] = T.up[2 * i + 1] * T.hann[i];
+        t1[2 * i] = T.down[2 * i] * T.hann[i];
+        t1[2 * i + 1] = T.down[2 * i + 1] * T.hann[i];
+      }
+      break;
+    default:
+      break;
+  }
+  if (!rc) rc = upload((void**)&c->d_tab0, t0.data(), t0.size() * sizeof(float));
+  if (!rc) rc = upload((void**)&c->d_tab1, t1.data(), t1.size() * sizeof(float));
+  if (rc) {
+    uc_destroy(c);
+    return rc;
+  }
+  *out = c;
+  return 0;
+}
+
+void uc_destroy(uc_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->d_tab0) (void)hipFree(c->d_tab0);
+  if (c->d_tab1) (void)hipFree(c->d_tab1);
+  if (c->d_tw) (void)hipFree(c->d_tw);
+  if (c->d_aux) (void)hipFree(c->d_aux);
+  c->s_frames.release();
+  c->s_mm.release();
+  c->s_sym.release();
+  c->s_stats.release();
+  delete c;
+}
+
+int uc_stats_per_frame(const uc_ctx* c) {
+  if (!c) return fail(-EINVAL, "uc_stats_per_frame: NULL ctx");
+  return (c->cfg.variant == UC_RX_REAL || c->cfg.variant == UC_SYNC_CPLX) ? 2 : 1;
+}
+
+int uc_iq_halo(const uc_ctx* c) {
+  if (!c) return fail(-EINVAL, "uc_iq_halo: NULL ctx");
+  return c->cfg.variant == UC_IQ ? uc::kFirTaps - 1 : 0;
+}
+
+int uc_get_windows(const uc_ctx* c, uint32_t* bw, uint32_t* bw2, uint32_t* ilz) {
+  if (!c) return fail(-EINVAL, "uc_get_windows: NULL ctx");
+  if (bw) *bw = c->tab.bandwidth;
+  if (bw2) *bw2 = c->tab.bandwidth2;
+  if (ilz) *ilz = c->tab.idx_left_zero;
+  return 0;
+}
+
+int uc_get_table(const uc_ctx* c, int id, float* out, size_t cap) {
+  if (!c || !out) return fail(-EINVAL, "uc_get_table: NULL argument");
+  const std::vector<float>* v = nullptr;
+  switch (id) {
+    case UC_TABLE_UP: v = &c->tab.up; break;
+    case UC_TABLE_DOWN: v = &c->tab.down; break;
+    case UC_TABLE_HANN: v = &c->tab.hann; break;
+    case UC_TABLE_H_UP: v = &c->tab.h_up; break;
+    case UC_TABLE_H_DOWN: v = &c->tab.h_down; break;
+    case UC_TABLE_CARRIER_C: v = &c->tab.carrier_c; break;
+    case UC_TABLE_CARRIER_S: v = &c->tab.carrier_s; break;
+    case UC_TABLE_FIR: v = &c->tab.fir; break;
+    default: return fail(-EINVAL, "uc_get_table: unknown table %d", id);
+  }
+  if (v->empty()) return fail(-ENOENT, "uc_get_table: table %d does not exist for this variant", id);
+  if (cap < v->size()) return fail(-ENOSPC, "uc_get_table: need %zu floats", v->size());
+  memcpy(out, v->data(), v->size() * sizeof(float));
+  return (int)v->size();
+}
+
+int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
+  if (!c) return 0;
+  const uint32_t n = c->cfg.n;
+  if (c->cfg.variant == UC_IQ)  // experiments/iq_modulation/Src/main.c:112-114
+    return (int32_t)(uint32_t)(c->cfg.fs * (float)idx / (float)n);
+  const uint32_t ifs = (uint32_t)(int32_t)c->cfg.fs;
+  if (idx < n / 2) return (int32_t)(ifs * idx / n);
+  return (int32_t)((ifs * (n - idx) / n) * 0xFFFFFFFFu);
+}
+
+int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
+                     const float* mag_mean, uint8_t* symbols, uc_stats* stats, void* hip_stream) {
+  if (!c) return fail(-EINVAL, "uc_process_batch: NULL ctx");
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32)
+    return fail(-EINVAL, "uc_process_batch: dtype %d is neither UC_DTYPE_I32 nor UC_DTYPE_F32", dtype);
+  if (n_frames == 0) return 0;
+  if (!frames) return fail(-EINVAL, "uc_process_batch: frames is NULL");
+  const uint32_t n = c->cfg.n;
+  if (stride_elems == 0) stride_elems = n;
+  const int variant = c->cfg.variant;
+  if (variant == UC_COMPRESS || variant == UC_IQ)
+    return fail(-ENOSYS, "uc_process_batch: variant %d has no kernel yet", variant);
+  const int spf = uc_stats_per_frame(c);
+  const int halo = uc_iq_halo(c);
+
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+
+  const size_t span = (n_frames - 1) * stride_elems + n + (size_t)halo;  // elements touched
+  bool any_host_out = false;
+
+  const void* d_frames = frames;
+  if (!is_device_ptr(frames)) {
+    int rc = c->s_frames.ensure(span * 4);
+    if (rc) return rc;
+    const char* src = (const char*)frames - (size_t)halo * 4;
+    e = hipMemcpyAsync(c->s_frames.p, src, span * 4, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(frames)");
+    d_frames = (const char*)c->s_frames.p + (size_t)halo * 4;
+  }
+  const float* d_mm = mag_mean;
+  if (mag_mean && !is_device_ptr(mag_mean)) {
+    int rc = c->s_mm.ensure(n_frames * 2 * sizeof(float));
+    if (rc) return rc;
+    e = hipMemcpyAsync(c->s_mm.p, mag_mean, n_frames * 2 * sizeof(float), hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(mag_mean)");
+    d_mm = (const float*)c->s_mm.p;
+  }
+  uint8_t* d_sym = symbols;
+  if (symbols && !is_device_ptr(symbols)) {
+    int rc = c->s_sym.ensure(n_frames);
+    if (rc) return rc;
+    d_sym = (uint8_t*)c->s_sym.p;
+    any_host_out = true;
+  }
+  uc_stats* d_stats = stats;
+  if (stats && !is_device_ptr(stats)) {
+    int rc = c->s_stats.ensure(n_frames * (size_t)spf * sizeof(uc_stats));
+    if (rc) return rc;
+    d_stats = (uc_stats*)c->s_stats.p;
+    any_host_out = true;
+  }
+
+  uc::BandParams p;
+  memset(&p, 0, sizeof(p));
+  p.frames = d_frames;
+  p.n_frames = n_frames;
+  p.stride = stride_elems;
+  p.tab0 = c->d_tab0;
+  p.tab1 = c->d_tab1;
+  p.tw = c->d_tw;
+  p.mag_mean = d_mm;
+  p.symbols = d_sym;
+  p.stats = d_stats;
+  p.mag_mean_scalar = c->cfg.mag_mean;
+  p.snr_threshold = c->cfg.snr_threshold;
+  p.bw2 = c->tab.bandwidth2;
+  p.ifs = (uint32_t)(int32_t)c->cfg.fs;
+  p.true_dc = (c->cfg.flags & UC_FLAG_TRUE_DC) ? 1u : 0u;
+  p.single = (variant == UC_DECHIRP_DOWN) ? 1u : 0u;
+  const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx : uc::kModeRxReal;
+  int& bpc = c->band_blocks_per_cu[mode];
+  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype);
+  size_t grid = (size_t)c->num_cu * (size_t)bpc;
+  if (grid > n_frames) grid = n_frames;
+  int lrc = uc::launch_band(mode, dtype, p, (int)grid, stream);
+  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
+
+  if (any_host_out) {
+    if (symbols && d_sym != symbols) {
+      e = hipMemcpyAsync(symbols, d_sym, n_frames, hipMemcpyDeviceToHost, stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(symbols)");
+    }
+    if (stats && d_stats != stats) {
+      e = hipMemcpyAsync(stats, d_stats, n_frames * (size_t)spf * sizeof(uc_stats), hipMemcpyDeviceToHost, stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(stats)");
+    }
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  }
+  return 0;
+}
+
+int uc_process_frame(uc_ctx* c, const int32_t* pcm_in, float mag_mean, uint8_t* symbol_out, uc_stats st[2]) {
+  if (!c || !pcm_in) return fail(-EINVAL, "uc_process_frame: NULL argument");
+  if (uc_iq_halo(c)) return fail(-EINVAL, "uc_process_frame: UC_IQ needs FIR history, use uc_process_batch");
+  float mm[2] = {mag_mean, mag_mean};
+  uint8_t sym = UC_SYM_NONE;
+  uc_stats tmp[2];
+  memset(tmp, 0, sizeof(tmp));
+  int rc = uc_process_batch(c, pcm_in, UC_DTYPE_I32, 1, c->cfg.n, mm, &sym, tmp, nullptr);
+  if (rc) return rc;
+  if (symbol_out) *symbol_out = sym;
+  if (st) memcpy(st, tmp, sizeof(uc_stats) * (size_t)uc_stats_per_frame(c));
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,40 @@
+// uc_kernels.hpp -- launch interface between the C-ABI (uc_api.cpp) and the
+// gfx950 kernels (uc_band_kernel.hip, uc_full_kernel.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/uchirp.h"
+
+namespace uc {
+
+constexpr int kN = 2048;          // frame length all kernels are specialised for
+constexpr int kBandThreads = 128; // one 16x16x8 frame per 2-wave workgroup
+
+// Band pipeline: RX_REAL, SYNC_CPLX, DECHIRP_DOWN (windows around DC only).
+struct BandParams {
+  const void* frames;     // device, int32 or float
+  size_t n_frames;
+  size_t stride;          // elements between frame starts
+  const float2* tab0;     // RX_REAL: (up*hann, down*hann)[n]   CPLX: (cos,sin)*hann of UP
+  const float2* tab1;     // CPLX: (cos,sin)*hann of DOWN
+  const float2* tw;       // exp(-2 pi i k / 2048), k < 2048
+  const float* mag_mean;  // device, 2 per frame {up,down}, or nullptr
+  uint8_t* symbols;       // device or nullptr
+  uc_stats* stats;        // device or nullptr
+  float mag_mean_scalar;
+  float snr_threshold;
+  uint32_t bw2;           // window length (<= 255)
+  uint32_t ifs;           // (uint32_t)(int32_t)fs for idx2freq
+  uint32_t true_dc;       // UC_FLAG_TRUE_DC
+  uint32_t single;        // 1: only history[0] exists (DECHIRP_DOWN), raw-index stats
+};
+
+enum BandMode { kModeRxReal = 0, kModeCplx = 1 };
+
+// returns hipError_t as int
+int launch_band(int mode, int dtype, const BandParams& p, int grid, hipStream_t stream);
+int band_max_blocks_per_cu(int mode, int dtype);
+
+}  // namespace uc

@@ -1,0 +1,236 @@
+"""uchirp -- thin ctypes binding of libuchirp.so (include/uchirp.h).
+
+The compute path is the HIP library and nothing else: if libuchirp.so is
+missing or no MI355X is visible, importing works but creating an Engine raises
+(there is no CPU fallback; the CPU restatement under oracle/ is test
+infrastructure and is never imported from here).
+
+PyTorch is optional plumbing: device tensors are passed by data_ptr() and run
+on torch's current HIP stream; numpy arrays go through the library's own
+staging copies.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)  # ultrasonic-communication_amd/
+LIB_PATH = os.path.join(_ROOT, "libuchirp.so")
+
+RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ = range(5)
+DOWN_CHIRP, UP_CHIRP = 0, 1
+DTYPE_I32, DTYPE_F32 = 0, 1
+SYM_DOWN, SYM_UP, SYM_NONE = 0, 1, 0xFF
+FLAG_LIBM_TRIG, FLAG_TRUE_DC = 1, 2
+(TABLE_UP, TABLE_DOWN, TABLE_HANN, TABLE_H_UP, TABLE_H_DOWN, TABLE_CARRIER_C, TABLE_CARRIER_S,
+ TABLE_FIR) = range(8)
+
+EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", "uc_destroy",
+           "uc_process_frame", "uc_process_batch", "uc_stats_per_frame", "uc_iq_halo",
+           "uc_get_table", "uc_get_windows", "uc_idx2freq"]
+
+
+class Config(C.Structure):
+    """struct uc_config (include/uchirp.h)."""
+    _fields_ = [("n", C.c_uint32), ("fs", C.c_float), ("f0", C.c_float), ("f1", C.c_float),
+                ("time_frame", C.c_float), ("phase_deg", C.c_float), ("snr_threshold", C.c_float),
+                ("mag_mean", C.c_float), ("carrier", C.c_float), ("variant", C.c_int32),
+                ("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+STATS_DTYPE = np.dtype([("mag_max", "<f4"), ("mag_max_left", "<f4"), ("mag_max_right", "<f4"),
+                        ("max_freq", "<i4"), ("max_freq_left", "<i4"), ("max_freq_right", "<i4"),
+                        ("mag_mean", "<f4"), ("snr", "<f4")])
+
+
+class UchirpError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """Compile libuchirp.so for gfx950 with hipcc (in-tree)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", _ROOT] + (["-B"] if force else []) + ["libuchirp.so"])
+    else:
+        subprocess.check_call(["make", "-C", _ROOT, "libuchirp.so"], stdout=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libuchirp.so; raises UchirpError if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise UchirpError("libuchirp.so not built: run `make -C %s` (hipcc, gfx950); "
+                          "there is no CPU fallback" % _ROOT)
+    L = C.CDLL(LIB_PATH)
+    L.uc_abi_version.restype = C.c_int
+    L.uc_last_error.restype = C.c_char_p
+    L.uc_default_config.argtypes = [C.c_int32, C.POINTER(Config)]
+    L.uc_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    L.uc_destroy.argtypes = [C.c_void_p]
+    L.uc_destroy.restype = None
+    L.uc_process_frame.argtypes = [C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]
+    L.uc_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.uc_stats_per_frame.argtypes = [C.c_void_p]
+    L.uc_iq_halo.argtypes = [C.c_void_p]
+    L.uc_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.uc_get_windows.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 3
+    L.uc_idx2freq.argtypes = [C.c_void_p, C.c_uint32]
+    L.uc_idx2freq.restype = C.c_int32
+    _lib = L
+    return L
+
+
+def _check(rc, what):
+    if rc < 0:
+        msg = lib().uc_last_error()
+        raise UchirpError("%s failed (rc=%d): %s" % (what, rc, msg.decode() if msg else ""))
+    return rc
+
+
+def default_config(variant=RX_REAL, **over):
+    cfg = Config()
+    _check(lib().uc_default_config(variant, C.byref(cfg)), "uc_default_config")
+    for k, v in over.items():
+        setattr(cfg, k, v)
+    return cfg
+
+
+def _is_torch(x):
+    return type(x).__module__.startswith("torch")
+
+
+class Engine:
+    """One uc_ctx: the receiver's DSP state for one variant on one MI355X."""
+
+    def __init__(self, variant=RX_REAL, device=0, **over):
+        self.cfg = default_config(variant, device=device, **over)
+        h = C.c_void_p()
+        _check(lib().uc_create(C.byref(self.cfg), C.byref(h)), "uc_create")
+        self._h = h
+        self.n = int(self.cfg.n)
+        self.variant = variant
+        self.device = device
+        self.spf = lib().uc_stats_per_frame(h)
+        self.halo = lib().uc_iq_halo(h)
+        bw, bw2, ilz = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        lib().uc_get_windows(h, C.byref(bw), C.byref(bw2), C.byref(ilz))
+        self.bandwidth, self.bandwidth2, self.idx_left_zero = bw.value, bw2.value, ilz.value
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def table(self, tid):
+        buf = np.zeros(4 * self.n, np.float32)
+        cnt = _check(lib().uc_get_table(self._h, tid, buf.ctypes.data_as(C.c_void_p), buf.size),
+                     "uc_get_table")
+        return buf[:cnt].copy()
+
+    def idx2freq(self, idx):
+        return lib().uc_idx2freq(self._h, int(idx))
+
+    def process_frame(self, pcm, mag_mean=1.0):
+        """uc_process_frame: n int32 DFSDM words -> (symbol, stats[spf])."""
+        pcm = np.ascontiguousarray(pcm, np.int32)
+        if pcm.size != self.n:
+            raise ValueError("frame must hold %d samples" % self.n)
+        sym = C.c_uint8(SYM_NONE)
+        st = np.zeros(2, STATS_DTYPE)
+        _check(lib().uc_process_frame(self._h, pcm.ctypes.data_as(C.c_void_p), float(mag_mean),
+                                      C.byref(sym), st.ctypes.data_as(C.c_void_p)), "uc_process_frame")
+        return sym.value, st[:self.spf]
+
+    def process(self, frames, n_frames=None, stride=0, mag_mean=None, want_symbols=True,
+                want_stats=True, symbols_out=None, stats_out=None, stream=None, halo=None):
+        """uc_process_batch.
+
+        frames: numpy int32/float32 array (host path, synchronous) or a torch
+        device tensor (device path, asynchronous on `stream` / torch's current
+        stream; outputs are torch tensors on the same device).
+        """
+        halo = self.halo if halo is None else halo
+        st = stride or self.n
+        if _is_torch(frames):
+            import torch
+            t = frames
+            if not t.is_contiguous():
+                raise ValueError("frames tensor must be contiguous")
+            if t.dtype == torch.int32:
+                dt = DTYPE_I32
+            elif t.dtype == torch.float32:
+                dt = DTYPE_F32
+            else:
+                raise TypeError("frames must be int32 or float32")
+            total = t.numel()
+            if n_frames is None:
+                n_frames = (total - halo - self.n) // st + 1 if total >= self.n + halo else 0
+            if n_frames and halo + (n_frames - 1) * st + self.n > total:
+                raise ValueError("frames tensor too small for %d frames" % n_frames)
+            dev = t.device
+            if dev.type != "cuda":
+                raise ValueError("torch frames must live on the GPU (numpy arrays take the host path)")
+            sym = symbols_out
+            if sym is None and want_symbols:
+                sym = torch.empty(n_frames, dtype=torch.uint8, device=dev)
+            stt = stats_out
+            if stt is None and want_stats:
+                stt = torch.empty((n_frames, self.spf, 8), dtype=torch.float32, device=dev)
+            mm_ptr = None
+            if mag_mean is not None:
+                mm = mag_mean.to(device=dev, dtype=torch.float32).contiguous()
+                if mm.numel() != 2 * n_frames:
+                    raise ValueError("mag_mean must hold 2 floats per frame")
+                mm_ptr = C.c_void_p(mm.data_ptr())
+            if stream is None:
+                stream = torch.cuda.current_stream(dev).cuda_stream
+            _check(lib().uc_process_batch(self._h, C.c_void_p(t.data_ptr() + 4 * halo), dt, n_frames, st,
+                                          mm_ptr,
+                                          C.c_void_p(sym.data_ptr()) if sym is not None else None,
+                                          C.c_void_p(stt.data_ptr()) if stt is not None else None,
+                                          C.c_void_p(stream)), "uc_process_batch")
+            return sym, stt
+        a = np.ascontiguousarray(frames)
+        if a.dtype == np.int32:
+            dt = DTYPE_I32
+        elif a.dtype == np.float32:
+            dt = DTYPE_F32
+        else:
+            raise TypeError("frames must be int32 or float32")
+        flat = a.reshape(-1)
+        if n_frames is None:
+            n_frames = (flat.size - halo - self.n) // st + 1 if flat.size >= self.n + halo else 0
+        if n_frames and halo + (n_frames - 1) * st + self.n > flat.size:
+            raise ValueError("frames buffer too small for %d frames" % n_frames)
+        sym = np.full(n_frames, SYM_NONE, np.uint8) if want_symbols else None
+        stt = np.zeros((n_frames, self.spf), STATS_DTYPE) if want_stats else None
+        mm = None
+        if mag_mean is not None:
+            mm = np.ascontiguousarray(mag_mean, np.float32).reshape(n_frames, 2)
+        _check(lib().uc_process_batch(self._h, C.c_void_p(flat.ctypes.data + 4 * halo), dt, n_frames, st,
+                                      mm.ctypes.data_as(C.c_void_p) if mm is not None else None,
+                                      sym.ctypes.data_as(C.c_void_p) if sym is not None else None,
+                                      stt.ctypes.data_as(C.c_void_p) if stt is not None else None,
+                                      None), "uc_process_batch")
+        return sym, stt
+
+
+def stats_from_tensor(t):
+    """View a (n_frames, spf, 8) float32 torch stats tensor as a numpy STATS_DTYPE array."""
+    a = t.detach().cpu().numpy()
+    return a.view(STATS_DTYPE).reshape(a.shape[0], a.shape[1])
