@@ -66,6 +66,14 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # One process must hold ONE HIP runtime.  PyTorch-ROCm wheels bundle their own
+    # libamdhip64; if libuchirp.so pulled in /opt/rocm's copy first, a later
+    # `import torch` would initialise a second runtime and one of the two loses
+    # the device.  Importing torch first makes both bind to the same runtime.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise UchirpError("libuchirp.so not built: run `make -C %s` (hipcc, gfx950); "
                           "there is no CPU fallback" % _ROOT)
