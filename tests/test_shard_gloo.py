@@ -1,0 +1,78 @@
+"""N > 1 path on CPU: world_size-2 gloo.  The partition + symbol gather are the
+product code (uchirp.shard); the per-rank compute is stood in by the oracle
+(tests may use it) because the HIP kernels need a GPU."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+for p in (ROOT, os.path.join(ROOT, "ultrasonic-communication_amd"), HERE):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+from uchirp import shard  # noqa: E402
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_partition_covers_every_frame_once():
+    for n in (0, 1, 7, 8, 9, 1000, 1 << 20):
+        for w in (1, 2, 3, 4, 8):
+            spans = [shard.partition(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (l0, h0), (l1, h1) in zip(spans, spans[1:]):
+                assert h0 == l1
+            sizes = [h - l for l, h in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert shard.frame_span(4, 8, 2048, 256) == (1024, 7 * 256 + 2048)
+    assert shard.frame_span(4, 8, 2048, 2048, halo=26) == (4 * 2048 - 26, 8 * 2048)
+    assert shard.symbols_to_bytes([0, 1, 0, 0, 1, 0, 0, 0, 0, 1, 1, 0, 1, 0, 0, 1]) == b"Hi"
+
+
+def _worker(rank, world, port, n_frames, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import synth
+        from oracle import uco
+        frames, bits = synth.make_frames(n_frames, seed=42, snr_db=0.0)
+        lo, hi = shard.partition(n_frames, world, rank)
+        o = uco.Oracle(uco.RX_REAL, mag_mean=1000.0)
+        sym, _ = o.process(frames[lo:hi], precision=uco.F32, threads=1)
+        full = shard.gather_symbols(torch.from_numpy(sym), n_frames, dist)
+        ref, _ = o.process(frames, precision=uco.F32, threads=1)
+        ok = bool(np.array_equal(full.numpy(), ref)) and full.numel() == n_frames
+        q.put((rank, ok, int((full.numpy() == bits).sum())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_frames", [64, 37])
+def test_frame_sharded_decode_with_symbol_gather_world2(n_frames):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_frames, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(cnt == n_frames for _, _, cnt in res)  # 0 dB: decoded == transmitted on every rank

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -80,6 +81,8 @@ struct uc_ctx {
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
   int band_blocks_per_cu[2] = {0, 0};
+  int band_waves = 2;     // tuning knobs (env UC_BAND_WAVES / UC_GRID): not part of the ABI
+  int grid_override = 0;
 };
 
 extern "C" {
@@ -150,6 +153,11 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   if (!c) return fail(-ENOMEM, "uc_create: out of memory");
   c->cfg = *cfg;
   c->device = cfg->device;
+  if (const char* w = getenv("UC_BAND_WAVES")) {
+    const int v = atoi(w);
+    if (v >= 2 && v <= 4) c->band_waves = v;
+  }
+  if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
   int rc = uc::build_tables(*cfg, c->tab);
   if (rc) {
     delete c;
@@ -342,10 +350,11 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   p.single = (variant == UC_DECHIRP_DOWN) ? 1u : 0u;
   const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx : uc::kModeRxReal;
   int& bpc = c->band_blocks_per_cu[mode];
-  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype);
+  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, c->band_waves);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;
+  if (c->grid_override > 0) grid = (size_t)c->grid_override;
   if (grid > n_frames) grid = n_frames;
-  int lrc = uc::launch_band(mode, dtype, p, (int)grid, stream);
+  int lrc = uc::launch_band(mode, dtype, c->band_waves, p, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
 
   if (any_host_out) {

@@ -133,8 +133,8 @@ __device__ __forceinline__ void store_hist(uc_stats* dst, const Hist& h, float m
   d[1] = b;
 }
 
-template <int MODE, int DTYPE>
-__global__ __launch_bounds__(T, 2) void band_kernel(const BandParams p) {
+template <int MODE, int DTYPE, int WAVES>
+__global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   float* mag0 = lds + kMagOff;        // RX_REAL: |A[k]| (up)   CPLX: |Z[k]|
   float* mag1 = lds + kMagOff + 256;  // RX_REAL: |B[k]| (down) CPLX: |Z[n-k]|
@@ -372,31 +372,49 @@ __global__ __launch_bounds__(T, 2) void band_kernel(const BandParams p) {
 
 }  // namespace
 
-int launch_band(int mode, int dtype, const BandParams& p, int grid, hipStream_t stream) {
-  if (grid <= 0) return (int)hipSuccess;
-  dim3 g((unsigned)grid), b((unsigned)T);
-  if (mode == kModeRxReal) {
-    if (dtype == UC_DTYPE_I32) hipLaunchKernelGGL((band_kernel<kModeRxReal, UC_DTYPE_I32>), g, b, 0, stream, p);
-    else hipLaunchKernelGGL((band_kernel<kModeRxReal, UC_DTYPE_F32>), g, b, 0, stream, p);
-  } else {
-    if (dtype == UC_DTYPE_I32) hipLaunchKernelGGL((band_kernel<kModeCplx, UC_DTYPE_I32>), g, b, 0, stream, p);
-    else hipLaunchKernelGGL((band_kernel<kModeCplx, UC_DTYPE_F32>), g, b, 0, stream, p);
-  }
+template <int MODE, int DTYPE, int WAVES>
+static int launch_one(const BandParams& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
   return (int)hipGetLastError();
 }
 
-int band_max_blocks_per_cu(int mode, int dtype) {
+template <int MODE, int DTYPE, int WAVES>
+static int occupancy_one() {
   int nb = 0;
-  hipError_t e;
-  if (mode == kModeRxReal) {
-    if (dtype == UC_DTYPE_I32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<kModeRxReal, UC_DTYPE_I32>, T, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<kModeRxReal, UC_DTYPE_F32>, T, 0);
-  } else {
-    if (dtype == UC_DTYPE_I32) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<kModeCplx, UC_DTYPE_I32>, T, 0);
-    else e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<kModeCplx, UC_DTYPE_F32>, T, 0);
-  }
-  if (e != hipSuccess || nb <= 0) nb = 4;
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES>, T, 0);
+  if (e != hipSuccess || nb <= 0) nb = 2 * WAVES;
   return nb;
+}
+
+#define UC_DISPATCH(FN, ...)                                                              \
+  do {                                                                                    \
+    if (mode == kModeRxReal) {                                                            \
+      if (dtype == UC_DTYPE_I32) {                                                        \
+        if (waves == 3) return FN<kModeRxReal, UC_DTYPE_I32, 3>(__VA_ARGS__);             \
+        if (waves == 4) return FN<kModeRxReal, UC_DTYPE_I32, 4>(__VA_ARGS__);             \
+        return FN<kModeRxReal, UC_DTYPE_I32, 2>(__VA_ARGS__);                             \
+      }                                                                                   \
+      if (waves == 3) return FN<kModeRxReal, UC_DTYPE_F32, 3>(__VA_ARGS__);               \
+      if (waves == 4) return FN<kModeRxReal, UC_DTYPE_F32, 4>(__VA_ARGS__);               \
+      return FN<kModeRxReal, UC_DTYPE_F32, 2>(__VA_ARGS__);                               \
+    }                                                                                     \
+    if (dtype == UC_DTYPE_I32) {                                                          \
+      if (waves == 3) return FN<kModeCplx, UC_DTYPE_I32, 3>(__VA_ARGS__);                 \
+      if (waves == 4) return FN<kModeCplx, UC_DTYPE_I32, 4>(__VA_ARGS__);                 \
+      return FN<kModeCplx, UC_DTYPE_I32, 2>(__VA_ARGS__);                                 \
+    }                                                                                     \
+    if (waves == 3) return FN<kModeCplx, UC_DTYPE_F32, 3>(__VA_ARGS__);                   \
+    if (waves == 4) return FN<kModeCplx, UC_DTYPE_F32, 4>(__VA_ARGS__);                   \
+    return FN<kModeCplx, UC_DTYPE_F32, 2>(__VA_ARGS__);                                   \
+  } while (0)
+
+int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream) {
+  if (grid <= 0) return (int)hipSuccess;
+  UC_DISPATCH(launch_one, p, grid, stream);
+}
+
+int band_max_blocks_per_cu(int mode, int dtype, int waves) {
+  UC_DISPATCH(occupancy_one);
 }
 
 }  // namespace uc

@@ -34,7 +34,8 @@ struct BandParams {
 enum BandMode { kModeRxReal = 0, kModeCplx = 1 };
 
 // returns hipError_t as int
-int launch_band(int mode, int dtype, const BandParams& p, int grid, hipStream_t stream);
-int band_max_blocks_per_cu(int mode, int dtype);
+// `waves` = min waves per SIMD the kernel was compiled for (2, 3 or 4): a tuning knob
+int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
+int band_max_blocks_per_cu(int mode, int dtype, int waves);
 
 }  // namespace uc
