@@ -163,9 +163,9 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     delete c;
     return fail(rc, "uc_create: invalid configuration (rc=%d)", rc);
   }
-  if (cfg->variant != UC_IQ && cfg->variant != UC_COMPRESS && c->tab.bandwidth2 > 255) {
+  if (cfg->variant != UC_IQ && cfg->variant != UC_COMPRESS && c->tab.bandwidth2 > 191) {
     delete c;
-    return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 255-bin window the kernel evaluates",
+    return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 191-bin window the kernel evaluates",
                 c->tab.bandwidth2);
   }
   e = hipSetDevice(c->device);
@@ -348,6 +348,8 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   p.ifs = (uint32_t)(int32_t)c->cfg.fs;
   p.true_dc = (c->cfg.flags & UC_FLAG_TRUE_DC) ? 1u : 0u;
   p.single = (variant == UC_DECHIRP_DOWN) ? 1u : 0u;
+  p.debug = nullptr;
+  if (const char* d = getenv("UC_DEBUG_PTR")) p.debug = (unsigned long long*)strtoull(d, nullptr, 0);
   const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx : uc::kModeRxReal;
   int& bpc = c->band_blocks_per_cu[mode];
   if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, c->band_waves);

@@ -11,44 +11,87 @@
 //
 // Design (MI355X): one 2-wave workgroup transforms one frame at a time and
 // walks the batch persistently.  The 2048-point transform is 16 x 16 x 8
-// Stockham: both radix-16 passes are register-resident, the two exchanges go
-// through a 16 KiB LDS tile (XOR-swizzled so that every ds_write_b64 /
+// Stockham: both radix-16 passes are register-resident and written in packed
+// fp32 (uc_pk.hpp: one complex number = one VGPR pair, every butterfly add,
+// rotation and twiddle product is 1-2 v_pk_* instructions), the two exchanges
+// go through a 16 KiB LDS tile (XOR-swizzled so that every ds_write_b64 /
 // ds_read_b64 lane group is conflict-free), and the last radix-8 pass is
 // evaluated only for bins 0..bandwidth2 and their mirror images -- the only
 // bins dsp() looks at.  RX_REAL: both real references ride in one complex FFT
 // (re = x*up*hann, im = x*down*hann) and are separated by Hermitian symmetry
 // inside the pruned last pass.  HBM traffic is the frame itself (8 KiB) plus
 // one symbol byte; the window*chirp table (16 KiB) lives in VGPRs, twiddles too.
-#include "uc_fft.hpp"
 #include "uc_kernels.hpp"
+#include "uc_pk.hpp"
 
 namespace uc {
 
 namespace {
 
 constexpr int T = kBandThreads;  // 128
-constexpr int kMagOff = 2 * kN;  // floats: two magnitude arrays of 256 after the data tile
-constexpr int kResOff = kMagOff + 512;
-constexpr int kLdsFloats = kResOff + 16;
+// LDS: the 2048-point complex tile, then a ring of per-frame window partials that a
+// 64-lane finaliser drains once per 64 frames.
+constexpr int kRingFrames = 64;
+constexpr int kRingStride = 13;  // 2 waves x 6 words + 1 pad word (conflict-free lane-strided reads)
+constexpr int kRingOff = 2 * kN;
+constexpr int kLdsFloats = kRingOff + kRingFrames * kRingStride;
+
+constexpr float kSqrtHalfF = 0.70710678118654752440f;
+constexpr float kCos8 = 0.92387953251128675613f;   // cos(pi/8)
+constexpr float kSin8 = 0.38268343236508977173f;   // sin(pi/8)
+constexpr float kCos16 = 0.98078528040323044913f;  // cos(pi/16)
+constexpr float kSin16 = 0.19509032201612826785f;  // sin(pi/16)
 
 template <int DTYPE>
-__device__ __forceinline__ float ld_sample(const void* base, size_t idx) {
-  if (DTYPE == UC_DTYPE_I32) return (float)(reinterpret_cast<const int32_t*>(base)[idx]);
+__device__ __forceinline__ float ld_raw(const void* base, size_t idx) {
+  // raw 32-bit word; int32 words are converted when consumed (the ISR's (float) cast)
   return reinterpret_cast<const float*>(base)[idx];
 }
-
-__device__ __forceinline__ cf lds_ld(const float* lds, int cidx) {
-  const float2 v = *reinterpret_cast<const float2*>(lds + 2 * cidx);
-  return mk(v.x, v.y);
-}
-__device__ __forceinline__ void lds_st(float* lds, int cidx, cf v) {
-  *reinterpret_cast<float2*>(lds + 2 * cidx) = make_float2(v.re, v.im);
+template <int DTYPE>
+__device__ __forceinline__ v2f cvt_pair(v2f raw) {
+  if (DTYPE == UC_DTYPE_I32) return mkv((float)__float_as_int(raw.x), (float)__float_as_int(raw.y));
+  return raw;
 }
 
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, __shfl_xor(v, m, 64));
-  return v;
+__device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
+  return *reinterpret_cast<const v2f*>(lds + 2 * cidx);
+}
+__device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
+  *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
+}
+
+// ---- wave-wide reductions without LDS ----------------------------------------
+// Six DPP steps (row_ror 1/2/4/8 make every lane of a 16-lane row hold the row
+// result, row_bcast:15 / :31 fold the rows into lane 63) and one v_readlane.
+// hipcc does not see inside asm, so each step carries the 2 wait states a DPP
+// read of a just-written VGPR needs (s_nop 1).
+#define UC_DPP_REDUCE(OP, v)                                                                       \
+  do {                                                                                             \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));         \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));         \
+  } while (0)
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+  UC_DPP_REDUCE("v_max_f32_dpp", v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_u32(int v) {
+  UC_DPP_REDUCE("v_min_u32_dpp", v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  UC_DPP_REDUCE("v_max_i32_dpp", v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// IEEE maxNum without the canonicalising moves fmaxf() drags in
+__device__ __forceinline__ float max_f32(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
 }
 
 // idx2freq(): receiver/Src/main.c:154-160, 32-bit unsigned arithmetic as on the MCU
@@ -57,44 +100,51 @@ __device__ __forceinline__ int32_t idx2freq(uint32_t ifs, uint32_t idx) {
   return (int32_t)((ifs * ((uint32_t)kN - idx) / (uint32_t)kN) * 0xFFFFFFFFu);
 }
 
-// One arm_max_f32 over window bins k in [lo, hi] of arr[], executed by one wave.
-// prefer_small: ties resolve to the smallest k (right window, ascending index);
-// otherwise to the largest k (left window: index n-k ascending = k descending).
-__device__ __forceinline__ void wave_window_max(const float* arr, int lo, int hi, bool prefer_small,
-                                                int lane, float& out_val, int& out_k) {
-  float v[4];
-#pragma unroll
-  for (int s = 0; s < 4; s++) {
-    const int k = lane + 64 * s;
-    v[s] = (k >= lo && k <= hi) ? arr[k] : -INFINITY;
+// This wave's share of the two arm_max_f32 of one history (receiver/Src/main.c:205-208).
+// Candidates: slot 0 = bin k0 of every lane, slot 1 (HAS1R / HAS1L) = bin k1 = 128 + lane.
+//   right window: bins [0, bw2)  -- ties resolve to the SMALLEST bin (ascending index)
+//   left  window: bins [1, bw2]  -- index n-k ascending = bin descending: LARGEST bin wins
+// vr*/vl* are the right-/left-window magnitudes of the bin (equal for RX_REAL).
+struct Partial {
+  float vr, vl;
+  int kr, kl;
+  unsigned nan_first;  // bit0: right window's first element (bin 0) is NaN, bit1: left's (bin bw2)
+};
+
+template <bool HAS1R, bool HAS1L>
+__device__ __forceinline__ Partial window_partial(float vr0, float vl0, int k0, float vr1, float vl1, int k1,
+                                                  int bw2) {
+  const float ninf = -INFINITY;
+  const float r0 = (k0 < bw2) ? vr0 : ninf;
+  const float l0 = (k0 >= 1 && k0 <= bw2) ? vl0 : ninf;
+  float r1 = ninf, l1 = ninf;
+  if (HAS1R) r1 = (k1 < bw2) ? vr1 : ninf;
+  if (HAS1L) l1 = (k1 <= bw2) ? vl1 : ninf;
+  Partial o;
+  // value first (v_max_f32 skips NaNs exactly as arm_max_f32's '<' update does) ...
+  o.vr = wave_max_f32(HAS1R ? max_f32(r0, r1) : r0);
+  o.vl = wave_max_f32(HAS1L ? max_f32(l0, l1) : l0);
+  // ... then the winning bin: smallest for the right window, largest for the left
+  int cr = (r0 == o.vr) ? k0 : 0x7fffffff;
+  int cl = (l0 == o.vl) ? k0 : -1;
+  if (HAS1R) {
+    const int cr1 = (r1 == o.vr) ? k1 : 0x7fffffff;
+    cr = cr1 < cr ? cr1 : cr;
   }
-  const float m = wave_max(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])));
-  const int first = prefer_small ? lo : hi;
-  const float vfirst = arr[first];
-  int k = first;
-  if (vfirst != vfirst) {
-    // arm_max_f32 starts from src[0]; a NaN there never loses a '<' compare
-    out_val = vfirst;
-    out_k = first;
-    return;
+  if (HAS1L) {
+    const int cl1 = (l1 == o.vl) ? k1 : -1;
+    cl = cl1 > cl ? cl1 : cl;
   }
-  if (prefer_small) {
-    bool found = false;
-#pragma unroll
-    for (int s = 0; s < 4; s++) {
-      const unsigned long long b = __ballot(v[s] == m);
-      if (!found && b) { k = 64 * s + (__ffsll((long long)b) - 1); found = true; }
-    }
-  } else {
-    bool found = false;
-#pragma unroll
-    for (int s = 3; s >= 0; s--) {
-      const unsigned long long b = __ballot(v[s] == m);
-      if (!found && b) { k = 64 * s + (63 - __clzll((long long)b)); found = true; }
-    }
-  }
-  out_val = m;
-  out_k = k;
+  o.kr = wave_min_u32(cr);
+  o.kl = wave_max_i32(cl);
+  if (o.kr == 0x7fffffff) o.kr = 0;
+  if (o.kl < 0) o.kl = 0;
+  // arm_max_f32 starts from src[0]: a NaN there never loses a '<' compare
+  unsigned long long nr = __ballot(k0 == 0 && vr0 != vr0);
+  unsigned long long nl = __ballot(k0 == bw2 && vl0 != vl0);
+  if (HAS1L) nl |= __ballot(k1 == bw2 && vl1 != vl1);
+  o.nan_first = (nr ? 1u : 0u) | (nl ? 2u : 0u);
+  return o;
 }
 
 struct Hist {
@@ -104,16 +154,17 @@ struct Hist {
 
 // the tail of dsp(): receiver/Src/main.c:209-229
 __device__ __forceinline__ Hist make_hist(float mr, int kr, float ml, int kl, float mm, uint32_t ifs,
-                                          bool raw_idx, uint32_t bw2) {
+                                          bool raw_idx) {
   Hist h;
   h.mag_left = ml;
   h.mag_right = mr;
   uint32_t idx_r = (uint32_t)kr, idx_l = (uint32_t)kN - (uint32_t)kl, idx;
   if (ml > mr) { h.mag_max = ml; idx = idx_l; } else { h.mag_max = mr; idx = idx_r; }
   if (raw_idx) {
-    // chirp_compression_freq_domain/Src/main.c:152-156: indices, left as bw*8 - local
+    // chirp_compression_freq_domain/Src/main.c:152-156: raw indices, the left one as
+    // bandwidth*8 - local index = the mirrored bin kl
     h.fr = kr;
-    h.fl = (int32_t)(bw2 - (bw2 - (uint32_t)kl));
+    h.fl = kl;
     h.f = (ml > mr) ? h.fl : h.fr;
   } else {
     h.f = idx2freq(ifs, idx);
@@ -133,42 +184,80 @@ __device__ __forceinline__ void store_hist(uc_stats* dst, const Hist& h, float m
   d[1] = b;
 }
 
+// merge the two waves' partials of one window (ties: smallest / largest bin)
+__device__ __forceinline__ void merge_window(float v0, int k0, float v1, int k1, bool prefer_small, bool nan_first,
+                                             int first, float& v, int& k) {
+  const float a = (v0 != v0) ? -INFINITY : v0;
+  const float b = (v1 != v1) ? -INFINITY : v1;
+  const bool pick1 = (b > a) || (b == a && (prefer_small ? (k1 < k0) : (k1 > k0)));
+  v = pick1 ? b : a;
+  k = pick1 ? k1 : k0;
+  if (nan_first) {
+    v = __int_as_float(0x7fc00000);
+    k = first;
+  }
+}
+
+__device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
+  const float2 w = tw[idx & (kN - 1)];
+  return mkv(w.x, w.y);
+}
+
+// Diagnostic build only (-DUC_STAMPS): per-phase cycle sums of every wave go to
+// p.debug (never read by the kernel, never part of an output).  See tools/phase_stamps.py.
+#ifdef UC_STAMPS
+#define UC_STAMP(k)                                               \
+  do {                                                            \
+    const unsigned long long now_ = __builtin_readcyclecounter(); \
+    acc_[k] += now_ - last_;                                      \
+    last_ = now_;                                                 \
+  } while (0)
+#else
+#define UC_STAMP(k) do { } while (0)
+#endif
+
 template <int MODE, int DTYPE, int WAVES>
 __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
+#ifdef UC_STAMPS
+  unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long last_ = __builtin_readcyclecounter();
+#endif
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
-  float* mag0 = lds + kMagOff;        // RX_REAL: |A[k]| (up)   CPLX: |Z[k]|
-  float* mag1 = lds + kMagOff + 256;  // RX_REAL: |B[k]| (down) CPLX: |Z[n-k]|
-  float* res = lds + kResOff;         // 4 tasks x (value, k)
+  float* ring = lds + kRingOff;
 
   const int j = threadIdx.x;
   const int lane = j & 63;
   const int wave = j >> 6;
   const int bw2 = (int)p.bw2;
 
+  // contiguous chunk of frames per workgroup: [f, fend)
+  const size_t nfr = p.n_frames;
+  const size_t chunk = (nfr + gridDim.x - 1) / gridDim.x;
+  size_t f = (size_t)blockIdx.x * chunk;
+  if (f >= nfr) return;
+  const size_t fend = (f + chunk < nfr) ? f + chunk : nfr;
+
   // ---- per-thread constants, resident for the whole batch -----------------
-  cf wtab[16];  // RX_REAL only: window*chirp table entries of this thread's samples
+  v2f wt[16];  // RX_REAL only: window*chirp table entries of this thread's samples
   if (MODE == kModeRxReal) {
 #pragma unroll
     for (int t = 0; t < 16; t++) {
       const float2 w = p.tab0[j + T * t];
-      wtab[t] = mk(w.x, w.y);
+      wt[t] = mkv(w.x, w.y);
     }
   }
-  cf tw2[16];  // pass-2 twiddles W_256^(t*k), k = j & 15
+  // pass-2 twiddles W_256^(t*k), k = j & 15, factored t = 4*n1 + n2:
+  //   W^(t k) = wb[n1] * wa[n2],  wa[n2] = W_256^(n2 k),  wb[n1] = W_256^(4 n1 k)
+  // (6 resident values instead of 15; 24 instead of 15 complex products)
+  v2f wa[4], wb[4];
 #pragma unroll
-  for (int t = 1; t < 16; t++) {
-    const float2 w = p.tw[(8 * t * (j & 15)) & (kN - 1)];
-    tw2[t] = mk(w.x, w.y);
+  for (int m = 1; m < 4; m++) {
+    wa[m] = ld_tw(p.tw, 8 * m * (j & 15));
+    wb[m] = ld_tw(p.tw, 32 * m * (j & 15));
   }
-  // pass-3 twiddles W_2048^(t*j): only t = 1, 2, 4 stay resident, the other four
-  // are one complex product away (keeps the kernel at 3 waves/SIMD)
-  cf tw3_1, tw3_2, tw3_4;
-  {
-    const float2 w1 = p.tw[j & (kN - 1)], w2 = p.tw[(2 * j) & (kN - 1)], w4 = p.tw[(4 * j) & (kN - 1)];
-    tw3_1 = mk(w1.x, w1.y);
-    tw3_2 = mk(w2.x, w2.y);
-    tw3_4 = mk(w4.x, w4.y);
-  }
+  // pass-3 twiddles W_2048^(t*j): t = 1, 2, 4 resident, the rest one product away
+  const v2f tw3_1 = ld_tw(p.tw, j), tw3_2 = ld_tw(p.tw, 2 * j), tw3_4 = ld_tw(p.tw, 4 * j);
+  v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
 
   // LDS addresses (complex units)
   const int s1 = j & 15;
@@ -177,200 +266,242 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);        // + 128 t, t odd
   const int wr2 = (j >> 4) * 256 + (j & 15);                     // + 16 t
 
-  const size_t nfr = p.n_frames;
-  const size_t gstep = gridDim.x;
-  size_t f = blockIdx.x;
-  if (f >= nfr) return;
-
-  float xr[16];
+  v2f xp[8];  // the frame's 16 samples of this thread, two per register pair (raw words)
   {
-    const size_t base = f * p.stride;
+    const size_t base = f * p.stride + (size_t)j;
 #pragma unroll
-    for (int t = 0; t < 16; t++) xr[t] = ld_sample<DTYPE>(p.frames, base + j + T * t);
+    for (int m = 0; m < 8; m++)
+      xp[m] = mkv(ld_raw<DTYPE>(p.frames, base + T * (2 * m)), ld_raw<DTYPE>(p.frames, base + T * (2 * m + 1)));
   }
 
-  size_t fprev = 0;
-  bool have_prev = false;
-
-  // finaliser: history[0], history[1], symbol of frame `ff` from res[]
-  auto finalise = [&](size_t ff) {
-    float mm_up = p.mag_mean_scalar, mm_dn = p.mag_mean_scalar;
-    if (p.mag_mean) { mm_up = p.mag_mean[2 * ff]; mm_dn = p.mag_mean[2 * ff + 1]; }
-    const Hist h0 = make_hist(res[0], __float_as_int(res[1]), res[2], __float_as_int(res[3]), mm_up,
-                              p.ifs, p.single != 0, p.bw2);
-    if (p.single) {
-      if (p.stats) store_hist(p.stats + ff, h0, mm_up);
-      if (p.symbols) p.symbols[ff] = (uint8_t)UC_SYM_NONE;
-      return;
-    }
-    const Hist h1 = make_hist(res[4], __float_as_int(res[5]), res[6], __float_as_int(res[7]), mm_dn,
-                              p.ifs, false, p.bw2);
-    if (p.stats) {
-      store_hist(p.stats + 2 * ff, h0, mm_up);
-      store_hist(p.stats + 2 * ff + 1, h1, mm_dn);
-    }
-    if (p.symbols) {
-      // receiver/Src/main.c:521-531
-      uint8_t sym = (uint8_t)UC_SYM_NONE;
-      if ((h0.snr >= p.snr_threshold) || (h1.snr >= p.snr_threshold))
-        sym = (h1.snr > h0.snr) ? (uint8_t)UC_SYM_DOWN : (uint8_t)UC_SYM_UP;
-      p.symbols[ff] = sym;
+  // Finaliser, vectorised over frames: lane L turns ring slot L into history[0],
+  // history[1] and the symbol of frame f0 + L (receiver/Src/main.c:209-229, 518-531).
+  auto finalise = [&](size_t f0, int count) {
+    if (lane < count) {
+      const float* e = ring + lane * kRingStride;
+      const size_t ff = f0 + (size_t)lane;
+      float mm_up = p.mag_mean_scalar, mm_dn = p.mag_mean_scalar;
+      if (p.mag_mean) { mm_up = p.mag_mean[2 * ff]; mm_dn = p.mag_mean[2 * ff + 1]; }
+      const unsigned kp0 = __float_as_uint(e[4]), kp1 = __float_as_uint(e[6 + 4]);
+      const unsigned fl = __float_as_uint(e[5]) | __float_as_uint(e[6 + 5]);
+      float mr, ml;
+      int kr, kl;
+      merge_window(e[0], kp0 & 255, e[6 + 0], kp1 & 255, true, fl & 1u, 0, mr, kr);
+      merge_window(e[1], (kp0 >> 8) & 255, e[6 + 1], (kp1 >> 8) & 255, false, fl & 2u, bw2, ml, kl);
+      const Hist h0 = make_hist(mr, kr, ml, kl, mm_up, p.ifs, p.single != 0);
+      if (p.single) {
+        if (p.stats) store_hist(p.stats + ff, h0, mm_up);
+        if (p.symbols) p.symbols[ff] = (uint8_t)UC_SYM_NONE;
+      } else {
+        merge_window(e[2], (kp0 >> 16) & 255, e[6 + 2], (kp1 >> 16) & 255, true, fl & 4u, 0, mr, kr);
+        merge_window(e[3], (kp0 >> 24) & 255, e[6 + 3], (kp1 >> 24) & 255, false, fl & 8u, bw2, ml, kl);
+        const Hist h1 = make_hist(mr, kr, ml, kl, mm_dn, p.ifs, false);
+        if (p.stats) {
+          store_hist(p.stats + 2 * ff, h0, mm_up);
+          store_hist(p.stats + 2 * ff + 1, h1, mm_dn);
+        }
+        if (p.symbols) {
+          // receiver/Src/main.c:521-531
+          uint8_t sym = (uint8_t)UC_SYM_NONE;
+          if ((h0.snr >= p.snr_threshold) || (h1.snr >= p.snr_threshold))
+            sym = (h1.snr > h0.snr) ? (uint8_t)UC_SYM_DOWN : (uint8_t)UC_SYM_UP;
+          p.symbols[ff] = sym;
+        }
+      }
     }
   };
 
-  for (; f < nfr; f += gstep) {
+  size_t ring_f0 = f;  // frame held by ring slot 0
+  int ring_n = 0;      // slots filled
+
+  for (; f < fend; f++) {
     // Opaque re-definitions: stop LICM from hoisting the 16 swizzled store
-    // addresses and the derived pass-3 twiddles out of the frame loop, where they
-    // would sit in (spilled) registers for the whole batch.
+    // addresses and the derived pass-3 twiddles out of the frame loop (they
+    // would sit in registers for the whole batch).
     int s1v = s1;
-    cf t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
-    asm volatile("" : "+v"(s1v), "+v"(t3a.re), "+v"(t3a.im), "+v"(t3b.re), "+v"(t3b.im), "+v"(t3c.re), "+v"(t3c.im));
-    const size_t fnext = f + gstep;
-    const bool has_next = fnext < nfr;
+    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
+    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
+    const bool has_next = f + 1 < fend;
     constexpr int kRuns = (MODE == kModeCplx) ? 2 : 1;
+    float pv[4] = {0.f, 0.f, 0.f, 0.f};  // this wave's partials: up right/left, down right/left
+    unsigned kpack = 0, flags = 0;
+    UC_STAMP(9);
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
-      cf v[16];
+      v2f v[16];
       // ---- pass 1: window*chirp multiply, radix-16, Ns = 1 ------------------
       if (MODE == kModeRxReal) {
 #pragma unroll
-        for (int t = 0; t < 16; t++) v[t] = mk(xr[t] * wtab[t].re, xr[t] * wtab[t].im);
+        for (int m = 0; m < 8; m++) {
+          const v2f x2 = cvt_pair<DTYPE>(xp[m]);
+          v[2 * m] = pk_scale_lo(wt[2 * m], x2);
+          v[2 * m + 1] = pk_scale_hi(wt[2 * m + 1], x2);
+        }
       } else {
         const float2* tab = run == 0 ? p.tab0 : p.tab1;
 #pragma unroll
-        for (int t = 0; t < 16; t++) {
-          const float2 w = tab[j + T * t];
-          v[t] = mk(xr[t] * w.x, xr[t] * w.y);
+        for (int m = 0; m < 8; m++) {
+          const v2f x2 = cvt_pair<DTYPE>(xp[m]);
+          const float2 w0 = tab[j + T * (2 * m)], w1 = tab[j + T * (2 * m + 1)];
+          v[2 * m] = pk_scale_lo(mkv(w0.x, w0.y), x2);
+          v[2 * m + 1] = pk_scale_hi(mkv(w1.x, w1.y), x2);
         }
       }
-      dft16<false>(v);
+      // prefetch the next frame a whole frame time ahead (HBM latency under load is
+      // microseconds; at 3 waves/SIMD the 16 registers are free)
+      if (run == kRuns - 1 && has_next) {
+        const size_t base = (f + 1) * p.stride + (size_t)j;
 #pragma unroll
-      for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[slot16(t)]);
+        for (int m = 0; m < 8; m++)
+          xp[m] = mkv(ld_raw<DTYPE>(p.frames, base + T * (2 * m)), ld_raw<DTYPE>(p.frames, base + T * (2 * m + 1)));
+      }
+      pk_dft16(v, K, H);
+      UC_STAMP(0);
+#pragma unroll
+      for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[4 * (t & 3) + (t >> 2)]);
+      UC_STAMP(1);
       __syncthreads();  // B1
-
-      if (j == 0 && have_prev && run == 0) finalise(fprev);
+      UC_STAMP(2);
 
       // ---- pass 2: radix-16, Ns = 16 ----------------------------------------
 #pragma unroll
       for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
 #pragma unroll
-      for (int t = 1; t < 16; t++) v[t] = cmul(v[t], tw2[t]);
-      dft16<false>(v);
-      __syncthreads();  // B2: every pass-2 read is done before the tile is overwritten
-#pragma unroll
-      for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[slot16(t)]);
-      __syncthreads();  // B3
-
-      // prefetch the next frame while the pruned pass and the window search run
-      if (run == kRuns - 1 && has_next) {
-        const size_t base = fnext * p.stride;
-#pragma unroll
-        for (int t = 0; t < 16; t++) xr[t] = ld_sample<DTYPE>(p.frames, base + j + T * t);
+      for (int t = 1; t < 16; t++) {
+        if (t & 3) v[t] = pk_cmul(v[t], wa[t & 3]);
+        if (t >> 2) v[t] = pk_cmul(v[t], wb[t >> 2]);
       }
+      pk_dft16(v, K, H);
+      UC_STAMP(3);
+      __syncthreads();  // B2: every pass-2 read is done before the tile is overwritten
+      UC_STAMP(4);
+#pragma unroll
+      for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[4 * (t & 3) + (t >> 2)]);
+      __syncthreads();  // B3
+      UC_STAMP(5);
 
       // ---- pass 3: radix-8, Ns = 256, only bins i in [0, bw2] and n - i -----
+      // Round 0: bin j on every thread.  Round 1: bins 128 + lane on wave 1 only (wave 0
+      // owns the finaliser).  A round is latency- not throughput-bound: splitting round 1
+      // into one dot product per wave was measured SLOWER (both waves then pay a round).
+      // RX_REAL: first = |A[i]| (up), second = |B[i]| (down); CPLX: |Z[i]|, |Z[n-i]|.
+      float m_a[2] = {0.f, 0.f}, m_b[2] = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        const int i = j + T * r;
-        if (i <= bw2) {
-          cf w[8];
+        const int i = (r == 0) ? j : 128 + lane;
+        if (i <= bw2 && (r == 0 || wave == 1)) {
+          v2f w[8];
           if (r == 0) {
             w[1] = t3a;
             w[2] = t3b;
             w[4] = t3c;
-            w[3] = cmul(t3a, t3b);
-            w[5] = cmul(t3a, t3c);
-            w[6] = cmul(t3b, t3c);
-            w[7] = cmul(w[3], t3c);
           } else {
-#pragma unroll
-            for (int t = 1; t < 8; t++) {
-              const float2 ww = p.tw[(t * i) & (kN - 1)];
-              w[t] = mk(ww.x, ww.y);
-            }
+            // i = j + 64: W_2048^(t (j+64)) = W_2048^(t j) * W_32^t
+            w[1] = pk_cmul(t3a, mkv(kCos16, -kSin16));
+            w[2] = pk_mul_w1(t3b, K);
+            w[4] = pk_mul_w2(t3c, H);
           }
+          w[3] = pk_cmul(w[1], w[2]);
+          w[5] = pk_cmul(w[1], w[4]);
+          w[6] = pk_cmul(w[2], w[4]);
+          w[7] = pk_cmul(w[3], w[4]);
           const int ib = (256 - i) & 255;
-          cf a[8], b[8];
-#pragma unroll
-          for (int t = 0; t < 8; t++) {
-            a[t] = lds_ld(lds, i + 256 * t);
-            b[t] = lds_ld(lds, ib + 256 * t);
-          }
+          constexpr bool do_a = true, do_b = true;
           if (MODE == kModeRxReal) {
             // A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2j
-            cf sa = a[0] + cconj(b[0]);
-            cf sb = a[0] - cconj(b[0]);
+            const v2f a0 = lds_ld(lds, i), b0 = lds_ld(lds, ib);
+            v2f sa = pk_add_conj(a0, b0);
+            v2f sb = pk_sub_conj(a0, b0);
+            v2f zn = a0;  // Z[n/2] partial sum, only meaningful for i == 0
 #pragma unroll
             for (int t = 1; t < 8; t++) {
-              sa = cfma(a[t] + cconj(b[t]), w[t], sa);
-              sb = cfma(a[t] - cconj(b[t]), w[t], sb);
+              const v2f a = lds_ld(lds, i + 256 * t), b = lds_ld(lds, ib + 256 * t);
+              if (do_a) sa = pk_cfma(pk_add_conj(a, b), w[t], sa);
+              if (do_b) sb = pk_cfma(pk_sub_conj(a, b), w[t], sb);
+              if (r == 0) zn = (t & 1) ? (zn - a) : (zn + a);
             }
-            float ma = 0.5f * sqrtf(sa.re * sa.re + sa.im * sa.im);
-            float mb = 0.5f * sqrtf(sb.re * sb.re + sb.im * sb.im);
-            if (i == 0) {
+            float ma = 0.f, mb = 0.f;
+            if (do_a) ma = 0.5f * sqrtf(sa.x * sa.x + sa.y * sa.y);
+            if (do_b) mb = 0.5f * sqrtf(sb.x * sb.x + sb.y * sb.y);
+            if (r == 0 && i == 0) {
               // Q2: the packed RFFT stores Re X[n/2] in the imaginary slot of bin 0,
               // so the reference's mag[0] is hypot(X0, X[n/2]) (receiver/Src/main.c:178)
-              const float a0 = 0.5f * sa.re;  // Re Z[0]  = X_up[0]
-              const float b0 = 0.5f * sb.im;  // Im Z[0]  = X_down[0]   (sb = 2j*Im)
-              cf zn = a[0];
-#pragma unroll
-              for (int t = 1; t < 8; t++) zn = (t & 1) ? (zn - a[t]) : (zn + a[t]);
+              const float x0u = 0.5f * sa.x;  // Re Z[0] = X_up[0]
+              const float x0d = 0.5f * sb.y;  // Im Z[0] = X_down[0]   (sb = 2j * Im)
               if (p.true_dc) {
-                ma = fabsf(a0);
-                mb = fabsf(b0);
+                ma = fabsf(x0u);
+                mb = fabsf(x0d);
               } else {
-                ma = sqrtf(a0 * a0 + zn.re * zn.re);
-                mb = sqrtf(b0 * b0 + zn.im * zn.im);
+                ma = sqrtf(x0u * x0u + zn.x * zn.x);
+                mb = sqrtf(x0d * x0d + zn.y * zn.y);
               }
             }
-            mag0[i] = ma;
-            mag1[i] = mb;
+            m_a[r] = ma;
+            m_b[r] = mb;
           } else {
-            cf zl = a[0], zh = b[0];
+            v2f zl = lds_ld(lds, i), zh = lds_ld(lds, ib);
 #pragma unroll
             for (int t = 1; t < 8; t++) {
-              zl = cfma(a[t], w[t], zl);
-              zh = cfma(b[t], cconj(w[t]), zh);
+              if (do_a) zl = pk_cfma(lds_ld(lds, i + 256 * t), w[t], zl);
+              if (do_b) zh = pk_cfmac(lds_ld(lds, ib + 256 * t), w[t], zh);
             }
-            mag0[i] = sqrtf(zl.re * zl.re + zl.im * zl.im);
-            mag1[i] = sqrtf(zh.re * zh.re + zh.im * zh.im);
+            if (do_a) m_a[r] = sqrtf(zl.x * zl.x + zl.y * zl.y);
+            if (do_b) m_b[r] = sqrtf(zh.x * zh.x + zh.y * zh.y);
           }
         }
       }
-      __syncthreads();  // B4: magnitudes visible; data tile free for the next pass 1
+      UC_STAMP(6);
 
-      // ---- windows: arm_max_f32 x 2 per history ------------------------------
+      // ---- windows: this wave's partial arm_max_f32 results, in registers -----
+      // (bins beyond bw2 fail the window predicates inside window_partial)
+      const int k1 = 128 + lane;
       if (MODE == kModeRxReal) {
-        const float* arr = wave == 0 ? mag0 : mag1;
-        float mr, ml;
-        int kr, kl;
-        wave_window_max(arr, 0, bw2 - 1, true, lane, mr, kr);
-        wave_window_max(arr, 1, bw2, false, lane, ml, kl);
-        if (lane == 0) {
-          res[4 * wave + 0] = mr;
-          res[4 * wave + 1] = __int_as_float(kr);
-          res[4 * wave + 2] = ml;
-          res[4 * wave + 3] = __int_as_float(kl);
+        // up history looks at m_a, down history at m_b; wave 1 also holds slot 1
+        Partial up, dn;
+        if (wave == 0) {
+          up = window_partial<false, false>(m_a[0], m_a[0], j, 0.f, 0.f, k1, bw2);
+          dn = window_partial<false, false>(m_b[0], m_b[0], j, 0.f, 0.f, k1, bw2);
+        } else {
+          up = window_partial<true, true>(m_a[0], m_a[0], j, m_a[1], m_a[1], k1, bw2);
+          dn = window_partial<true, true>(m_b[0], m_b[0], j, m_b[1], m_b[1], k1, bw2);
         }
+        pv[0] = up.vr; pv[1] = up.vl; pv[2] = dn.vr; pv[3] = dn.vl;
+        kpack = (unsigned)up.kr | ((unsigned)up.kl << 8) | ((unsigned)dn.kr << 16) | ((unsigned)dn.kl << 24);
+        flags = up.nan_first | (dn.nan_first << 2);
       } else {
-        float m;
-        int k;
-        if (wave == 0) wave_window_max(mag0, 0, bw2 - 1, true, lane, m, k);
-        else wave_window_max(mag1, 1, bw2, false, lane, m, k);
-        if (lane == 0) {
-          res[4 * run + 2 * wave + 0] = m;
-          res[4 * run + 2 * wave + 1] = __int_as_float(k);
-        }
+        // right window looks at |Z[k]| (m_a), left window at |Z[n-k]| (m_b)
+        Partial q;
+        if (wave == 0) q = window_partial<false, false>(m_a[0], m_b[0], j, 0.f, 0.f, k1, bw2);
+        else q = window_partial<true, true>(m_a[0], m_b[0], j, m_a[1], m_b[1], k1, bw2);
+        pv[2 * run] = q.vr;
+        pv[2 * run + 1] = q.vl;
+        kpack |= ((unsigned)q.kr | ((unsigned)q.kl << 8)) << (16 * run);
+        flags |= q.nan_first << (2 * run);
       }
+      if (run == kRuns - 1 && lane == 0) {
+        float* e = ring + ring_n * kRingStride + wave * 6;
+        e[0] = pv[0]; e[1] = pv[1]; e[2] = pv[2]; e[3] = pv[3];
+        e[4] = __uint_as_float(kpack);
+        e[5] = __uint_as_float(flags);
+      }
+      UC_STAMP(8);
+      __syncthreads();  // B4: tile free for the next pass 1; ring entry visible
+      UC_STAMP(7);
     }
-    fprev = f;
-    have_prev = true;
+    ring_n++;
+    if (ring_n == kRingFrames) {
+      if (wave == 0) finalise(ring_f0, ring_n);
+      ring_f0 = f + 1;
+      ring_n = 0;
+    }
   }
-  __syncthreads();
-  if (j == 0 && have_prev) finalise(fprev);
+  if (ring_n > 0 && wave == 0) finalise(ring_f0, ring_n);
+#ifdef UC_STAMPS
+  if (lane == 0 && p.debug) {
+    for (int k = 0; k < 10; k++) p.debug[((size_t)blockIdx.x * 2 + wave) * 10 + k] = acc_[k];
+  }
+#endif
 }
-
-}  // namespace
 
 template <int MODE, int DTYPE, int WAVES>
 static int launch_one(const BandParams& p, int grid, hipStream_t stream) {
@@ -385,6 +516,8 @@ static int occupancy_one() {
   if (e != hipSuccess || nb <= 0) nb = 2 * WAVES;
   return nb;
 }
+
+}  // namespace
 
 #define UC_DISPATCH(FN, ...)                                                              \
   do {                                                                                    \

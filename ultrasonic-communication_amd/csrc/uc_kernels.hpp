@@ -29,6 +29,7 @@ struct BandParams {
   uint32_t ifs;           // (uint32_t)(int32_t)fs for idx2freq
   uint32_t true_dc;       // UC_FLAG_TRUE_DC
   uint32_t single;        // 1: only history[0] exists (DECHIRP_DOWN), raw-index stats
+  unsigned long long* debug;  // diagnostic builds only (UC_STAMPS), else nullptr
 };
 
 enum BandMode { kModeRxReal = 0, kModeCplx = 1 };

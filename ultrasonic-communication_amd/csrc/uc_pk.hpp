@@ -1,0 +1,166 @@
+// uc_pk.hpp -- packed-fp32 complex arithmetic for gfx950 (v_pk_*_f32, VOP3P).
+//
+// A complex number is one 64-bit VGPR pair (re = low dword, im = high dword).
+// hipcc (ROCm 7.2) does not fold the "swap halves + negate one" operand of a
+// complex product or of a multiplication by -j into the op_sel / neg modifiers
+// of v_pk_mul/fma/add_f32: it emits v_xor + v_mov + v_pk_* (3-4 instructions).
+// The forms below are the 1-2 instruction encodings, written out by hand:
+//   D.lo = S0[op_sel[0]]    * S1[op_sel[1]]    (+ S2[op_sel[2]])
+//   D.hi = S0[op_sel_hi[0]] * S1[op_sel_hi[1]] (+ S2[op_sel_hi[2]])
+// with neg_lo / neg_hi negating the operands of the low / high result.
+// Packed fp32 VALU has no software-visible hazards (dependencies interlock),
+// so no wait states are needed inside the asm statements.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace uc {
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f mkv(float re, float im) { v2f r; r.x = re; r.y = im; return r; }
+
+// a * w
+__device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+
+// a * conj(w)
+__device__ __forceinline__ v2f pk_cmulc(v2f a, v2f w) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+
+// acc + a * w
+__device__ __forceinline__ v2f pk_cfma(v2f a, v2f w, v2f acc) {
+  v2f t, r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
+      : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+
+// acc + a * conj(w)
+__device__ __forceinline__ v2f pk_cfmac(v2f a, v2f w, v2f acc) {
+  v2f t, r;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  return r;
+}
+
+// x + (-j) d  = (x.re + d.im, x.im - d.re)
+__device__ __forceinline__ v2f pk_add_mj(v2f x, v2f d) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(x), "v"(d));
+  return r;
+}
+
+// x - (-j) d  = x + j d = (x.re - d.im, x.im + d.re)
+__device__ __forceinline__ v2f pk_sub_mj(v2f x, v2f d) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(x), "v"(d));
+  return r;
+}
+
+// a + conj(b), a - conj(b)
+__device__ __forceinline__ v2f pk_add_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ v2f pk_sub_conj(v2f a, v2f b) {
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+// (-j) a = (a.im, -a.re)
+__device__ __forceinline__ v2f pk_mul_mj(v2f a) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, 1.0 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(r) : "v"(a));
+  return r;
+}
+
+// w * x.lo  /  w * x.hi  (real sample broadcast from one half of a register pair)
+__device__ __forceinline__ v2f pk_scale_lo(v2f w, v2f x) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(w), "v"(x));
+  return r;
+}
+__device__ __forceinline__ v2f pk_scale_hi(v2f w, v2f x) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(r) : "v"(w), "v"(x));
+  return r;
+}
+
+// ---- multiplications by the fixed radix-16 twiddles -------------------------
+// K = (cos(pi/8), sin(pi/8)), H = (sqrt(1/2), sqrt(1/2)) live in two register pairs.
+
+// a * W16^1 = a * (c, -s) = (a.re c + a.im s, a.im c - a.re s)
+__device__ __forceinline__ v2f pk_mul_w1(v2f a, v2f K) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(K));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(K), "v"(t));
+  return r;
+}
+// a * W16^3 = a * (s, -c) = (a.re s + a.im c, a.im s - a.re c)
+__device__ __forceinline__ v2f pk_mul_w3(v2f a, v2f K) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(K));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(K), "v"(t));
+  return r;
+}
+// a * W16^9 = -(a * W16^1)
+__device__ __forceinline__ v2f pk_mul_w9(v2f a, v2f K) {
+  v2f t, r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(K));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+      : "=v"(r) : "v"(a), "v"(K), "v"(t));
+  return r;
+}
+// a * W16^2 = a * (h, -h) = h (a.re + a.im, a.im - a.re)
+__device__ __forceinline__ v2f pk_mul_w2(v2f a, v2f H) {
+  v2f t, r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(a));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(H));
+  return r;
+}
+// a * W16^6 = a * (-h, -h) = h (a.im - a.re, -(a.re + a.im))
+__device__ __forceinline__ v2f pk_mul_w6(v2f a, v2f H) {
+  v2f t, r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(t) : "v"(a));
+  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(H));
+  return r;
+}
+
+// forward 4-point DFT in place, natural order (8 packed instructions)
+__device__ __forceinline__ void pk_dft4(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {
+  const v2f a0 = x0 + x2, a1 = x0 - x2, a2 = x1 + x3, d = x1 - x3;
+  x0 = a0 + a2;
+  x2 = a0 - a2;
+  x1 = pk_add_mj(a1, d);
+  x3 = pk_sub_mj(a1, d);
+}
+
+// forward 16-point DFT as 4 x 4; X[t] ends up in v[4*(t&3) + (t>>2)]
+__device__ __forceinline__ void pk_dft16(v2f (&v)[16], v2f K, v2f H) {
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) pk_dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+  v[5] = pk_mul_w1(v[5], K);
+  v[6] = pk_mul_w2(v[6], H);
+  v[7] = pk_mul_w3(v[7], K);
+  v[9] = pk_mul_w2(v[9], H);
+  v[10] = pk_mul_mj(v[10]);
+  v[11] = pk_mul_w6(v[11], H);
+  v[13] = pk_mul_w3(v[13], K);
+  v[14] = pk_mul_w6(v[14], H);
+  v[15] = pk_mul_w9(v[15], K);
+#pragma unroll
+  for (int k1 = 0; k1 < 4; k1++) pk_dft4(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+}
+
+}  // namespace uc

@@ -17,7 +17,7 @@ import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)  # ultrasonic-communication_amd/
-LIB_PATH = os.path.join(_ROOT, "libuchirp.so")
+LIB_PATH = os.environ.get("UCHIRP_LIB") or os.path.join(_ROOT, "libuchirp.so")  # UCHIRP_LIB: diagnostic builds
 
 RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ = range(5)
 DOWN_CHIRP, UP_CHIRP = 0, 1
