@@ -81,7 +81,7 @@ struct uc_ctx {
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
   int band_blocks_per_cu[2] = {0, 0};
-  int band_waves = 2;     // tuning knobs (env UC_BAND_WAVES / UC_GRID): not part of the ABI
+  int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID): not part of the ABI
   int grid_override = 0;
 };
 

@@ -42,10 +42,21 @@ constexpr float kSin8 = 0.38268343236508977173f;   // sin(pi/8)
 constexpr float kCos16 = 0.98078528040323044913f;  // cos(pi/16)
 constexpr float kSin16 = 0.19509032201612826785f;  // sin(pi/16)
 
-template <int DTYPE>
-__device__ __forceinline__ float ld_raw(const void* base, size_t idx) {
-  // raw 32-bit word; int32 words are converted when consumed (the ISR's (float) cast)
-  return reinterpret_cast<const float*>(base)[idx];
+// Buffer loads (SGPR resource + ONE VGPR byte offset + SGPR/immediate offset): the 16
+// strided loads of a thread share a single address register; global_load would keep a
+// 64-bit VGPR pointer per 4 KiB of span (hipcc hoists and then spills them).
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+constexpr int kRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+}
+// raw 32-bit word; int32 words are converted when consumed (the ISR's (float) cast)
+__device__ __forceinline__ float buf_ld32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return mkv(__uint_as_float(w.x), __uint_as_float(w.y));
 }
 template <int DTYPE>
 __device__ __forceinline__ v2f cvt_pair(v2f raw) {
@@ -238,26 +249,23 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const size_t fend = (f + chunk < nfr) ? f + chunk : nfr;
 
   // ---- per-thread constants, resident for the whole batch -----------------
+  const __amdgpu_buffer_rsrc_t rs_tab0 = make_rsrc(p.tab0, kN * 8);
+  const __amdgpu_buffer_rsrc_t rs_tab1 = make_rsrc(p.tab1, kN * 8);
+  const int voff8 = j * 8, voff4 = j * 4;
   v2f wt[16];  // RX_REAL only: window*chirp table entries of this thread's samples
   if (MODE == kModeRxReal) {
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const float2 w = p.tab0[j + T * t];
-      wt[t] = mkv(w.x, w.y);
-    }
+    for (int t = 0; t < 16; t++) wt[t] = buf_ld64(rs_tab0, voff8, T * 8 * t);
   }
-  // pass-2 twiddles W_256^(t*k), k = j & 15, factored t = 4*n1 + n2:
-  //   W^(t k) = wb[n1] * wa[n2],  wa[n2] = W_256^(n2 k),  wb[n1] = W_256^(4 n1 k)
-  // (6 resident values instead of 15; 24 instead of 15 complex products)
-  v2f wa[4], wb[4];
+  // pass-2 twiddles W_256^(t*k), k = j & 15: all 15 resident (at 3 waves/SIMD the
+  // registers are there; the factored form wa[n2]*wb[n1] costs 9 more products per frame)
+  v2f tw2[16];
 #pragma unroll
-  for (int m = 1; m < 4; m++) {
-    wa[m] = ld_tw(p.tw, 8 * m * (j & 15));
-    wb[m] = ld_tw(p.tw, 32 * m * (j & 15));
-  }
-  // pass-3 twiddles W_2048^(t*j): t = 1, 2, 4 resident, the rest one product away
+  for (int t = 1; t < 16; t++) tw2[t] = ld_tw(p.tw, 8 * t * (j & 15));
+  // pass-3 twiddles W_2048^(t*j): t = 1, 2, 4 resident (t = 1 only when LEAN), the rest
+  // one or two products away
   const v2f tw3_1 = ld_tw(p.tw, j), tw3_2 = ld_tw(p.tw, 2 * j), tw3_4 = ld_tw(p.tw, 4 * j);
-  v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
+  const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);  // SGPR pairs
 
   // LDS addresses (complex units)
   const int s1 = j & 15;
@@ -268,10 +276,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 
   v2f xp[8];  // the frame's 16 samples of this thread, two per register pair (raw words)
   {
-    const size_t base = f * p.stride + (size_t)j;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + f * p.stride * 4, kN * 4);
 #pragma unroll
     for (int m = 0; m < 8; m++)
-      xp[m] = mkv(ld_raw<DTYPE>(p.frames, base + T * (2 * m)), ld_raw<DTYPE>(p.frames, base + T * (2 * m + 1)));
+      xp[m] = mkv(buf_ld32(rx, voff4, T * 4 * (2 * m)), buf_ld32(rx, voff4, T * 4 * (2 * m + 1)));
   }
 
   // Finaliser, vectorised over frames: lane L turns ring slot L into history[0],
@@ -286,8 +294,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       const unsigned fl = __float_as_uint(e[5]) | __float_as_uint(e[6 + 5]);
       float mr, ml;
       int kr, kl;
+      // the ring holds squared magnitudes (x4 for RX_REAL): |X| = mscale * sqrt(q)
+      const float mscale = (MODE == kModeRxReal) ? 0.5f : 1.0f;
       merge_window(e[0], kp0 & 255, e[6 + 0], kp1 & 255, true, fl & 1u, 0, mr, kr);
       merge_window(e[1], (kp0 >> 8) & 255, e[6 + 1], (kp1 >> 8) & 255, false, fl & 2u, bw2, ml, kl);
+      mr = mscale * sqrtf(mr);
+      ml = mscale * sqrtf(ml);
       const Hist h0 = make_hist(mr, kr, ml, kl, mm_up, p.ifs, p.single != 0);
       if (p.single) {
         if (p.stats) store_hist(p.stats + ff, h0, mm_up);
@@ -295,6 +307,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       } else {
         merge_window(e[2], (kp0 >> 16) & 255, e[6 + 2], (kp1 >> 16) & 255, true, fl & 4u, 0, mr, kr);
         merge_window(e[3], (kp0 >> 24) & 255, e[6 + 3], (kp1 >> 24) & 255, false, fl & 8u, bw2, ml, kl);
+        mr = mscale * sqrtf(mr);
+        ml = mscale * sqrtf(ml);
         const Hist h1 = make_hist(mr, kr, ml, kl, mm_dn, p.ifs, false);
         if (p.stats) {
           store_hist(p.stats + 2 * ff, h0, mm_up);
@@ -338,22 +352,22 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           v[2 * m + 1] = pk_scale_hi(wt[2 * m + 1], x2);
         }
       } else {
-        const float2* tab = run == 0 ? p.tab0 : p.tab1;
+        const __amdgpu_buffer_rsrc_t rt = run == 0 ? rs_tab0 : rs_tab1;
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const v2f x2 = cvt_pair<DTYPE>(xp[m]);
-          const float2 w0 = tab[j + T * (2 * m)], w1 = tab[j + T * (2 * m + 1)];
-          v[2 * m] = pk_scale_lo(mkv(w0.x, w0.y), x2);
-          v[2 * m + 1] = pk_scale_hi(mkv(w1.x, w1.y), x2);
+          v[2 * m] = pk_scale_lo(buf_ld64(rt, voff8, T * 8 * (2 * m)), x2);
+          v[2 * m + 1] = pk_scale_hi(buf_ld64(rt, voff8, T * 8 * (2 * m + 1)), x2);
         }
       }
       // prefetch the next frame a whole frame time ahead (HBM latency under load is
       // microseconds; at 3 waves/SIMD the 16 registers are free)
       if (run == kRuns - 1 && has_next) {
-        const size_t base = (f + 1) * p.stride + (size_t)j;
+        const __amdgpu_buffer_rsrc_t rx =
+            make_rsrc(reinterpret_cast<const char*>(p.frames) + (f + 1) * p.stride * 4, kN * 4);
 #pragma unroll
         for (int m = 0; m < 8; m++)
-          xp[m] = mkv(ld_raw<DTYPE>(p.frames, base + T * (2 * m)), ld_raw<DTYPE>(p.frames, base + T * (2 * m + 1)));
+          xp[m] = mkv(buf_ld32(rx, voff4, T * 4 * (2 * m)), buf_ld32(rx, voff4, T * 4 * (2 * m + 1)));
       }
       pk_dft16(v, K, H);
       UC_STAMP(0);
@@ -364,13 +378,13 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       UC_STAMP(2);
 
       // ---- pass 2: radix-16, Ns = 16 ----------------------------------------
+      // all 16 reads are issued back to back (the fence keeps hipcc from sinking them
+      // next to their uses, which serialises four load->wait round trips)
 #pragma unroll
       for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 1; t < 16; t++) {
-        if (t & 3) v[t] = pk_cmul(v[t], wa[t & 3]);
-        if (t >> 2) v[t] = pk_cmul(v[t], wb[t >> 2]);
-      }
+      for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], tw2[t]);
       pk_dft16(v, K, H);
       UC_STAMP(3);
       __syncthreads();  // B2: every pass-2 read is done before the tile is overwritten
@@ -379,7 +393,6 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[4 * (t & 3) + (t >> 2)]);
       __syncthreads();  // B3
       UC_STAMP(5);
-
       // ---- pass 3: radix-8, Ns = 256, only bins i in [0, bw2] and n - i -----
       // Round 0: bin j on every thread.  Round 1: bins 128 + lane on wave 1 only (wave 0
       // owns the finaliser).  A round is latency- not throughput-bound: splitting round 1
@@ -390,6 +403,15 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       for (int r = 0; r < 2; r++) {
         const int i = (r == 0) ? j : 128 + lane;
         if (i <= bw2 && (r == 0 || wave == 1)) {
+          // issue the 16 reads of the round first, derive the twiddles under their latency
+          const int ib = (256 - i) & 255;
+          v2f av[8], bv[8];
+#pragma unroll
+          for (int t = 0; t < 8; t++) {
+            av[t] = lds_ld(lds, i + 256 * t);
+            bv[t] = lds_ld(lds, ib + 256 * t);
+          }
+          __builtin_amdgcn_sched_barrier(0);
           v2f w[8];
           if (r == 0) {
             w[1] = t3a;
@@ -405,53 +427,49 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           w[5] = pk_cmul(w[1], w[4]);
           w[6] = pk_cmul(w[2], w[4]);
           w[7] = pk_cmul(w[3], w[4]);
-          const int ib = (256 - i) & 255;
           constexpr bool do_a = true, do_b = true;
           if (MODE == kModeRxReal) {
             // A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2j
-            const v2f a0 = lds_ld(lds, i), b0 = lds_ld(lds, ib);
-            v2f sa = pk_add_conj(a0, b0);
-            v2f sb = pk_sub_conj(a0, b0);
-            v2f zn = a0;  // Z[n/2] partial sum, only meaningful for i == 0
+            v2f sa = pk_add_conj(av[0], bv[0]);
+            v2f sb = pk_sub_conj(av[0], bv[0]);
+            v2f zn = av[0];  // Z[n/2] partial sum, only meaningful for i == 0
 #pragma unroll
             for (int t = 1; t < 8; t++) {
-              const v2f a = lds_ld(lds, i + 256 * t), b = lds_ld(lds, ib + 256 * t);
-              if (do_a) sa = pk_cfma(pk_add_conj(a, b), w[t], sa);
-              if (do_b) sb = pk_cfma(pk_sub_conj(a, b), w[t], sb);
-              if (r == 0) zn = (t & 1) ? (zn - a) : (zn + a);
+              if (do_a) sa = pk_cfma(pk_add_conj(av[t], bv[t]), w[t], sa);
+              if (do_b) sb = pk_cfma(pk_sub_conj(av[t], bv[t]), w[t], sb);
+              if (r == 0) zn = (t & 1) ? (zn - av[t]) : (zn + av[t]);
             }
+            // Window search on q = 4 |X|^2 (monotonic in |X|); the finaliser takes the
+            // square root of the four winners only: |X| = 0.5 sqrt(q).
             float ma = 0.f, mb = 0.f;
-            if (do_a) ma = 0.5f * sqrtf(sa.x * sa.x + sa.y * sa.y);
-            if (do_b) mb = 0.5f * sqrtf(sb.x * sb.x + sb.y * sb.y);
+            if (do_a) ma = sa.x * sa.x + sa.y * sa.y;
+            if (do_b) mb = sb.x * sb.x + sb.y * sb.y;
             if (r == 0 && i == 0) {
-              // Q2: the packed RFFT stores Re X[n/2] in the imaginary slot of bin 0,
-              // so the reference's mag[0] is hypot(X0, X[n/2]) (receiver/Src/main.c:178)
-              const float x0u = 0.5f * sa.x;  // Re Z[0] = X_up[0]
-              const float x0d = 0.5f * sb.y;  // Im Z[0] = X_down[0]   (sb = 2j * Im)
-              if (p.true_dc) {
-                ma = fabsf(x0u);
-                mb = fabsf(x0d);
-              } else {
-                ma = sqrtf(x0u * x0u + zn.x * zn.x);
-                mb = sqrtf(x0d * x0d + zn.y * zn.y);
+              // Q2: the packed RFFT stores Re X[n/2] in the imaginary slot of bin 0, so the
+              // reference's mag[0] is hypot(X0, X[n/2]) (receiver/Src/main.c:178).
+              // sa.x = 2 Re Z[0] = 2 X_up[0], sb.y = 2 Im Z[0] = 2 X_down[0], zn = Z[n/2].
+              ma = sa.x * sa.x;
+              mb = sb.y * sb.y;
+              if (!p.true_dc) {
+                ma += 4.0f * (zn.x * zn.x);
+                mb += 4.0f * (zn.y * zn.y);
               }
             }
             m_a[r] = ma;
             m_b[r] = mb;
           } else {
-            v2f zl = lds_ld(lds, i), zh = lds_ld(lds, ib);
+            v2f zl = av[0], zh = bv[0];
 #pragma unroll
             for (int t = 1; t < 8; t++) {
-              if (do_a) zl = pk_cfma(lds_ld(lds, i + 256 * t), w[t], zl);
-              if (do_b) zh = pk_cfmac(lds_ld(lds, ib + 256 * t), w[t], zh);
+              if (do_a) zl = pk_cfma(av[t], w[t], zl);
+              if (do_b) zh = pk_cfmac(bv[t], w[t], zh);
             }
-            if (do_a) m_a[r] = sqrtf(zl.x * zl.x + zl.y * zl.y);
-            if (do_b) m_b[r] = sqrtf(zh.x * zh.x + zh.y * zh.y);
+            if (do_a) m_a[r] = zl.x * zl.x + zl.y * zl.y;  // |Z|^2: the finaliser takes sqrt
+            if (do_b) m_b[r] = zh.x * zh.x + zh.y * zh.y;
           }
         }
       }
       UC_STAMP(6);
-
       // ---- windows: this wave's partial arm_max_f32 results, in registers -----
       // (bins beyond bw2 fail the window predicates inside window_partial)
       const int k1 = 128 + lane;

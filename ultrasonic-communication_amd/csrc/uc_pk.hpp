@@ -21,35 +21,37 @@ __device__ __forceinline__ v2f mkv(float re, float im) { v2f r; r.x = re; r.y = 
 
 // a * w
 __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
-  v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(t) : "v"(a), "v"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+      : "=&v"(r) : "v"(a), "v"(w));
   return r;
 }
 
 // a * conj(w)
 __device__ __forceinline__ v2f pk_cmulc(v2f a, v2f w) {
-  v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]" : "=v"(t) : "v"(a), "v"(w));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+      : "=&v"(r) : "v"(a), "v"(w));
   return r;
 }
 
 // acc + a * w
 __device__ __forceinline__ v2f pk_cfma(v2f a, v2f w, v2f acc) {
-  v2f t, r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]"
-      : "=v"(t) : "v"(a), "v"(w), "v"(acc));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-  return r;
+  // in place on the accumulator: acc is both input and output
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1] neg_lo:[0,1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+      : "+v"(acc) : "v"(a), "v"(w));
+  return acc;
 }
 
 // acc + a * conj(w)
 __device__ __forceinline__ v2f pk_cfmac(v2f a, v2f w, v2f acc) {
-  v2f t, r;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,0,1]" : "=v"(t) : "v"(a), "v"(w), "v"(acc));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(a), "v"(w), "v"(t));
-  return r;
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,1,0] op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_hi:[1,0,0]"
+      : "+v"(acc) : "v"(a), "v"(w));
+  return acc;
 }
 
 // x + (-j) d  = (x.re + d.im, x.im - d.re)
@@ -98,52 +100,64 @@ __device__ __forceinline__ v2f pk_scale_hi(v2f w, v2f x) {
 }
 
 // ---- multiplications by the fixed radix-16 twiddles -------------------------
-// K = (cos(pi/8), sin(pi/8)), H = (sqrt(1/2), sqrt(1/2)) live in two register pairs.
+// K = (cos(pi/8), sin(pi/8)), H = (sqrt(1/2), sqrt(1/2)) live in two SGPR pairs ("s" operands:
+// wave-uniform constants cost no VGPRs).
 
 // a * W16^1 = a * (c, -s) = (a.re c + a.im s, a.im c - a.re s)
 __device__ __forceinline__ v2f pk_mul_w1(v2f a, v2f K) {
-  v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(K));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(a), "v"(K), "v"(t));
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]"
+      : "=&v"(r) : "v"(a), "s"(K));
   return r;
 }
 // a * W16^3 = a * (s, -c) = (a.re s + a.im c, a.im s - a.re c)
 __device__ __forceinline__ v2f pk_mul_w3(v2f a, v2f K) {
-  v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]" : "=v"(t) : "v"(a), "v"(K));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(r) : "v"(a), "v"(K), "v"(t));
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[0,0] neg_hi:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+      : "=&v"(r) : "v"(a), "s"(K));
   return r;
 }
 // a * W16^9 = -(a * W16^1)
 __device__ __forceinline__ v2f pk_mul_w9(v2f a, v2f K) {
-  v2f t, r;
-  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]" : "=v"(t) : "v"(a), "v"(K));
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
-      : "=v"(r) : "v"(a), "v"(K), "v"(t));
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[0,1] neg_lo:[1,0]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+      : "=&v"(r) : "v"(a), "s"(K));
   return r;
 }
 // a * W16^2 = a * (h, -h) = h (a.re + a.im, a.im - a.re)
 __device__ __forceinline__ v2f pk_mul_w2(v2f a, v2f H) {
-  v2f t, r;
-  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(t) : "v"(a));
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(H));
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+      "v_pk_mul_f32 %0, %0, %2"
+      : "=&v"(r) : "v"(a), "s"(H));
   return r;
 }
 // a * W16^6 = a * (-h, -h) = h (a.im - a.re, -(a.re + a.im))
 __device__ __forceinline__ v2f pk_mul_w6(v2f a, v2f H) {
-  v2f t, r;
-  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]" : "=v"(t) : "v"(a));
-  asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(t), "v"(H));
+  v2f r;
+  asm("v_pk_add_f32 %0, %1, %1 op_sel:[1,0] op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[1,1]\n\t"
+      "v_pk_mul_f32 %0, %0, %2"
+      : "=&v"(r) : "v"(a), "s"(H));
   return r;
 }
 
 // forward 4-point DFT in place, natural order (8 packed instructions)
+// One asm block: hipcc pads every dependent pair of separate asm statements with an
+// s_nop, which the hardware does not need between packed-fp32 VALU instructions.
 __device__ __forceinline__ void pk_dft4(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {
-  const v2f a0 = x0 + x2, a1 = x0 - x2, a2 = x1 + x3, d = x1 - x3;
-  x0 = a0 + a2;
-  x2 = a0 - a2;
-  x1 = pk_add_mj(a1, d);
-  x3 = pk_sub_mj(a1, d);
+  v2f a1, d;
+  asm("v_pk_add_f32 %4, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"   // a1 = x0 - x2
+      "v_pk_add_f32 %0, %0, %2\n\t"                              // a0 = x0 + x2   (in x0)
+      "v_pk_add_f32 %5, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"   // d  = x1 - x3
+      "v_pk_add_f32 %1, %1, %3\n\t"                              // a2 = x1 + x3   (in x1)
+      "v_pk_add_f32 %2, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"   // X2 = a0 - a2
+      "v_pk_add_f32 %0, %0, %1\n\t"                              // X0 = a0 + a2
+      "v_pk_add_f32 %1, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"  // X1 = a1 + (-j) d
+      "v_pk_add_f32 %3, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"        // X3 = a1 - (-j) d
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(a1), "=&v"(d));
 }
 
 // forward 16-point DFT as 4 x 4; X[t] ends up in v[4*(t&3) + (t>>2)]
