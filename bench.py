@@ -141,6 +141,16 @@ def main():
         total_frames = world * nf * args.steps
         value = total_frames / elapsed
         achieved = nf * BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+        # collected with rocprofv3 --pmc in their own runs: profiles/*_hbm_traffic.json), scaled to
+        # this launch's frame count; null if no profile is committed.
+        traffic = None
+        try:
+            import glob
+            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]
+            traffic = json.load(open(tf))["hbm_bytes_per_frame"] * nf
+        except Exception:
+            traffic = None
         out = {
             "metric": "chirp frames/s (2048-pt FFT demod)", "value": value, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -151,7 +161,7 @@ def main():
                        "frames_per_gpu": nf, "frame_len": N, "variant": "rx_real",
                        "parallelism": "frame-sharded x%d, RCCL all-gather of symbols" % world},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "band_kernel<rx_real,f32>", "kernel_ms": kern_ms,
                          "bytes_per_frame": BYTES_PER_FRAME},
             "bit_error_rate_vs_transmitted": ber,

@@ -158,6 +158,55 @@ __device__ __forceinline__ Partial window_partial(float vr0, float vl0, int k0, 
   return o;
 }
 
+// RX_REAL: both windows of a history look at the SAME magnitudes; they differ only in
+// bin 0 (right window only) and bin bw2 (left window only).  So one maximum over the
+// common bins [1, bw2) with its smallest and its largest attaining bin serves both, and
+// the two edge bins are folded in by the finaliser (3 wave reductions instead of 4).
+struct Common {
+  float m;
+  int ks, kl;
+};
+
+template <bool HAS1>
+__device__ __forceinline__ Common common_partial(float q0, int k0, float q1, int k1, int bw2) {
+  const float ninf = -INFINITY;
+  const float c0 = (k0 >= 1 && k0 < bw2) ? q0 : ninf;
+  float c1 = ninf;
+  if (HAS1) c1 = (k1 < bw2) ? q1 : ninf;
+  Common o;
+  o.m = wave_max_f32(HAS1 ? max_f32(c0, c1) : c0);
+  int cs = (c0 == o.m) ? k0 : 0x7fffffff;
+  int cl = (c0 == o.m) ? k0 : -1;
+  if (HAS1) {
+    const int cs1 = (c1 == o.m) ? k1 : 0x7fffffff;
+    const int cl1 = (c1 == o.m) ? k1 : -1;
+    cs = cs1 < cs ? cs1 : cs;
+    cl = cl1 > cl ? cl1 : cl;
+  }
+  o.ks = wave_min_u32(cs);
+  o.kl = wave_max_i32(cl);
+  if (o.ks == 0x7fffffff) o.ks = 0;
+  if (o.kl < 0) o.kl = 0;
+  return o;
+}
+
+// finaliser side of common_partial: merge the two waves' common maxima, then fold in the
+// edge bins exactly as arm_max_f32 would meet them (first element wins ties, NaN sticks)
+__device__ __forceinline__ void resolve_windows(float m0, int ks0, int kl0, float m1, int ks1, int kl1, float q_first,
+                                                float q_last, int bw2, float& vr, int& kr, float& vl, int& kl) {
+  const float a = (m0 != m0) ? -INFINITY : m0;
+  const float b = (m1 != m1) ? -INFINITY : m1;
+  float m;
+  int ks, kg;
+  if (b > a) { m = b; ks = ks1; kg = kl1; }
+  else if (a > b) { m = a; ks = ks0; kg = kl0; }
+  else { m = a; ks = ks0 < ks1 ? ks0 : ks1; kg = kl0 > kl1 ? kl0 : kl1; }
+  // right window: bin 0 first, then ascending bins
+  if (q_first != q_first || !(m > q_first)) { vr = q_first; kr = 0; } else { vr = m; kr = ks; }
+  // left window: bin bw2 first, then descending bins
+  if (q_last != q_last || !(m > q_last)) { vl = q_last; kl = bw2; } else { vl = m; kl = kg; }
+}
+
 struct Hist {
   float mag_max, mag_left, mag_right, snr;
   int32_t f, fl, fr;
@@ -290,14 +339,24 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       const size_t ff = f0 + (size_t)lane;
       float mm_up = p.mag_mean_scalar, mm_dn = p.mag_mean_scalar;
       if (p.mag_mean) { mm_up = p.mag_mean[2 * ff]; mm_dn = p.mag_mean[2 * ff + 1]; }
-      const unsigned kp0 = __float_as_uint(e[4]), kp1 = __float_as_uint(e[6 + 4]);
-      const unsigned fl = __float_as_uint(e[5]) | __float_as_uint(e[6 + 5]);
       float mr, ml;
       int kr, kl;
       // the ring holds squared magnitudes (x4 for RX_REAL): |X| = mscale * sqrt(q)
       const float mscale = (MODE == kModeRxReal) ? 0.5f : 1.0f;
-      merge_window(e[0], kp0 & 255, e[6 + 0], kp1 & 255, true, fl & 1u, 0, mr, kr);
-      merge_window(e[1], (kp0 >> 8) & 255, e[6 + 1], (kp1 >> 8) & 255, false, fl & 2u, bw2, ml, kl);
+      unsigned kp0, kp1, fl = 0;
+      if (MODE == kModeRxReal) {
+        // per wave: [M_up, M_dn, kpack, edge_up, edge_dn]; wave 0's edge = bin 0, wave 1's = bin bw2
+        kp0 = __float_as_uint(e[2]);
+        kp1 = __float_as_uint(e[6 + 2]);
+        resolve_windows(e[0], kp0 & 255, (kp0 >> 8) & 255, e[6 + 0], kp1 & 255, (kp1 >> 8) & 255, e[3], e[6 + 3],
+                        bw2, mr, kr, ml, kl);
+      } else {
+        kp0 = __float_as_uint(e[4]);
+        kp1 = __float_as_uint(e[6 + 4]);
+        fl = __float_as_uint(e[5]) | __float_as_uint(e[6 + 5]);
+        merge_window(e[0], kp0 & 255, e[6 + 0], kp1 & 255, true, fl & 1u, 0, mr, kr);
+        merge_window(e[1], (kp0 >> 8) & 255, e[6 + 1], (kp1 >> 8) & 255, false, fl & 2u, bw2, ml, kl);
+      }
       mr = mscale * sqrtf(mr);
       ml = mscale * sqrtf(ml);
       const Hist h0 = make_hist(mr, kr, ml, kl, mm_up, p.ifs, p.single != 0);
@@ -305,8 +364,13 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         if (p.stats) store_hist(p.stats + ff, h0, mm_up);
         if (p.symbols) p.symbols[ff] = (uint8_t)UC_SYM_NONE;
       } else {
-        merge_window(e[2], (kp0 >> 16) & 255, e[6 + 2], (kp1 >> 16) & 255, true, fl & 4u, 0, mr, kr);
-        merge_window(e[3], (kp0 >> 24) & 255, e[6 + 3], (kp1 >> 24) & 255, false, fl & 8u, bw2, ml, kl);
+        if (MODE == kModeRxReal) {
+          resolve_windows(e[1], (kp0 >> 16) & 255, (kp0 >> 24) & 255, e[6 + 1], (kp1 >> 16) & 255, (kp1 >> 24) & 255,
+                          e[4], e[6 + 4], bw2, mr, kr, ml, kl);
+        } else {
+          merge_window(e[2], (kp0 >> 16) & 255, e[6 + 2], (kp1 >> 16) & 255, true, fl & 4u, 0, mr, kr);
+          merge_window(e[3], (kp0 >> 24) & 255, e[6 + 3], (kp1 >> 24) & 255, false, fl & 8u, bw2, ml, kl);
+        }
         mr = mscale * sqrtf(mr);
         ml = mscale * sqrtf(ml);
         const Hist h1 = make_hist(mr, kr, ml, kl, mm_dn, p.ifs, false);
@@ -473,21 +537,30 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // ---- windows: this wave's partial arm_max_f32 results, in registers -----
       // (bins beyond bw2 fail the window predicates inside window_partial)
       const int k1 = 128 + lane;
+      float* e = ring + ring_n * kRingStride + wave * 6;
       if (MODE == kModeRxReal) {
         // up history looks at m_a, down history at m_b; wave 1 also holds slot 1
-        Partial up, dn;
+        Common up, dn;
         if (wave == 0) {
-          up = window_partial<false, false>(m_a[0], m_a[0], j, 0.f, 0.f, k1, bw2);
-          dn = window_partial<false, false>(m_b[0], m_b[0], j, 0.f, 0.f, k1, bw2);
+          up = common_partial<false>(m_a[0], j, 0.f, k1, bw2);
+          dn = common_partial<false>(m_b[0], j, 0.f, k1, bw2);
         } else {
-          up = window_partial<true, true>(m_a[0], m_a[0], j, m_a[1], m_a[1], k1, bw2);
-          dn = window_partial<true, true>(m_b[0], m_b[0], j, m_b[1], m_b[1], k1, bw2);
+          up = common_partial<true>(m_a[0], j, m_a[1], k1, bw2);
+          dn = common_partial<true>(m_b[0], j, m_b[1], k1, bw2);
         }
-        pv[0] = up.vr; pv[1] = up.vl; pv[2] = dn.vr; pv[3] = dn.vl;
-        kpack = (unsigned)up.kr | ((unsigned)up.kl << 8) | ((unsigned)dn.kr << 16) | ((unsigned)dn.kl << 24);
-        flags = up.nan_first | (dn.nan_first << 2);
+        if (lane == 0) {
+          e[0] = up.m;
+          e[1] = dn.m;
+          e[2] = __uint_as_float((unsigned)up.ks | ((unsigned)up.kl << 8) | ((unsigned)dn.ks << 16) |
+                                 ((unsigned)dn.kl << 24));
+        }
+        // edge bins go straight to the ring from the lanes that own them
+        float* e0 = ring + ring_n * kRingStride;
+        if (j == 0) { e0[3] = m_a[0]; e0[4] = m_b[0]; }
+        if (j == bw2) { e0[6 + 3] = m_a[0]; e0[6 + 4] = m_b[0]; }
+        if (wave == 1 && k1 == bw2) { e0[6 + 3] = m_a[1]; e0[6 + 4] = m_b[1]; }
       } else {
-        // right window looks at |Z[k]| (m_a), left window at |Z[n-k]| (m_b)
+        // right window looks at |Z[k]|^2 (m_a), left window at |Z[n-k]|^2 (m_b)
         Partial q;
         if (wave == 0) q = window_partial<false, false>(m_a[0], m_b[0], j, 0.f, 0.f, k1, bw2);
         else q = window_partial<true, true>(m_a[0], m_b[0], j, m_a[1], m_b[1], k1, bw2);
@@ -495,12 +568,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         pv[2 * run + 1] = q.vl;
         kpack |= ((unsigned)q.kr | ((unsigned)q.kl << 8)) << (16 * run);
         flags |= q.nan_first << (2 * run);
-      }
-      if (run == kRuns - 1 && lane == 0) {
-        float* e = ring + ring_n * kRingStride + wave * 6;
-        e[0] = pv[0]; e[1] = pv[1]; e[2] = pv[2]; e[3] = pv[3];
-        e[4] = __uint_as_float(kpack);
-        e[5] = __uint_as_float(flags);
+        if (run == kRuns - 1 && lane == 0) {
+          e[0] = pv[0]; e[1] = pv[1]; e[2] = pv[2]; e[3] = pv[3];
+          e[4] = __uint_as_float(kpack);
+          e[5] = __uint_as_float(flags);
+        }
       }
       UC_STAMP(8);
       __syncthreads();  // B4: tile free for the next pass 1; ring entry visible
