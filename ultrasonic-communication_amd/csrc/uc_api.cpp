@@ -81,6 +81,7 @@ struct uc_ctx {
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
   int band_blocks_per_cu[2] = {0, 0};
+  int full_blocks_per_cu = 0;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID): not part of the ABI
   int grid_override = 0;
 };
@@ -202,6 +203,24 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
         t1[2 * i + 1] = T.down[2 * i + 1] * T.hann[i];
       }
       break;
+    case UC_COMPRESS: {
+      // t0 <- full Hermitian spectrum of the windowed down chirp, scaled by 1/n (the inverse
+      // RFFT's scaling, chirp_compression_time_domain/Src/chirp.c:82); t1[0..n) <- symmetric Hann
+      const std::vector<float>& pk = T.h_down;
+      const float inv = 1.0f / (float)n;
+      t0[0] = pk[0] * inv;
+      t0[1] = 0.0f;
+      t0[2 * (n / 2)] = pk[1] * inv;
+      t0[2 * (n / 2) + 1] = 0.0f;
+      for (uint32_t k = 1; k < n / 2; k++) {
+        t0[2 * k] = pk[2 * k] * inv;
+        t0[2 * k + 1] = pk[2 * k + 1] * inv;
+        t0[2 * (n - k)] = pk[2 * k] * inv;
+        t0[2 * (n - k) + 1] = -pk[2 * k + 1] * inv;
+      }
+      for (uint32_t i = 0; i < n; i++) t1[i] = T.hann[i];
+      break;
+    }
     default:
       break;
   }
@@ -287,7 +306,7 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   const uint32_t n = c->cfg.n;
   if (stride_elems == 0) stride_elems = n;
   const int variant = c->cfg.variant;
-  if (variant == UC_COMPRESS || variant == UC_IQ)
+  if (variant == UC_IQ)
     return fail(-ENOSYS, "uc_process_batch: variant %d has no kernel yet", variant);
   const int spf = uc_stats_per_frame(c);
   const int halo = uc_iq_halo(c);
@@ -331,6 +350,29 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
     any_host_out = true;
   }
 
+  if (variant == UC_COMPRESS) {
+    uc::FullParams fp;
+    memset(&fp, 0, sizeof(fp));
+    fp.frames = d_frames;
+    fp.n_frames = n_frames;
+    fp.stride = stride_elems;
+    fp.hann = (const float*)c->d_tab1;
+    fp.hn = c->d_tab0;
+    fp.tw = c->d_tw;
+    fp.mag_mean = d_mm;
+    fp.symbols = d_sym;
+    fp.stats = d_stats;
+    fp.mag_mean_scalar = c->cfg.mag_mean;
+    if (c->full_blocks_per_cu == 0) c->full_blocks_per_cu = uc::compress_max_blocks_per_cu(dtype);
+    size_t grid = (size_t)c->num_cu * (size_t)c->full_blocks_per_cu;
+    if (c->grid_override > 0) grid = (size_t)c->grid_override;
+    const size_t npairs = (n_frames + 1) / 2;
+    if (grid > npairs) grid = npairs;
+    int lrc = uc::launch_compress(dtype, fp, (int)grid, stream);
+    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "compress kernel launch");
+    goto copy_back;
+  }
+  {
   uc::BandParams p;
   memset(&p, 0, sizeof(p));
   p.frames = d_frames;
@@ -358,6 +400,8 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   if (grid > n_frames) grid = n_frames;
   int lrc = uc::launch_band(mode, dtype, c->band_waves, p, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
+  }
+copy_back:
 
   if (any_host_out) {
     if (symbols && d_sym != symbols) {

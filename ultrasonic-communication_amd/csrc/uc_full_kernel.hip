@@ -1,0 +1,328 @@
+// uc_full_kernel.hip -- UC_COMPRESS: chirp compression by FFT x H x IFFT.
+//
+// Replaces, per frame (reference lines, experiments/chirp_compression_time_domain):
+//   windowing(pInOut)                          Src/chirp.c:47-50, 79   (symmetric Hann)
+//   arm_rfft_fast_f32(&S, pInOut, pInOut, 0)   Src/chirp.c:80
+//   arm_cmplx_mult_cmplx_f32(pInOut, H_down)   Src/chirp.c:81          (Q5 fixed: DC / Nyquist separately)
+//   arm_rfft_fast_f32(&S, pInOut, pInOut, 1)   Src/chirp.c:82          (inverse, 1/N inside)
+//   arm_max_f32(fft_inout, PCM_SAMPLES, ...)   Src/main.c:186-189      (signed maximum + index)
+//
+// Design (MI355X): the filter h is real, so two frames ride in ONE complex
+// transform (re = frame 2q, im = frame 2q+1) and stay separate through
+// FFT -> xH -> IFFT.  One 2-wave workgroup per frame pair, persistent.  Forward
+// 2048 = 16 x 16 x 8 Stockham (as uc_band_kernel.hip, full last pass); the
+// spectrum is multiplied by H/N in registers and -- because a Stockham first
+// pass consumes exactly the stride-256 octets the forward last pass produced --
+// the inverse transform (8 x 16 x 16) starts in the same registers: 4 LDS
+// exchanges per pair.  Inverse butterflies reuse the forward ones through
+// IDFT_R[k] = DFT_R[-k mod R] with conjugated twiddles.
+// HBM traffic: 2 x 8 KiB in, 2 x 32 B stats out per pair; H/N (16 KiB), Hann and
+// twiddles come from L2.
+#include "uc_kernels.hpp"
+#include "uc_pk.hpp"
+
+namespace uc {
+
+namespace {
+
+constexpr int T = kBandThreads;  // 128
+constexpr int kRedOff = 2 * kN;  // floats: per-wave reduction results after the tile
+constexpr int kLdsFloats = kRedOff + 16;
+
+constexpr float kSqrtHalfF = 0.70710678118654752440f;
+constexpr float kCos8 = 0.92387953251128675613f;
+constexpr float kSin8 = 0.38268343236508977173f;
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+constexpr int kRsrcFlags = 0x00020000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+}
+__device__ __forceinline__ float buf_ld32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return mkv(__uint_as_float(w.x), __uint_as_float(w.y));
+}
+__device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
+  return *reinterpret_cast<const v2f*>(lds + 2 * cidx);
+}
+__device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
+  *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
+}
+
+#define UC_DPP_REDUCE(OP, v)                                                                       \
+  do {                                                                                             \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));         \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));         \
+  } while (0)
+__device__ __forceinline__ float wave_max_f32(float v) {
+  UC_DPP_REDUCE("v_max_f32_dpp", v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_u32(int v) {
+  UC_DPP_REDUCE("v_min_u32_dpp", v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+template <int DTYPE>
+__device__ __forceinline__ float cvt1(float raw) {
+  if (DTYPE == UC_DTYPE_I32) return (float)__float_as_int(raw);
+  return raw;
+}
+
+// arm_max_f32 over the 2048 signed values of one frame held as v[slot].{x|y}, index j + 128 t
+template <int COMP>
+__device__ __forceinline__ void frame_max(const v2f (&y)[16], int j, int lane, float& out_v, int& out_i) {
+  // per thread: ascending t = ascending index, strict '>' keeps the first maximum
+  float m = COMP == 0 ? y[0].x : y[0].y;
+  int mi = j;
+  bool first_nan = false;
+  if (j == 0) first_nan = (m != m);  // element 0 of the frame: a NaN there sticks (arm_max_f32)
+#pragma unroll
+  for (int t = 1; t < 16; t++) {
+    const float c = COMP == 0 ? y[t].x : y[t].y;
+    // '!(m >= c)' also replaces a NaN running maximum by a number, like skipping NaNs
+    const bool take = (c > m) || (m != m && c == c);
+    m = take ? c : m;
+    mi = take ? j + T * t : mi;
+  }
+  const float ms = (m != m) ? -INFINITY : m;
+  const float wm = wave_max_f32(ms);
+  const int cand = (ms == wm) ? mi : 0x7fffffff;
+  const int wi = wave_min_u32(cand);
+  out_v = wm;
+  out_i = wi;
+  if (__ballot(first_nan)) {
+    out_v = __int_as_float(0x7fc00000);
+    out_i = 0;
+  }
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(T, 3) void compress_kernel(const FullParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float* red = lds + kRedOff;
+
+  const int j = threadIdx.x;
+  const int lane = j & 63;
+  const int wave = j >> 6;
+
+  const size_t npairs = (p.n_frames + 1) / 2;
+  const size_t chunk = (npairs + gridDim.x - 1) / gridDim.x;
+  size_t q = (size_t)blockIdx.x * chunk;
+  if (q >= npairs) return;
+  const size_t qend = (q + chunk < npairs) ? q + chunk : npairs;
+
+  const __amdgpu_buffer_rsrc_t rs_hn = make_rsrc(p.hn, kN * 8);
+  const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
+  const int voff8 = j * 8, voff4 = j * 4;
+  const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
+
+  // resident per-thread constants
+  float hw[16];  // symmetric Hann at this thread's samples
+  {
+    const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(p.hann, kN * 4);
+#pragma unroll
+    for (int t = 0; t < 16; t++) hw[t] = buf_ld32(rs_h, voff4, T * 4 * t);
+  }
+  v2f tw2[16];  // forward pass 2: W_256^(t k), k = j & 15
+#pragma unroll
+  for (int t = 1; t < 16; t++) tw2[t] = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN - 1)) * 8, 0);
+  const v2f tw3_1 = buf_ld64(rs_tw, (j & (kN - 1)) * 8, 0);        // W_2048^j
+  const v2f tw3_2 = buf_ld64(rs_tw, ((2 * j) & (kN - 1)) * 8, 0);  // W_2048^2j
+  const v2f tw3_4 = buf_ld64(rs_tw, ((4 * j) & (kN - 1)) * 8, 0);  // W_2048^4j
+
+  // LDS addresses (complex units)
+  const int s1 = j & 15;
+  const int wr1 = 16 * j;                                   // forward exchange 1: + (t ^ s1)
+  const int rd1e = (j & ~15) + ((j & 15) ^ (j >> 4));       // + 128 t, t even
+  const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);   // + 128 t, t odd
+  const int wr2 = (j >> 4) * 256 + (j & 15);                // forward exchange 2: + 16 t
+  const int rdA = j ^ ((j >> 4) & 7);                       // inverse exchange A read: + 128 t
+  // inverse exchange B write: element (j>>3)*128 + (j&7) + 8 t, swizzled by flipping bit 3
+  // for odd j>>3, i.e. t -> t ^ ((j>>3)&1): two bases, one for even and one for odd t
+  const int wrBe = (j >> 3) * 128 + (j & 7) + 8 * ((j >> 3) & 1);
+  const int wrBo = (j >> 3) * 128 + (j & 7) - 8 * ((j >> 3) & 1);
+  const int rdBe = j, rdBo = j ^ 8;                         // inverse exchange B read: + 128 t
+
+  const bool has_mm = p.mag_mean != nullptr;
+
+  for (; q < qend; q++) {
+    int s1v = s1;
+    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
+    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
+    const size_t fa = 2 * q, fb = 2 * q + 1;
+    const bool has_b = fb < p.n_frames;
+
+    // ---- load both frames, window, forward pass 1 ----------------------------
+    v2f v[16];
+    {
+      const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const char*>(p.frames) + fa * p.stride * 4, kN * 4);
+      const __amdgpu_buffer_rsrc_t rb =
+          make_rsrc(reinterpret_cast<const char*>(p.frames) + (has_b ? fb : fa) * p.stride * 4, has_b ? kN * 4 : 0);
+#pragma unroll
+      for (int t = 0; t < 16; t++) {
+        // hann * x, one float32 rounding, as windowing() does (chirp.c:47-50)
+        const float xa = cvt1<DTYPE>(buf_ld32(ra, voff4, T * 4 * t));
+        const float xb = cvt1<DTYPE>(buf_ld32(rb, voff4, T * 4 * t));  // zero records -> 0.0 when there is no frame b
+        v[t] = mkv(xa * hw[t], xb * hw[t]);
+      }
+    }
+    pk_dft16(v, K, H);
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    __syncthreads();
+
+    // ---- forward pass 2 ---------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], tw2[t]);
+    pk_dft16(v, K, H);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[pk_slot16(t)]);
+    __syncthreads();
+
+    // ---- forward pass 3 (full radix-8), x H/N, inverse pass A (radix-8) --------
+    // butterfly b = j (h = 0) and b = j + 128 (h = 1): X[b + 256 t], t = 0..7
+    v2f y8[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int b = j + T * h;
+      v2f u[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) u[t] = lds_ld(lds, b + 256 * t);
+      __builtin_amdgcn_sched_barrier(0);
+      v2f w[8];
+      if (h == 0) {
+        w[1] = t3a; w[2] = t3b; w[4] = t3c;
+      } else {  // W_2048^(t (j+128)) = W_2048^(t j) W_16^t
+        w[1] = pk_mul_w1(t3a, K); w[2] = pk_mul_w2(t3b, H); w[4] = pk_mul_mj(t3c);
+      }
+      w[3] = pk_cmul(w[1], w[2]);
+      w[5] = pk_cmul(w[1], w[4]);
+      w[6] = pk_cmul(w[2], w[4]);
+      w[7] = pk_cmul(w[3], w[4]);
+#pragma unroll
+      for (int t = 1; t < 8; t++) u[t] = pk_cmul(u[t], w[t]);
+      pk_dft8(u, H);
+      // spectrum bin k = b + 256 t sits in u[slot8(t)]: multiply by H_down[k] / N
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const v2f hk = buf_ld64(rs_hn, voff8 + T * 8 * h, 256 * 8 * t);
+        u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hk);
+      }
+      // inverse radix-8, Ns = 1 (no twiddles): inputs in natural t order
+      v2f g[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) g[t] = u[pk_slot8(t)];
+      pk_dft8(g, H);
+      // IDFT8[t] = DFT8[(8 - t) & 7]
+#pragma unroll
+      for (int t = 0; t < 8; t++) y8[h][t] = g[pk_slot8((8 - t) & 7)];
+    }
+    __syncthreads();  // all forward pass-3 reads done before the tile is overwritten
+    // inverse exchange A: element 8 b + t, swizzled phys = o ^ ((o >> 4) & 7)
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int b = j + T * h;
+#pragma unroll
+      for (int t = 0; t < 8; t++) lds_st(lds, 8 * b + (t ^ ((b >> 1) & 7)), y8[h][t]);
+    }
+    __syncthreads();
+
+    // ---- inverse pass B: radix-16, Ns = 8, conj twiddles W_128^(t k), k = j & 7
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rdA + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) {
+      const v2f w = buf_ld64(rs_tw, ((16 * t * (j & 7)) & (kN - 1)) * 8, 0);
+      v[t] = pk_cmulc(v[t], w);
+    }
+    pk_dft16(v, K, H);
+    __syncthreads();
+    // output t of the inverse = forward output (16 - t) & 15; element (j>>3)*128 + (j&7) + 8 t
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(lds, ((t & 1) ? wrBo : wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
+    __syncthreads();
+
+    // ---- inverse pass C: radix-16, Ns = 128, conj twiddles W_2048^(t j) ---------
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rdBo : rdBe) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) {
+      const v2f w = buf_ld64(rs_tw, ((t * j) & (kN - 1)) * 8, 0);
+      v[t] = pk_cmulc(v[t], w);
+    }
+    pk_dft16(v, K, H);
+    // y[j + 128 t] = inverse output t = v[slot16((16 - t) & 15)]; re = frame a, im = frame b
+    v2f y[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) y[t] = v[pk_slot16((16 - t) & 15)];
+
+    // ---- arm_max_f32 over the 2048 signed values of each frame -------------------
+    float va, vb;
+    int ia, ib;
+    frame_max<0>(y, j, lane, va, ia);
+    frame_max<1>(y, j, lane, vb, ib);
+    if (lane == 0) {
+      red[4 * wave + 0] = va;
+      red[4 * wave + 1] = __int_as_float(ia);
+      red[4 * wave + 2] = vb;
+      red[4 * wave + 3] = __int_as_float(ib);
+    }
+    __syncthreads();  // also frees the tile for the next pair
+    if (j < 2 && (j == 0 || has_b) && p.stats) {
+      // merge the two waves: value, then smallest index; a NaN partial only survives
+      // if element 0 was NaN (wave 0 reports it with index 0)
+      const float v0 = red[2 * j], v1 = red[4 + 2 * j];
+      const int i0 = __float_as_int(red[2 * j + 1]), i1 = __float_as_int(red[4 + 2 * j + 1]);
+      float mx;
+      int mi;
+      if (v0 != v0) { mx = v0; mi = i0; }
+      else if (v1 > v0 || (v1 == v0 && i1 < i0)) { mx = v1; mi = i1; }
+      else { mx = v0; mi = i0; }
+      const size_t ff = 2 * q + j;
+      const float mm = has_mm ? p.mag_mean[2 * ff] : p.mag_mean_scalar;
+      float4 a, bq;
+      a.x = mx; a.y = 0.0f; a.z = mx; a.w = __int_as_float(mi);
+      bq.x = __int_as_float(0); bq.y = __int_as_float(mi); bq.z = mm; bq.w = (mx - mm) / mm;
+      float4* d = reinterpret_cast<float4*>(p.stats + ff);
+      d[0] = a;
+      d[1] = bq;
+    }
+    if (j < 2 && (j == 0 || has_b) && p.symbols) p.symbols[2 * q + j] = (uint8_t)UC_SYM_NONE;
+  }
+}
+
+}  // namespace
+
+int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream) {
+  if (grid <= 0) return (int)hipSuccess;
+  if (dtype == UC_DTYPE_I32)
+    hipLaunchKernelGGL((compress_kernel<UC_DTYPE_I32>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  else
+    hipLaunchKernelGGL((compress_kernel<UC_DTYPE_F32>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+int compress_max_blocks_per_cu(int dtype) {
+  int nb = 0;
+  hipError_t e = dtype == UC_DTYPE_I32
+                     ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, compress_kernel<UC_DTYPE_I32>, T, 0)
+                     : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, compress_kernel<UC_DTYPE_F32>, T, 0);
+  if (e != hipSuccess || nb <= 0) nb = 4;
+  return nb;
+}
+
+}  // namespace uc

@@ -39,4 +39,20 @@ enum BandMode { kModeRxReal = 0, kModeCplx = 1 };
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
 int band_max_blocks_per_cu(int mode, int dtype, int waves);
 
+// Full-spectrum pipeline: UC_COMPRESS (FFT x H x IFFT, two frames per complex transform).
+struct FullParams {
+  const void* frames;     // device, int32 or float
+  size_t n_frames;
+  size_t stride;          // elements between frame starts
+  const float* hann;      // symmetric Hann, n floats
+  const float2* hn;       // full Hermitian spectrum of the reference, divided by n
+  const float2* tw;       // exp(-2 pi i k / 2048)
+  const float* mag_mean;  // device, 2 per frame (first used), or nullptr
+  uint8_t* symbols;       // device or nullptr (always UC_SYM_NONE)
+  uc_stats* stats;        // device or nullptr, 1 per frame
+  float mag_mean_scalar;
+};
+int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream);
+int compress_max_blocks_per_cu(int dtype);
+
 }  // namespace uc

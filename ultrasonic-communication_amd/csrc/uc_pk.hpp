@@ -178,3 +178,24 @@ __device__ __forceinline__ void pk_dft16(v2f (&v)[16], v2f K, v2f H) {
 }
 
 }  // namespace uc
+
+namespace uc {
+
+// forward 8-point DFT as 2 x 4; X[t] ends up in v[4*(t&1) + (t>>1)]
+__device__ __forceinline__ void pk_dft8(v2f (&v)[8], v2f H) {
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) {
+    const v2f a = v[n2], b = v[4 + n2];
+    v[n2] = a + b;
+    v[4 + n2] = a - b;
+  }
+  v[5] = pk_mul_w2(v[5], H);  // W8^1
+  v[6] = pk_mul_mj(v[6]);     // W8^2 = -j
+  v[7] = pk_mul_w6(v[7], H);  // W8^3
+  pk_dft4(v[0], v[1], v[2], v[3]);
+  pk_dft4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ constexpr int pk_slot8(int t) { return 4 * (t & 1) + (t >> 1); }
+__device__ __forceinline__ constexpr int pk_slot16(int t) { return 4 * (t & 3) + (t >> 2); }
+
+}  // namespace uc
