@@ -170,6 +170,31 @@ int uc_get_windows(const uc_ctx* ctx, uint32_t* bandwidth, uint32_t* bandwidth2,
 /* idx2freq(), integer arithmetic -- receiver/Src/main.c:154-160 */
 int32_t uc_idx2freq(const uc_ctx* ctx, uint32_t idx);
 
+/*
+ * The receiver's main loop over a recorded sample stream: ISR FIFO (receiver/Src/main.c:659-668),
+ * IDLE -> SYNCHRONIZING -> SYNCHRONIZED -> DATA_RECEIVING (main.c:417-554), resync (main.c:243-273,
+ * Q8 fixed: bounds are checked before evaluating), bit -> byte assembly MSB first (main.c:523-537).
+ * All dsp() calls of all blocks are evaluated in ONE batched launch (every FIFO offset the state
+ * machine can visit is a multiple of 256 samples: stride_elems = 256), then the switch() is
+ * replayed on the host over the statistics.  RX_REAL and SYNC_CPLX only.
+ */
+enum { UC_STATE_IDLE = 0, UC_STATE_SYNCHRONIZING = 1, UC_STATE_SYNCHRONIZED = 2, UC_STATE_DATA_RECEIVING = 3 };
+
+typedef struct uc_rx_event {      /* one per processed block */
+  uint32_t block;                 /* index of the 2048-sample block just appended to the FIFO */
+  uint32_t sync_position;         /* after the block was processed */
+  uint8_t  state_before, state_after;
+  int8_t   bit;                   /* 0 / 1 if a data bit was decoded in this block, else -1 */
+  uint8_t  reserved;
+  float    snr_up, snr_down;      /* of SYNCHRONIZED / DATA_RECEIVING blocks, else 0 */
+} uc_rx_event;
+
+/* samples: n_samples int32 / float words, host or device.  text receives the decoded characters
+ * ('\n' ends a message) and is always NUL-terminated; returns the number of characters or <0. */
+int uc_receive_stream(uc_ctx* ctx, const void* samples, int dtype, size_t n_samples,
+                      char* text, size_t text_cap,
+                      uc_rx_event* trace /*nullable*/, size_t trace_cap, size_t* n_trace /*nullable*/);
+
 /* human-readable text of the last error on this thread ("" if none) */
 const char* uc_last_error(void);
 

@@ -939,3 +939,188 @@ int uco_spectrum(uco_ctx* c, const void* frame, int dtype, int precision, double
   scratch_free(&s);
   return 0;
 }
+
+/* ------------------------------------------------------------------------- */
+/* the receiver's main loop, literally                                        */
+/* ------------------------------------------------------------------------- */
+
+typedef struct {
+  float mag_max, mag_mean, snr;
+} hist_lite;
+
+typedef struct {
+  const uco_ctx* c;
+  scratch s;
+  float* fifo; /* 3n */
+  int precision;
+} rx_env;
+
+/* dsp(): receiver/Src/main.c:183-231 on the FIFO */
+static void rx_dsp(rx_env* e, uint32_t pos, hist_lite* h, float mag_mean, int updown) {
+  uc_stats st;
+  if (e->c->cfg.variant == UC_RX_REAL) rx_real_one(e->c, &e->s, e->fifo + pos, UC_DTYPE_F32, updown, e->precision);
+  else sync_cplx_one(e->c, &e->s, e->fifo + pos, UC_DTYPE_F32, updown, e->precision);
+  fill_history(e->c, e->s.mag, mag_mean, &st);
+  h->mag_max = st.mag_max;
+  h->mag_mean = mag_mean;
+  h->snr = st.snr;
+}
+
+/* symbol_snr(): main.c:233-236 */
+static float rx_symbol_snr(rx_env* e, uint32_t pos, hist_lite* h, int updown) {
+  rx_dsp(e, pos, h, h->mag_mean, updown);
+  return h->snr;
+}
+
+/* resync(): main.c:243-273.  Q8 fixed: an out-of-range neighbour is not evaluated
+ * (the firmware evaluates it first and checks the bound afterwards). */
+static void rx_resync(rx_env* e, float snr, hist_lite* hist, uint32_t offset, uint32_t* sync_position, int updown) {
+  const uint32_t n = e->c->n;
+  int32_t pos_l = (int32_t)*sync_position - (int32_t)offset;
+  int32_t pos_r = (int32_t)*sync_position + (int32_t)offset;
+  float snr_l = -INFINITY, snr_r = -INFINITY;
+  if (pos_l >= 0) snr_l = rx_symbol_snr(e, (uint32_t)pos_l, &hist[2], updown);
+  if (pos_r <= (int32_t)(2 * n)) snr_r = rx_symbol_snr(e, (uint32_t)pos_r, &hist[3], updown);
+  if ((snr > snr_l) && (snr > snr_r)) {
+    /* keep */
+  } else {
+    if (snr_l >= snr_r) {
+      if (pos_l >= 0) *sync_position = (uint32_t)pos_l;
+    } else if (snr_l < snr_r) {
+      if (pos_r <= (int32_t)(2 * n)) *sync_position = (uint32_t)pos_r;
+    }
+  }
+}
+
+int uco_receive_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samples, int precision,
+                       char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
+  if (!c || (!samples && n_samples) || !text || text_cap == 0) return -EINVAL;
+  if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX) return -ENOTSUP;
+  const uint32_t n = c->n;
+  rx_env e;
+  e.c = c;
+  e.precision = precision;
+  if (scratch_alloc(&e.s, n)) { scratch_free(&e.s); return -ENOMEM; }
+  e.fifo = (float*)calloc(3 * (size_t)n, sizeof(float));
+  if (!e.fifo) { scratch_free(&e.s); return -ENOMEM; }
+
+  /* main()'s locals: receiver/Src/main.c:314-339 (history[] starts zeroed here; the
+   * firmware leaves it uninitialised, which only matters before the first full pass) */
+  uint32_t max_idx = 0, turn = 0;
+  const uint32_t offset = n / 8, shift = n / 4; /* main.c:406-407 */
+  hist_lite history[8];
+  memset(history, 0, sizeof(history));
+  float mag_stat[12];
+  for (int i = 0; i < 12; i++) mag_stat[i] = 1E37f;
+  float mag_max, mag_mean = 0.0f, mag_max_max;
+  uint32_t sync_cnt = 0, sync_position = n / 2;
+  float snr, snr_up, snr_down;
+  int state = UC_STATE_IDLE;
+  unsigned char msg = 0;
+  int msg_cnt = 0;
+  size_t nt = 0, ntext = 0;
+  const float thr = c->cfg.snr_threshold;
+
+  const size_t n_blocks = n_samples / n;
+  for (size_t b = 0; b < n_blocks; b++) {
+    /* ISR: main.c:659-668 */
+    memmove(e.fifo, e.fifo + n, sizeof(float) * 2 * n);
+    for (uint32_t i = 0; i < n; i++) e.fifo[2 * n + i] = load_sample(samples, dtype, b * (size_t)n + i);
+
+    const int prev_state = state;
+    int bit = -1;
+    snr_up = snr_down = 0.0f;
+    switch (state) {
+      case UC_STATE_IDLE: {
+        sync_cnt = 0;
+        float sum = 0.0f; /* arm_mean_f32(&mag_stat[4], 8, &mag_mean): main.c:431 */
+        for (int i = 4; i < 12; i++) sum += mag_stat[i];
+        mag_mean = sum / 8.0f;
+      }
+        /* intentionally no break: main.c:434 */
+        /* fall through */
+      case UC_STATE_SYNCHRONIZING:
+        for (uint32_t i = 0; i < 4; i++) { /* main.c:447-451 */
+          sync_position = n / 2 + turn * offset + shift * i;
+          rx_dsp(&e, sync_position, &history[i * 2 + turn], mag_mean, UC_UP_CHIRP);
+        }
+        turn = (turn == 0) ? 1 : 0;
+        if (turn == 1) {
+          for (int i = 10; i >= 0; i--) mag_stat[i + 1] = mag_stat[i];
+          mag_max_max = 0.0f;
+          for (int i = 0; i < 8; i++) {
+            mag_max = history[i].mag_max;
+            if (mag_max > mag_max_max) { mag_max_max = mag_max; max_idx = (uint32_t)i; }
+          }
+          mag_stat[0] = mag_max_max;
+          snr = (mag_max_max - mag_mean) / mag_mean;
+          if (snr >= thr) {
+            state = UC_STATE_SYNCHRONIZING;
+            if (++sync_cnt >= 3) {
+              state = UC_STATE_SYNCHRONIZED;
+              sync_position = n / 2 + max_idx * offset;
+            }
+          } else {
+            state = UC_STATE_IDLE;
+          }
+        }
+        break;
+      case UC_STATE_SYNCHRONIZED: /* main.c:491-510 */
+        snr_up = rx_symbol_snr(&e, sync_position, &history[0], UC_UP_CHIRP);
+        snr_down = rx_symbol_snr(&e, sync_position, &history[1], UC_DOWN_CHIRP);
+        if ((snr_up >= thr) || (snr_down >= thr)) {
+          if (snr_down > snr_up) {
+            rx_resync(&e, snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
+            state = UC_STATE_DATA_RECEIVING;
+          } else {
+            rx_resync(&e, snr_up, history, offset, &sync_position, UC_UP_CHIRP);
+          }
+        } else {
+          state = UC_STATE_IDLE;
+        }
+        break;
+      case UC_STATE_DATA_RECEIVING: /* main.c:512-550 */
+        snr_up = rx_symbol_snr(&e, sync_position, &history[0], UC_UP_CHIRP);
+        snr_down = rx_symbol_snr(&e, sync_position, &history[1], UC_DOWN_CHIRP);
+        if ((snr_up >= thr) || (snr_down >= thr)) {
+          if (snr_down > snr_up) {
+            bit = 0;
+            msg = (unsigned char)((msg << 1) + 0);
+            rx_resync(&e, snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
+          } else {
+            bit = 1;
+            msg = (unsigned char)((msg << 1) + 1);
+            rx_resync(&e, snr_up, history, offset, &sync_position, UC_UP_CHIRP);
+          }
+          if (++msg_cnt >= 8) {
+            if (ntext + 1 < text_cap) text[ntext++] = (char)msg;
+            msg = 0;
+            msg_cnt = 0;
+          }
+        } else {
+          if (ntext + 1 < text_cap) text[ntext++] = '\n';
+          state = UC_STATE_IDLE;
+          msg = 0;
+          msg_cnt = 0;
+        }
+        break;
+    }
+    if (trace && nt < trace_cap) {
+      uc_rx_event* ev = &trace[nt];
+      ev->block = (uint32_t)b;
+      ev->sync_position = sync_position;
+      ev->state_before = (uint8_t)prev_state;
+      ev->state_after = (uint8_t)state;
+      ev->bit = (int8_t)bit;
+      ev->reserved = 0;
+      ev->snr_up = snr_up;
+      ev->snr_down = snr_down;
+    }
+    nt++;
+  }
+  text[ntext] = '\0';
+  if (n_trace) *n_trace = nt;
+  free(e.fifo);
+  scratch_free(&e.s);
+  return (int)ntext;
+}

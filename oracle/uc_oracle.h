@@ -62,6 +62,12 @@ int uco_get_windows(const uco_ctx* ctx, uint32_t* bandwidth, uint32_t* bandwidth
                     uint32_t* idx_left_zero);
 int32_t uco_idx2freq(const uco_ctx* ctx, uint32_t idx);
 
+/* Literal, sequential restatement of the receiver's main loop over a recorded stream
+ * (receiver/Src/main.c:417-554, 243-273, 659-668): one dsp() per call site, in program order.
+ * Same outputs as uc_receive_stream (include/uchirp.h). */
+int uco_receive_stream(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples, int precision,
+                       char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace);
+
 /* the CMSIS-DSP primitives, restated (exposed for the golden-vector tests) */
 float uco_arm_cos_f32(float x);
 void  uco_arm_sin_cos_f32(float theta_deg, float* sin_val, float* cos_val);

@@ -26,6 +26,10 @@ class Config(C.Structure):
                 ("device", C.c_int32), ("flags", C.c_uint32)]
 
 
+RX_EVENT_DTYPE = np.dtype([("block", "<u4"), ("sync_position", "<u4"), ("state_before", "u1"), ("state_after", "u1"),
+                           ("bit", "i1"), ("reserved", "u1"), ("snr_up", "<f4"), ("snr_down", "<f4")])
+assert RX_EVENT_DTYPE.itemsize == 20
+
 STATS_DTYPE = np.dtype([("mag_max", "<f4"), ("mag_max_left", "<f4"), ("mag_max_right", "<f4"),
                         ("max_freq", "<i4"), ("max_freq_left", "<i4"), ("max_freq_right", "<i4"),
                         ("mag_mean", "<f4"), ("snr", "<f4")])
@@ -55,6 +59,8 @@ def lib():
         L.uco_destroy.restype = None
         L.uco_process_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+        L.uco_receive_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t,
+                                         C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.uco_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.uco_stats_per_frame.argtypes = [C.c_void_p]
         L.uco_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -154,6 +160,21 @@ class Oracle:
         if rc:
             raise RuntimeError("uco_process_batch rc=%d" % rc)
         return sym, stats
+
+    def receive(self, samples, precision=F64):
+        """The receiver's main loop over a recorded stream -> (text, trace[RX_EVENT_DTYPE])."""
+        a = np.ascontiguousarray(samples).reshape(-1)
+        if a.dtype not in (np.int32, np.float32):
+            raise TypeError("samples must be int32 or float32")
+        dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
+        nb = a.size // self.n
+        trace = np.zeros(nb, RX_EVENT_DTYPE)
+        text = C.create_string_buffer(4096)
+        nt = C.c_size_t(0)
+        rc = lib().uco_receive_stream(self._h, _ptr(a), dt, a.size, precision, text, 4096, _ptr(trace), nb, C.byref(nt))
+        if rc < 0:
+            raise RuntimeError("uco_receive_stream rc=%d" % rc)
+        return text.value.decode("latin-1"), trace[:nt.value]
 
     def spectrum(self, frame, precision=F64, halo=0):
         a = np.ascontiguousarray(frame).reshape(-1)

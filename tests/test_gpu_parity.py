@@ -321,3 +321,28 @@ def test_compress_variant_fft_h_ifft(uchirp):
     gs2, gst2 = e.process(fi)
     assert np.array_equal(gst2[:, 0]["max_freq"], rst2[:, 0]["max_freq"])
     assert (np.abs(gst2[:, 0]["mag_max"].astype(np.float64) - rst2[:, 0]["mag_max"]) / np.abs(rst2[:, 0]["mag_max"])).max() <= MAG_TOL
+
+
+@pytest.mark.parametrize("variant", [uco.SYNC_CPLX, uco.RX_REAL])
+def test_receive_stream_state_machine_matches_oracle(uchirp, variant):
+    """uc_receive_stream (one batched launch + host replay of main()'s switch) against the oracle's
+    literal sequential loop: same text, same per-block trace."""
+    from test_oracle_golden import _hello_stream
+    for seed, skew in ((1, 777), (2, 1500), (3, 0)):
+        x = _hello_stream(seed=seed, skew=skew)
+        o = uco.Oracle(variant)
+        e = uchirp.Engine(variant)
+        text_o, tr_o = o.receive(x, precision=uco.F64)
+        text_g, tr_g = e.receive(x)
+        assert text_g == text_o
+        assert len(tr_g) == len(tr_o) == x.size // 2048
+        for fld in ("state_before", "state_after", "bit", "sync_position"):
+            assert np.array_equal(tr_g[fld], tr_o[fld]), fld
+        act = tr_o["state_before"] >= 2
+        assert np.allclose(tr_g["snr_up"][act], tr_o["snr_up"][act], rtol=1e-4, atol=1e-3)
+        if variant == uco.SYNC_CPLX:
+            assert text_g == "Hello World!\n"
+    # device-resident stream, int32 words
+    import torch
+    xi = torch.from_numpy((np.round(_hello_stream()).astype(np.int64) * 256).astype(np.int32)).to("cuda:0")
+    assert uchirp.Engine(uco.SYNC_CPLX).receive(xi)[0] == "Hello World!\n"

@@ -2,6 +2,7 @@
 // No CPU compute path exists here: without a usable HIP device uc_create fails.
 #include <errno.h>
 #include <hip/hip_runtime.h>
+#include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -433,3 +434,203 @@ int uc_process_frame(uc_ctx* c, const int32_t* pcm_in, float mag_mean, uint8_t* 
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------
+// uc_receive_stream: the receiver's main loop over a recorded stream.
+// DSP: ONE batched launch over every 256-sample offset of the zero-prefixed
+// stream; control: main()'s switch replayed on the host over the statistics.
+// ---------------------------------------------------------------------------
+namespace {
+
+struct HistLite {
+  float mag_max = 0.0f, mag_mean = 0.0f, snr = 0.0f;
+};
+
+struct RxReplay {
+  const uc_stats* stats;  // [n_frames][2]: {up, down}
+  size_t n_frames;
+  uint32_t n;
+  size_t block;  // current block index b: FIFO = padded[b*n, b*n + 3n)
+
+  // dsp(): receiver/Src/main.c:183-231 -- the frame at FIFO offset pos is frame (b*n + pos)/256
+  void dsp(uint32_t pos, HistLite* h, float mag_mean, int updown) const {
+    const size_t g = (block * (size_t)n + pos) / 256;
+    const uc_stats& s = stats[2 * g + (updown == UC_UP_CHIRP ? 0 : 1)];
+    h->mag_max = s.mag_max;
+    h->mag_mean = mag_mean;
+    h->snr = (s.mag_max - mag_mean) / mag_mean;  // main.c:229
+  }
+  float symbol_snr(uint32_t pos, HistLite* h, int updown) const {  // main.c:233-236
+    dsp(pos, h, h->mag_mean, updown);
+    return h->snr;
+  }
+  // resync(): main.c:243-273, Q8 fixed (bounds first)
+  void resync(float snr, HistLite* hist, uint32_t offset, uint32_t* sync_position, int updown) const {
+    const int32_t pos_l = (int32_t)*sync_position - (int32_t)offset;
+    const int32_t pos_r = (int32_t)*sync_position + (int32_t)offset;
+    float snr_l = -INFINITY, snr_r = -INFINITY;
+    if (pos_l >= 0) snr_l = symbol_snr((uint32_t)pos_l, &hist[2], updown);
+    if (pos_r <= (int32_t)(2 * n)) snr_r = symbol_snr((uint32_t)pos_r, &hist[3], updown);
+    if ((snr > snr_l) && (snr > snr_r)) return;
+    if (snr_l >= snr_r) {
+      if (pos_l >= 0) *sync_position = (uint32_t)pos_l;
+    } else if (snr_l < snr_r) {
+      if (pos_r <= (int32_t)(2 * n)) *sync_position = (uint32_t)pos_r;
+    }
+  }
+};
+
+}  // namespace
+
+extern "C" int uc_receive_stream(uc_ctx* c, const void* samples, int dtype, size_t n_samples, char* text,
+                                 size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
+  if (!c || !text || text_cap == 0) return fail(-EINVAL, "uc_receive_stream: NULL argument");
+  text[0] = '\0';
+  if (n_trace) *n_trace = 0;
+  if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX)
+    return fail(-ENOTSUP, "uc_receive_stream: variant %d has no up/down state machine", (int)c->cfg.variant);
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return fail(-EINVAL, "uc_receive_stream: bad dtype %d", dtype);
+  const uint32_t n = c->cfg.n;
+  const size_t n_blocks = n_samples / n;
+  if (n_blocks == 0) return 0;
+  if (!samples) return fail(-EINVAL, "uc_receive_stream: samples is NULL");
+
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  // zero-prefixed copy of the stream on the device: fifo_queue starts as 3n zeros (main.c:94)
+  const size_t padded = (2 + n_blocks) * (size_t)n;
+  const size_t n_frames = (padded - n) / 256 + 1;
+  void* d_pad = nullptr;
+  uc_stats* d_stats = nullptr;
+  e = hipMalloc(&d_pad, padded * 4);
+  if (e != hipSuccess) return hip_fail(e, "hipMalloc(stream)");
+  e = hipMalloc((void**)&d_stats, n_frames * 2 * sizeof(uc_stats));
+  if (e != hipSuccess) { (void)hipFree(d_pad); return hip_fail(e, "hipMalloc(stats)"); }
+  int rc = 0;
+  std::vector<uc_stats> stats(n_frames * 2);
+  e = hipMemset(d_pad, 0, 2 * (size_t)n * 4);
+  if (e == hipSuccess)
+    e = hipMemcpy((char*)d_pad + 2 * (size_t)n * 4, samples, n_blocks * (size_t)n * 4,
+                  is_device_ptr(samples) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+  if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(stream)");
+  if (!rc) rc = uc_process_batch(c, d_pad, dtype, n_frames, 256, nullptr, nullptr, d_stats, nullptr);
+  if (!rc) {
+    e = hipMemcpy(stats.data(), d_stats, stats.size() * sizeof(uc_stats), hipMemcpyDeviceToHost);  // syncs stream 0
+    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(stats)");
+  }
+  (void)hipFree(d_pad);
+  (void)hipFree(d_stats);
+  if (rc) return rc;
+
+  // main()'s locals: receiver/Src/main.c:314-339
+  RxReplay rx{stats.data(), n_frames, n, 0};
+  uint32_t max_idx = 0, turn = 0;
+  const uint32_t offset = n / 8, shift = n / 4;  // main.c:406-407
+  HistLite history[8];
+  float mag_stat[12];
+  for (float& v : mag_stat) v = 1E37f;
+  float mag_mean = 0.0f;
+  uint32_t sync_cnt = 0, sync_position = n / 2;
+  int state = UC_STATE_IDLE;
+  unsigned char msg = 0;
+  int msg_cnt = 0;
+  size_t nt = 0, ntext = 0;
+  const float thr = c->cfg.snr_threshold;
+
+  for (size_t b = 0; b < n_blocks; b++) {
+    rx.block = b;
+    const int prev_state = state;
+    int bit = -1;
+    float snr_up = 0.0f, snr_down = 0.0f;
+    switch (state) {
+      case UC_STATE_IDLE: {
+        sync_cnt = 0;
+        float sum = 0.0f;  // arm_mean_f32(&mag_stat[4], 8, &mag_mean): main.c:431
+        for (int i = 4; i < 12; i++) sum += mag_stat[i];
+        mag_mean = sum / 8.0f;
+      }
+        [[fallthrough]];  // "intentionally no break here": main.c:434
+      case UC_STATE_SYNCHRONIZING: {
+        for (uint32_t i = 0; i < 4; i++) {  // main.c:447-451
+          sync_position = n / 2 + turn * offset + shift * i;
+          rx.dsp(sync_position, &history[i * 2 + turn], mag_mean, UC_UP_CHIRP);
+        }
+        turn = (turn == 0) ? 1 : 0;
+        if (turn == 1) {
+          for (int i = 10; i >= 0; i--) mag_stat[i + 1] = mag_stat[i];
+          float mag_max_max = 0.0f;
+          for (int i = 0; i < 8; i++) {
+            const float mag_max = history[i].mag_max;
+            if (mag_max > mag_max_max) { mag_max_max = mag_max; max_idx = (uint32_t)i; }
+          }
+          mag_stat[0] = mag_max_max;
+          const float snr = (mag_max_max - mag_mean) / mag_mean;
+          if (snr >= thr) {
+            state = UC_STATE_SYNCHRONIZING;
+            if (++sync_cnt >= 3) {
+              state = UC_STATE_SYNCHRONIZED;
+              sync_position = n / 2 + max_idx * offset;
+            }
+          } else {
+            state = UC_STATE_IDLE;
+          }
+        }
+        break;
+      }
+      case UC_STATE_SYNCHRONIZED:  // main.c:491-510
+        snr_up = rx.symbol_snr(sync_position, &history[0], UC_UP_CHIRP);
+        snr_down = rx.symbol_snr(sync_position, &history[1], UC_DOWN_CHIRP);
+        if ((snr_up >= thr) || (snr_down >= thr)) {
+          if (snr_down > snr_up) {
+            rx.resync(snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
+            state = UC_STATE_DATA_RECEIVING;
+          } else {
+            rx.resync(snr_up, history, offset, &sync_position, UC_UP_CHIRP);
+          }
+        } else {
+          state = UC_STATE_IDLE;
+        }
+        break;
+      case UC_STATE_DATA_RECEIVING:  // main.c:512-550
+        snr_up = rx.symbol_snr(sync_position, &history[0], UC_UP_CHIRP);
+        snr_down = rx.symbol_snr(sync_position, &history[1], UC_DOWN_CHIRP);
+        if ((snr_up >= thr) || (snr_down >= thr)) {
+          if (snr_down > snr_up) {
+            bit = 0;
+            msg = (unsigned char)((msg << 1) + 0);
+            rx.resync(snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
+          } else {
+            bit = 1;
+            msg = (unsigned char)((msg << 1) + 1);
+            rx.resync(snr_up, history, offset, &sync_position, UC_UP_CHIRP);
+          }
+          if (++msg_cnt >= 8) {
+            if (ntext + 1 < text_cap) text[ntext++] = (char)msg;
+            msg = 0;
+            msg_cnt = 0;
+          }
+        } else {
+          if (ntext + 1 < text_cap) text[ntext++] = '\n';
+          state = UC_STATE_IDLE;
+          msg = 0;
+          msg_cnt = 0;
+        }
+        break;
+    }
+    if (trace && nt < trace_cap) {
+      uc_rx_event& ev = trace[nt];
+      ev.block = (uint32_t)b;
+      ev.sync_position = sync_position;
+      ev.state_before = (uint8_t)prev_state;
+      ev.state_after = (uint8_t)state;
+      ev.bit = (int8_t)bit;
+      ev.reserved = 0;
+      ev.snr_up = snr_up;
+      ev.snr_down = snr_down;
+    }
+    nt++;
+  }
+  text[ntext] = '\0';
+  if (n_trace) *n_trace = nt;
+  return (int)ntext;
+}

@@ -29,7 +29,7 @@ FLAG_LIBM_TRIG, FLAG_TRUE_DC = 1, 2
 
 EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", "uc_destroy",
            "uc_process_frame", "uc_process_batch", "uc_stats_per_frame", "uc_iq_halo",
-           "uc_get_table", "uc_get_windows", "uc_idx2freq"]
+           "uc_get_table", "uc_get_windows", "uc_idx2freq", "uc_receive_stream"]
 
 
 class Config(C.Structure):
@@ -39,6 +39,10 @@ class Config(C.Structure):
                 ("mag_mean", C.c_float), ("carrier", C.c_float), ("variant", C.c_int32),
                 ("device", C.c_int32), ("flags", C.c_uint32)]
 
+
+RX_EVENT_DTYPE = np.dtype([("block", "<u4"), ("sync_position", "<u4"), ("state_before", "u1"), ("state_after", "u1"),
+                           ("bit", "i1"), ("reserved", "u1"), ("snr_up", "<f4"), ("snr_down", "<f4")])
+STATE_IDLE, STATE_SYNCHRONIZING, STATE_SYNCHRONIZED, STATE_DATA_RECEIVING = range(4)
 
 STATS_DTYPE = np.dtype([("mag_max", "<f4"), ("mag_max_left", "<f4"), ("mag_max_right", "<f4"),
                         ("max_freq", "<i4"), ("max_freq_left", "<i4"), ("max_freq_right", "<i4"),
@@ -93,6 +97,8 @@ def lib():
     L.uc_get_windows.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 3
     L.uc_idx2freq.argtypes = [C.c_void_p, C.c_uint32]
     L.uc_idx2freq.restype = C.c_int32
+    L.uc_receive_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_char_p, C.c_size_t,
+                                    C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     _lib = L
     return L
 
@@ -152,6 +158,29 @@ class Engine:
 
     def idx2freq(self, idx):
         return lib().uc_idx2freq(self._h, int(idx))
+
+    def receive(self, samples):
+        """uc_receive_stream: the receiver's main loop over a recorded stream.
+        samples: numpy int32/float32 array or a torch device tensor.  Returns (text, trace)."""
+        if _is_torch(samples):
+            import torch
+            if not samples.is_contiguous():
+                raise ValueError("samples tensor must be contiguous")
+            dt = DTYPE_I32 if samples.dtype == torch.int32 else DTYPE_F32
+            ptr, count = C.c_void_p(samples.data_ptr()), samples.numel()
+        else:
+            a = np.ascontiguousarray(samples).reshape(-1)
+            if a.dtype not in (np.int32, np.float32):
+                raise TypeError("samples must be int32 or float32")
+            dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
+            ptr, count = a.ctypes.data_as(C.c_void_p), a.size
+        nb = count // self.n
+        trace = np.zeros(max(nb, 1), RX_EVENT_DTYPE)
+        text = C.create_string_buffer(4096)
+        nt = C.c_size_t(0)
+        _check(lib().uc_receive_stream(self._h, ptr, dt, count, text, 4096, trace.ctypes.data_as(C.c_void_p),
+                                       nb, C.byref(nt)), "uc_receive_stream")
+        return text.value.decode("latin-1"), trace[:nt.value]
 
     def process_frame(self, pcm, mag_mean=1.0):
         """uc_process_frame: n int32 DFSDM words -> (symbol, stats[spf])."""
