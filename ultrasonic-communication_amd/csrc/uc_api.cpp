@@ -83,6 +83,7 @@ struct uc_ctx {
   DevBuf s_frames, s_mm, s_sym, s_stats;
   int band_blocks_per_cu[2] = {0, 0};
   int full_blocks_per_cu = 0;
+  int iq_blocks_per_cu = 0;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID): not part of the ABI
   int grid_override = 0;
 };
@@ -170,6 +171,10 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 191-bin window the kernel evaluates",
                 c->tab.bandwidth2);
   }
+  if (cfg->variant == UC_IQ && c->tab.bandwidth4 > 256) {
+    delete c;
+    return fail(-ENOTSUP, "uc_create: IQ window of %u bins exceeds the 256 the kernel evaluates", c->tab.bandwidth4);
+  }
   e = hipSetDevice(c->device);
   if (e != hipSuccess) {
     delete c;
@@ -222,6 +227,16 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
       for (uint32_t i = 0; i < n; i++) t1[i] = T.hann[i];
       break;
     }
+    case UC_IQ:
+      // t0 <- carrier (cos, sin); t1 <- down chirp (cos, sin) * hann (Hann duplicated per re/im,
+      // experiments/iq_modulation/Src/main.c:126,237)
+      for (uint32_t i = 0; i < n; i++) {
+        t0[2 * i] = T.carrier_c[i];
+        t0[2 * i + 1] = T.carrier_s[i];
+        t1[2 * i] = T.down[2 * i] * T.hann[i];
+        t1[2 * i + 1] = T.down[2 * i + 1] * T.hann[i];
+      }
+      break;
     default:
       break;
   }
@@ -307,8 +322,6 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   const uint32_t n = c->cfg.n;
   if (stride_elems == 0) stride_elems = n;
   const int variant = c->cfg.variant;
-  if (variant == UC_IQ)
-    return fail(-ENOSYS, "uc_process_batch: variant %d has no kernel yet", variant);
   const int spf = uc_stats_per_frame(c);
   const int halo = uc_iq_halo(c);
 
@@ -351,6 +364,33 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
     any_host_out = true;
   }
 
+  if (variant == UC_IQ) {
+    uc::IqParams ip;
+    memset(&ip, 0, sizeof(ip));
+    ip.frames = d_frames;
+    ip.n_frames = n_frames;
+    ip.stride = stride_elems;
+    ip.carrier = c->d_tab0;
+    ip.chirp_hann = c->d_tab1;
+    ip.tw = c->d_tw;
+    ip.mag_mean = d_mm;
+    ip.symbols = d_sym;
+    ip.stats = d_stats;
+    for (int k = 0; k < uc::kFirTapsDev; k++) ip.fir[k] = c->tab.fir[k];
+    ip.mag_mean_scalar = c->cfg.mag_mean;
+    ip.fs = c->cfg.fs;
+    ip.idx_left_zero = c->tab.idx_left_zero;
+    ip.center = c->tab.center;
+    ip.bw2 = c->tab.bandwidth2;
+    ip.bw4 = c->tab.bandwidth4;
+    if (c->iq_blocks_per_cu == 0) c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype);
+    size_t grid = (size_t)c->num_cu * (size_t)c->iq_blocks_per_cu;
+    if (c->grid_override > 0) grid = (size_t)c->grid_override;
+    if (grid > n_frames) grid = n_frames;
+    int lrc = uc::launch_iq(dtype, ip, (int)grid, stream);
+    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "iq kernel launch");
+    goto copy_back;
+  }
   if (variant == UC_COMPRESS) {
     uc::FullParams fp;
     memset(&fp, 0, sizeof(fp));

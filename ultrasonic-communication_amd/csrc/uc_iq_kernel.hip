@@ -1,0 +1,306 @@
+// uc_iq_kernel.hip -- UC_IQ: I/Q down-conversion + chirp multiply + CFFT + band maxima.
+//
+// Replaces, per frame (reference lines, experiments/iq_modulation):
+//   iq_demodulation(): x*carrier_sin / x*carrier_cos              Src/iq_modem.c:60-61
+//                      2 x arm_fir_f32, 27 taps, state carried     Src/iq_modem.c:64-65, taps :18
+//   mult_ref_chirp():  (I + jQ) * down_chirp                       Src/chirp.c:46-48   (Q7 fixed: interleaved)
+//   Hann, arm_cfft_f32(len 2048), arm_cmplx_mag_f32(n/2)           Src/main.c:126-132
+//   arm_max_f32 x 3 over [idx_left_zero, +bw4), [.., +bw2), [center, +bw2)   Src/main.c:283-285
+//
+// Design (MI355X): one 2-wave workgroup per frame, persistent.  The frame plus its
+// 26-sample FIR history is mixed with the carrier while it is copied into a padded
+// LDS image (stride 17 per 16 samples: conflict-free for the per-thread sliding
+// window); every thread then filters 16 CONSECUTIVE outputs from a 42-sample register
+// window (27 packed FMAs per output, I and Q together), writes them back in the
+// XOR-swizzled layout of the band kernel's first exchange, and the 16 x 16 x 8 FFT
+// of uc_band_kernel.hip follows with the chirp*Hann table multiplied in pass 1.
+// Only the 4*bandwidth bins the three windows look at are evaluated in the last pass.
+// This variant is compute-bound (the FIR alone is ~110 kflop per frame, as much as
+// the FFT); HBM traffic is 8 KiB + 104 B of history in, 32 B of stats out per frame.
+#include "uc_kernels.hpp"
+#include "uc_pk.hpp"
+
+namespace uc {
+
+namespace {
+
+constexpr int T = kBandThreads;          // 128
+constexpr int kHalo = 26;                // FIR taps - 1
+constexpr int kMixLen = kN + kHalo;      // 2074 mixed samples
+constexpr int kMixPad = kMixLen + (kMixLen >> 4) + 2;  // padded image (complex units)
+constexpr int kRedOff = 2 * kMixPad;     // floats
+constexpr int kLdsFloats = kRedOff + 32;
+static_assert(kMixPad >= kN, "the FFT tile aliases the mixed image");
+
+constexpr float kSqrtHalfF = 0.70710678118654752440f;
+constexpr float kCos8 = 0.92387953251128675613f;
+constexpr float kSin8 = 0.38268343236508977173f;
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+constexpr int kRsrcFlags = 0x00020000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+}
+__device__ __forceinline__ float buf_ld32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return mkv(__uint_as_float(w.x), __uint_as_float(w.y));
+}
+__device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
+  return *reinterpret_cast<const v2f*>(lds + 2 * cidx);
+}
+__device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
+  *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
+}
+
+#define UC_DPP_REDUCE(OP, v)                                                                       \
+  do {                                                                                             \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));         \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));         \
+  } while (0)
+__device__ __forceinline__ float wave_max_f32(float v) {
+  UC_DPP_REDUCE("v_max_f32_dpp", v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_u32(int v) {
+  UC_DPP_REDUCE("v_min_u32_dpp", v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ float max_f32(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+template <int DTYPE>
+__device__ __forceinline__ float cvt1(float raw) {
+  if (DTYPE == UC_DTYPE_I32) return (float)__float_as_int(raw);
+  return raw;
+}
+
+// padded index of mixed sample m (m = frame index + 26)
+__device__ __forceinline__ int mix_idx(int m) { return m + (m >> 4); }
+
+// this wave's first-maximum (smallest bin on ties) over its candidates inside [lo, hi)
+__device__ __forceinline__ void window_first_max(float q0, int k0, float q1, int k1, int lo, int hi, float& v, int& k) {
+  const float c0 = (k0 >= lo && k0 < hi) ? q0 : -INFINITY;
+  const float c1 = (k1 >= lo && k1 < hi) ? q1 : -INFINITY;
+  v = wave_max_f32(max_f32(c0, c1));
+  int cand = (c0 == v) ? k0 : 0x7fffffff;
+  const int cand1 = (c1 == v) ? k1 : 0x7fffffff;
+  cand = cand1 < cand ? cand1 : cand;
+  k = wave_min_u32(cand);
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(T, 3) void iq_kernel(const IqParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float* red = lds + kRedOff;
+
+  const int j = threadIdx.x;
+  const int lane = j & 63;
+  const int wave = j >> 6;
+
+  const size_t nfr = p.n_frames;
+  const size_t chunk = (nfr + gridDim.x - 1) / gridDim.x;
+  size_t f = (size_t)blockIdx.x * chunk;
+  if (f >= nfr) return;
+  const size_t fend = (f + chunk < nfr) ? f + chunk : nfr;
+
+  const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN * 8);
+  const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN * 8);
+  const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
+  const int voff8 = j * 8;
+  const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
+
+  v2f tw2[16];  // pass 2: W_256^(t k), k = j & 15
+#pragma unroll
+  for (int t = 1; t < 16; t++) tw2[t] = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN - 1)) * 8, 0);
+
+  const int s1 = j & 15;
+  const int wr1 = 16 * j;                                   // exchange-1 layout: + (t ^ s1)
+  const int rd1e = (j & ~15) + ((j & 15) ^ (j >> 4));       // + 128 t, t even
+  const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);   // + 128 t, t odd
+  const int wr2 = (j >> 4) * 256 + (j & 15);                // exchange-2 layout: + 16 t
+
+  const int lo = (int)p.idx_left_zero, center = (int)p.center;
+  const int bw2 = (int)p.bw2, bw4 = (int)p.bw4;
+
+  for (; f < fend; f++) {
+    int s1v = s1;
+    asm volatile("" : "+v"(s1v));
+    // ---- stage 0: carrier mix while copying frame + history into the padded image ----
+    {
+      // sample i = -26 + j + 128 u of the frame; the resource starts at the first history sample
+      const __amdgpu_buffer_rsrc_t rx =
+          make_rsrc(reinterpret_cast<const char*>(p.frames) + (f * p.stride) * 4 - kHalo * 4, kMixLen * 4);
+#pragma unroll
+      for (int u = 0; u < 17; u++) {
+        const int m = j + T * u;  // 0 .. 2175, valid below kMixLen (out-of-range loads return 0)
+        if (m < kMixLen) {
+          const float x = cvt1<DTYPE>(buf_ld32(rx, j * 4, T * 4 * u));
+          const int i = m - kHalo;
+          // history was mixed with the TAIL of the table, as the previous back-to-back block's
+          // samples were (iq_modem.c:60-61 with the state carried in i_state / q_state)
+          const int ci = i < 0 ? kN + i : i;
+          const v2f cs = buf_ld64(rs_car, ci * 8, 0);
+          lds_st(lds, mix_idx(m), mkv(x * cs.x, x * cs.y));
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- stage 1: 27-tap FIR, 16 consecutive outputs per thread -----------------------
+    // output o = 16 j + u needs mixed[o + 26 - k], k = 0..26: window w[d] = mixed[16 j + d], d < 42
+    v2f acc[16];
+    {
+      v2f w[42];
+#pragma unroll
+      for (int d = 0; d < 42; d++) w[d] = lds_ld(lds, 17 * j + d + (d >> 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        v2f a = mkv(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kFirTapsDev; k++) {
+          const float b = p.fir[k];
+          a = __builtin_elementwise_fma(w[u + kHalo - k], mkv(b, b), a);
+        }
+        acc[u] = a;
+      }
+    }
+    __syncthreads();  // every window is in registers: the image may be overwritten
+#pragma unroll
+    for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), acc[u]);
+    __syncthreads();
+
+    // ---- stage 2: (I + jQ) * down_chirp * hann, FFT pass 1 -------------------------------
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], buf_ld64(rs_ch, voff8, T * 8 * t));
+    pk_dft16(v, K, H);
+    __syncthreads();  // all natural-order reads done before exchange 1 overwrites the tile
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    __syncthreads();
+
+    // ---- FFT pass 2 -----------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], tw2[t]);
+    pk_dft16(v, K, H);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[pk_slot16(t)]);
+    __syncthreads();
+
+    // ---- FFT pass 3, pruned: bins k = lo + j and k = lo + 128 + j (< lo + bw4) ------------
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int k = lo + T * r + j;
+      if (k < lo + bw4) {
+        const int b = k & 255;
+        v2f a[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) a[t] = lds_ld(lds, b + 256 * t);
+        v2f w[8];
+        w[1] = buf_ld64(rs_tw, (k & (kN - 1)) * 8, 0);
+        w[2] = buf_ld64(rs_tw, ((2 * k) & (kN - 1)) * 8, 0);
+        w[4] = buf_ld64(rs_tw, ((4 * k) & (kN - 1)) * 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        w[3] = pk_cmul(w[1], w[2]);
+        w[5] = pk_cmul(w[1], w[4]);
+        w[6] = pk_cmul(w[2], w[4]);
+        w[7] = pk_cmul(w[3], w[4]);
+        v2f z = a[0];
+#pragma unroll
+        for (int t = 1; t < 8; t++) z = pk_cfma(a[t], w[t], z);
+        q[r] = z.x * z.x + z.y * z.y;  // |Z[k]|^2, the square root is taken for the winners only
+      }
+    }
+
+    // ---- the three arm_max_f32 (first maximum wins) ---------------------------------------
+    const int k0 = lo + j, k1 = lo + T + j;
+    const float q1v = (k1 < lo + bw4) ? q[1] : -INFINITY;
+    float vl, vr;
+    int kl, kr;
+    window_first_max(q[0], k0, q1v, k1, lo, lo + bw2, vl, kl);           // left  [lo, lo + bw2)
+    window_first_max(q[0], k0, q1v, k1, center, center + bw2, vr, kr);   // right [center, center + bw2)
+    // first elements (a NaN there sticks): bin lo is thread 0 / round 0; bin `center` wherever it sits
+    const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
+    const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
+    if (lane == 0) {
+      red[8 * wave + 0] = vl;
+      red[8 * wave + 1] = __int_as_float(kl);
+      red[8 * wave + 2] = vr;
+      red[8 * wave + 3] = __int_as_float(kr);
+      red[8 * wave + 4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
+    }
+    __syncthreads();  // also frees the tile for the next frame
+    if (j == 0 && p.stats) {
+      float a0 = red[0], a1 = red[8], b0 = red[2], b1 = red[10];
+      int ka0 = __float_as_int(red[1]), ka1 = __float_as_int(red[9]);
+      int kb0 = __float_as_int(red[3]), kb1 = __float_as_int(red[11]);
+      const int flags = __float_as_int(red[4]) | __float_as_int(red[12]);
+      // merge waves: larger value, ties -> smaller bin
+      float ql = a0, qr = b0;
+      int il = ka0, ir = kb0;
+      if (a1 > a0 || (a1 == a0 && ka1 < ka0)) { ql = a1; il = ka1; }
+      if (b1 > b0 || (b1 == b0 && kb1 < kb0)) { qr = b1; ir = kb1; }
+      if (flags & 1) { ql = __int_as_float(0x7fc00000); il = lo; }
+      if (flags & 2) { qr = __int_as_float(0x7fc00000); ir = center; }
+      const float ml = sqrtf(ql), mr = sqrtf(qr);
+      // full window [lo, lo + bw4) = left then right: the right part wins only if strictly greater
+      float mx = ml;
+      int ix = il;
+      if (!(ml != ml) && mr > ml) { mx = mr; ix = ir; }
+      const float mm = p.mag_mean ? p.mag_mean[2 * f] : p.mag_mean_scalar;
+      // idx2freq of this experiment: (uint32)(sampling_rate * idx / n), Src/main.c:112-114
+      const float fsn = p.fs;
+      float4 sa, sb;
+      sa.x = mx; sa.y = ml; sa.z = mr;
+      sa.w = __int_as_float((int)(unsigned)(fsn * (float)ix / (float)kN));
+      sb.x = __int_as_float((int)(unsigned)(fsn * (float)il / (float)kN));
+      sb.y = __int_as_float((int)(unsigned)(fsn * (float)ir / (float)kN));
+      sb.z = mm;
+      sb.w = (mx - mm) / mm;
+      float4* d = reinterpret_cast<float4*>(p.stats + f);
+      d[0] = sa;
+      d[1] = sb;
+    }
+    if (j == 0 && p.symbols) p.symbols[f] = (uint8_t)UC_SYM_NONE;
+  }
+}
+
+}  // namespace
+
+int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream) {
+  if (grid <= 0) return (int)hipSuccess;
+  if (dtype == UC_DTYPE_I32)
+    hipLaunchKernelGGL((iq_kernel<UC_DTYPE_I32>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  else
+    hipLaunchKernelGGL((iq_kernel<UC_DTYPE_F32>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+int iq_max_blocks_per_cu(int dtype) {
+  int nb = 0;
+  hipError_t e = dtype == UC_DTYPE_I32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq_kernel<UC_DTYPE_I32>, T, 0)
+                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq_kernel<UC_DTYPE_F32>, T, 0);
+  if (e != hipSuccess || nb <= 0) nb = 4;
+  return nb;
+}
+
+}  // namespace uc

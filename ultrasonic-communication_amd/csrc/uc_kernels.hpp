@@ -55,4 +55,24 @@ struct FullParams {
 int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream);
 int compress_max_blocks_per_cu(int dtype);
 
+// UC_IQ: carrier mix + 27-tap FIR + chirp multiply + CFFT + three band maxima.
+constexpr int kFirTapsDev = 27;
+struct IqParams {
+  const void* frames;         // device; sample 0 of frame 0, 26 history samples sit in front of it
+  size_t n_frames;
+  size_t stride;
+  const float2* carrier;      // (cos, sin) of the carrier, n entries
+  const float2* chirp_hann;   // down chirp (cos, sin) * hann, n entries
+  const float2* tw;
+  const float* mag_mean;      // device, 2 per frame (first used), or nullptr
+  uint8_t* symbols;
+  uc_stats* stats;            // 1 per frame
+  float fir[kFirTapsDev];
+  float mag_mean_scalar;
+  float fs;
+  uint32_t idx_left_zero, center, bw2, bw4;
+};
+int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream);
+int iq_max_blocks_per_cu(int dtype);
+
 }  // namespace uc
