@@ -407,3 +407,70 @@ def test_iq_variant_mix_fir_chirp_cfft(uchirp):
     rs3, rst3 = o.process(xi, halo=26, n_frames=16)
     gs3, gst3 = e.process(xi, n_frames=16)
     assert (np.abs(gst3[:, 0]["mag_max"].astype(np.float64) - rst3[:, 0]["mag_max"]) / (256 * scale.max())).max() <= MAG_TOL
+
+
+def test_config5_hello_world_frames_at_minus_10_db(uchirp):
+    """BASELINE config 5 on one GPU: the K7 framing (7 H, 1 L, 96 data bits) rendered as pre-aligned
+    2048-sample frames at fs = 78125, AWGN -10 dB, repeated to fill the batch; per-frame decisions ->
+    MSB-first bytes.  Matched time_frame decodes the transmitted text; the literal TIME_FRAME = 0.0205
+    decodes whatever the oracle decodes (Q4)."""
+    import torch
+    from uchirp import shard, tx
+    seq = tx.symbol_sequence("Hello World!")
+    bits = seq[seq >= 0]                       # 7 H + L + 96 data bits
+    reps = 200
+    allbits = np.tile(bits, reps).astype(np.uint8)
+    up, down = synth.chirp_pair()
+    rng = np.random.default_rng(55)
+    frames = np.where(allbits[:, None] == 1, up[None, :], down[None, :])
+    frames = (frames + 1000.0 * 10 ** 0.5 * rng.standard_normal(frames.shape)).astype(np.float32)
+    fr = torch.from_numpy(frames).to("cuda:0")
+    tf = 2048.0 / 78125.0
+    for variant in (uchirp.RX_REAL, uchirp.SYNC_CPLX):
+        e = uchirp.Engine(variant, mag_mean=1000.0, time_frame=tf)
+        sym, _ = e.process(fr, want_stats=False)
+        torch.cuda.synchronize()
+        s = sym.cpu().numpy()
+        assert (s == allbits).mean() > 0.995
+        words = s.reshape(reps, -1)[:, 8:]     # drop preamble + delimiter
+        texts = [shard.symbols_to_bytes(np.where(w == 1, 1, 0)) for w in words]
+        assert sum(t == b"Hello World!" for t in texts) >= 0.9 * reps
+    # literal TIME_FRAME: GPU == oracle frame by frame, whatever the text
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+    o = uco.Oracle(uco.RX_REAL, mag_mean=1000.0)
+    gs, _ = e.process(frames[:1040], want_stats=False)
+    rs, rst = o.process(frames[:1040])
+    su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+    clear = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30) >= MARGIN
+    assert np.array_equal(gs[clear], rs[clear])
+
+
+def test_hip_graph_capture_of_the_batch_call(uchirp):
+    """The launch path is capturable (no allocation, no sync with device pointers): BASELINE config 4's
+    'hipGraph capture' -- a streaming loop of fixed-shape chunks replayed as one graph."""
+    import torch
+    frames, bits = synth.make_frames(4096, seed=9, snr_db=0.0)
+    dev = torch.device("cuda:0")
+    fr = torch.from_numpy(frames).to(dev)
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+    chunks = fr.view(4, 1024, 2048)
+    out = torch.empty((4, 1024), dtype=torch.uint8, device=dev)
+    ref, _ = e.process(fr, want_stats=False)                         # eager reference (also warms caches)
+    ref_rev, _ = e.process(torch.from_numpy(np.ascontiguousarray(frames[::-1])).to(dev), want_stats=False)
+    torch.cuda.synchronize()
+    assert (ref.cpu().numpy() == bits).mean() > 0.97
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            for c in range(4):
+                e.process(chunks[c], want_stats=False, symbols_out=out[c], stream=s.cuda_stream)
+    out.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(-1), ref)
+    fr.copy_(torch.from_numpy(np.ascontiguousarray(frames[::-1])))   # new data, same graph
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out.reshape(-1), ref_rev)
