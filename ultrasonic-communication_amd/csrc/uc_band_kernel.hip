@@ -175,18 +175,21 @@ __device__ __forceinline__ Common common_partial(float q0, int k0, float q1, int
   if (HAS1) c1 = (k1 < bw2) ? q1 : ninf;
   Common o;
   o.m = wave_max_f32(HAS1 ? max_f32(c0, c1) : c0);
-  int cs = (c0 == o.m) ? k0 : 0x7fffffff;
-  int cl = (c0 == o.m) ? k0 : -1;
-  if (HAS1) {
-    const int cs1 = (c1 == o.m) ? k1 : 0x7fffffff;
-    const int cl1 = (c1 == o.m) ? k1 : -1;
-    cs = cs1 < cs ? cs1 : cs;
-    cl = cl1 > cl ? cl1 : cl;
+  // the attaining bins from two ballots and scalar bit scans (slot 0 holds the smaller bins)
+  const int base = __builtin_amdgcn_readfirstlane(k0);
+  const unsigned long long b0 = __ballot(c0 == o.m);
+  unsigned long long b1 = 0;
+  if (HAS1) b1 = __ballot(c1 == o.m);
+  o.ks = 0;
+  o.kl = 0;
+  if (b0) {
+    o.ks = base + (__ffsll((long long)b0) - 1);
+    o.kl = base + (63 - __clzll((long long)b0));
   }
-  o.ks = wave_min_u32(cs);
-  o.kl = wave_max_i32(cl);
-  if (o.ks == 0x7fffffff) o.ks = 0;
-  if (o.kl < 0) o.kl = 0;
+  if (HAS1 && b1) {
+    if (!b0) o.ks = 128 + (__ffsll((long long)b1) - 1);
+    o.kl = 128 + (63 - __clzll((long long)b1));
+  }
   return o;
 }
 
@@ -494,15 +497,16 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           constexpr bool do_a = true, do_b = true;
           if (MODE == kModeRxReal) {
             // A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2j
-            v2f sa = pk_add_conj(av[0], bv[0]);
-            v2f sb = pk_sub_conj(av[0], bv[0]);
-            v2f zn = av[0];  // Z[n/2] partial sum, only meaningful for i == 0
+            // Z[k] = sum a_t w_t and Z[n-k] = sum b_t conj(w_t) first (2 packed FMAs per term each),
+            // then sa = Z[k] + conj Z[n-k] = 2 A[k], sb = Z[k] - conj Z[n-k] = 2j B[k]
+            v2f zl = av[0], zh = bv[0];
 #pragma unroll
             for (int t = 1; t < 8; t++) {
-              if (do_a) sa = pk_cfma(pk_add_conj(av[t], bv[t]), w[t], sa);
-              if (do_b) sb = pk_cfma(pk_sub_conj(av[t], bv[t]), w[t], sb);
-              if (r == 0) zn = (t & 1) ? (zn - av[t]) : (zn + av[t]);
+              zl = pk_cfma(av[t], w[t], zl);
+              zh = pk_cfmac(bv[t], w[t], zh);
             }
+            const v2f sa = pk_add_conj(zl, zh);
+            const v2f sb = pk_sub_conj(zl, zh);
             // Window search on q = 4 |X|^2 (monotonic in |X|); the finaliser takes the
             // square root of the four winners only: |X| = 0.5 sqrt(q).
             float ma = 0.f, mb = 0.f;
@@ -512,6 +516,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
               // Q2: the packed RFFT stores Re X[n/2] in the imaginary slot of bin 0, so the
               // reference's mag[0] is hypot(X0, X[n/2]) (receiver/Src/main.c:178).
               // sa.x = 2 Re Z[0] = 2 X_up[0], sb.y = 2 Im Z[0] = 2 X_down[0], zn = Z[n/2].
+              v2f zn = av[0];
+#pragma unroll
+              for (int t = 1; t < 8; t++) zn = (t & 1) ? (zn - av[t]) : (zn + av[t]);
               ma = sa.x * sa.x;
               mb = sb.y * sb.y;
               if (!p.true_dc) {
