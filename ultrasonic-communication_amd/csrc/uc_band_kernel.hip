@@ -314,9 +314,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   v2f tw2[16];
 #pragma unroll
   for (int t = 1; t < 16; t++) tw2[t] = ld_tw(p.tw, 8 * t * (j & 15));
-  // pass-3 twiddles W_2048^(t*j): t = 1, 2, 4 resident (t = 1 only when LEAN), the rest
-  // one or two products away
-  const v2f tw3_1 = ld_tw(p.tw, j), tw3_2 = ld_tw(p.tw, 2 * j), tw3_4 = ld_tw(p.tw, 4 * j);
+  // pass-3 twiddles: W_2048^j and its square (the pruned pass is evaluated in Horner form)
+  const v2f tw3_1 = ld_tw(p.tw, j), tw3_2 = ld_tw(p.tw, 2 * j);
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);  // SGPR pairs
 
   // LDS addresses (complex units)
@@ -400,8 +399,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     // addresses and the derived pass-3 twiddles out of the frame loop (they
     // would sit in registers for the whole batch).
     int s1v = s1;
-    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
-    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
+    v2f t3a = tw3_1, t3b = tw3_2;
+    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b));
     const bool has_next = f + 1 < fend;
     constexpr int kRuns = (MODE == kModeCplx) ? 2 : 1;
     float pv[4] = {0.f, 0.f, 0.f, 0.f};  // this wave's partials: up right/left, down right/left
@@ -479,32 +478,30 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             bv[t] = lds_ld(lds, ib + 256 * t);
           }
           __builtin_amdgcn_sched_barrier(0);
-          v2f w[8];
+          // Z = sum_t a_t w^t evaluated as E(w^2) + w O(w^2), E and O by Horner in w^2: seven fused
+          // multiply-adds with only w and w^2 (no per-frame derivation of w^3..w^7)
+          v2f w1, w2;
           if (r == 0) {
-            w[1] = t3a;
-            w[2] = t3b;
-            w[4] = t3c;
+            w1 = t3a;
+            w2 = t3b;
           } else {
-            // i = j + 64: W_2048^(t (j+64)) = W_2048^(t j) * W_32^t
-            w[1] = pk_cmul(t3a, mkv(kCos16, -kSin16));
-            w[2] = pk_mul_w1(t3b, K);
-            w[4] = pk_mul_w2(t3c, H);
+            // wave 1: W_2048^(j+64) = W_2048^j * W_32, squared: * W_16
+            w1 = pk_cmul(t3a, mkv(kCos16, -kSin16));
+            w2 = pk_mul_w1(t3b, K);
           }
-          w[3] = pk_cmul(w[1], w[2]);
-          w[5] = pk_cmul(w[1], w[4]);
-          w[6] = pk_cmul(w[2], w[4]);
-          w[7] = pk_cmul(w[3], w[4]);
           constexpr bool do_a = true, do_b = true;
           if (MODE == kModeRxReal) {
             // A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2j
             // Z[k] = sum a_t w_t and Z[n-k] = sum b_t conj(w_t) first (2 packed FMAs per term each),
             // then sa = Z[k] + conj Z[n-k] = 2 A[k], sb = Z[k] - conj Z[n-k] = 2j B[k]
-            v2f zl = av[0], zh = bv[0];
-#pragma unroll
-            for (int t = 1; t < 8; t++) {
-              zl = pk_cfma(av[t], w[t], zl);
-              zh = pk_cfmac(bv[t], w[t], zh);
-            }
+            v2f el = pk_cfma(av[6], w2, av[4]), ol = pk_cfma(av[7], w2, av[5]);
+            v2f eh = pk_cfmac(bv[6], w2, bv[4]), oh = pk_cfmac(bv[7], w2, bv[5]);
+            el = pk_cfma(el, w2, av[2]); ol = pk_cfma(ol, w2, av[3]);
+            eh = pk_cfmac(eh, w2, bv[2]); oh = pk_cfmac(oh, w2, bv[3]);
+            el = pk_cfma(el, w2, av[0]); ol = pk_cfma(ol, w2, av[1]);
+            eh = pk_cfmac(eh, w2, bv[0]); oh = pk_cfmac(oh, w2, bv[1]);
+            const v2f zl = pk_cfma(ol, w1, el);   // Z[k]
+            const v2f zh = pk_cfmac(oh, w1, eh);  // Z[n-k] (conjugated twiddles)
             const v2f sa = pk_add_conj(zl, zh);
             const v2f sb = pk_sub_conj(zl, zh);
             // Window search on q = 4 |X|^2 (monotonic in |X|); the finaliser takes the
@@ -529,12 +526,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             m_a[r] = ma;
             m_b[r] = mb;
           } else {
-            v2f zl = av[0], zh = bv[0];
-#pragma unroll
-            for (int t = 1; t < 8; t++) {
-              if (do_a) zl = pk_cfma(av[t], w[t], zl);
-              if (do_b) zh = pk_cfmac(bv[t], w[t], zh);
-            }
+            v2f el = pk_cfma(av[6], w2, av[4]), ol = pk_cfma(av[7], w2, av[5]);
+            v2f eh = pk_cfmac(bv[6], w2, bv[4]), oh = pk_cfmac(bv[7], w2, bv[5]);
+            el = pk_cfma(el, w2, av[2]); ol = pk_cfma(ol, w2, av[3]);
+            eh = pk_cfmac(eh, w2, bv[2]); oh = pk_cfmac(oh, w2, bv[3]);
+            el = pk_cfma(el, w2, av[0]); ol = pk_cfma(ol, w2, av[1]);
+            eh = pk_cfmac(eh, w2, bv[0]); oh = pk_cfmac(oh, w2, bv[1]);
+            const v2f zl = pk_cfma(ol, w1, el);
+            const v2f zh = pk_cfmac(oh, w1, eh);
             if (do_a) m_a[r] = zl.x * zl.x + zl.y * zl.y;  // |Z|^2: the finaliser takes sqrt
             if (do_b) m_b[r] = zh.x * zh.x + zh.y * zh.y;
           }
