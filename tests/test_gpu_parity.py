@@ -7,8 +7,12 @@ Bars (BASELINE.md section 4 / SURVEY.md section 8d):
   * window magnitudes within MAG_TOL = 2e-5 x the frame's peak magnitude of a
     float64 evaluation of the same float32 inputs.
 """
+import os
+
 import numpy as np
 import pytest
+
+ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import synth
 from oracle import uco
@@ -474,3 +478,27 @@ def test_hip_graph_capture_of_the_batch_call(uchirp):
     g.replay()
     torch.cuda.synchronize()
     assert torch.equal(out.reshape(-1), ref_rev)
+
+
+def test_cpp_host_layer_runs_the_firmware_main_loop(uchirp, tmp_path):
+    """include/uchirp_receiver.hpp: dsp / symbol_snr / resync / the ISR callback with the reference's
+    names and argument meaning; tests/cpp/rx_main.cpp is main()'s loop written against them.  Built
+    with g++ against libuchirp.so, fed DFSDM words, its stdout must be the oracle's text."""
+    import subprocess
+    from test_oracle_golden import _hello_stream
+    exe = str(tmp_path / "rx_main")
+    inc = os.path.join(ROOT_DIR, "include")
+    libdir = os.path.join(ROOT_DIR, "ultrasonic-communication_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-I" + inc, os.path.join(ROOT_DIR, "tests", "cpp", "rx_main.cpp"),
+                           "-o", exe, "-L" + libdir, "-luchirp", "-Wl,-rpath," + libdir])
+    x = _hello_stream()
+    words = (np.round(x).astype(np.int64) * 256).astype(np.int32)
+    path = str(tmp_path / "words.i32")
+    words.tofile(path)
+    for variant in (uco.SYNC_CPLX, uco.RX_REAL):
+        out = subprocess.run([exe, path, str(variant)], capture_output=True, timeout=300)
+        assert out.returncode == 0, out.stderr.decode()
+        want, _ = uco.Oracle(variant).receive(words, precision=uco.F64)
+        assert out.stdout.decode("latin-1") == want
+        if variant == uco.SYNC_CPLX:
+            assert want == "Hello World!\n"

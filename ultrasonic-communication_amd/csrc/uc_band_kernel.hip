@@ -437,6 +437,16 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       pk_dft16(v, K, H);
       UC_STAMP(0);
+      // B4, placed AFTER the register-only part of pass 1: the wave that finished the previous
+      // frame first computes ahead instead of idling (wave 1 carries the extra pruned round).
+      // It frees the tile (all pruned-pass reads done) and publishes the ring entry.
+      __syncthreads();
+      UC_STAMP(7);
+      if (run == 0 && ring_n == kRingFrames) {
+        if (wave == 0) finalise(ring_f0, ring_n);
+        ring_f0 = f;
+        ring_n = 0;
+      }
 #pragma unroll
       for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[4 * (t & 3) + (t >> 2)]);
       UC_STAMP(1);
@@ -581,16 +591,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         }
       }
       UC_STAMP(8);
-      __syncthreads();  // B4: tile free for the next pass 1; ring entry visible
-      UC_STAMP(7);
-    }
-    ring_n++;
-    if (ring_n == kRingFrames) {
-      if (wave == 0) finalise(ring_f0, ring_n);
-      ring_f0 = f + 1;
-      ring_n = 0;
+      if (run == kRuns - 1) ring_n++;
     }
   }
+  __syncthreads();
   if (ring_n > 0 && wave == 0) finalise(ring_f0, ring_n);
 #ifdef UC_STAMPS
   if (lane == 0 && p.debug) {
