@@ -502,3 +502,43 @@ def test_cpp_host_layer_runs_the_firmware_main_loop(uchirp, tmp_path):
         assert out.stdout.decode("latin-1") == want
         if variant == uco.SYNC_CPLX:
             assert want == "Hello World!\n"
+
+
+def test_iq_variant_at_1024_points_one_wave_per_frame(uchirp):
+    """BASELINE config 3 as worded: I/Q down-convert + 1024-point complex FFT (the README's intention
+    for experiments/iq_modulation, README.md:64-68).  One wave per frame, no workgroup barrier."""
+    o = uco.Oracle(uco.IQ, n=1024, mag_mean=1.0)
+    e = uchirp.Engine(uchirp.IQ, n=1024, mag_mean=1.0)
+    assert e.n == 1024 and (e.bandwidth, e.bandwidth2, e.idx_left_zero) == (o.bandwidth, o.bandwidth2, o.idx_left_zero) == (30, 60, 298)
+    for tid in (uco.TABLE_DOWN, uco.TABLE_HANN, uco.TABLE_CARRIER_C, uco.TABLE_CARRIER_S):
+        assert np.array_equal(e.table(tid).view(np.uint32), o.table(tid).view(np.uint32)), tid
+    x = _iq_stream(100)                 # 200 frames of 1024 behind 26 history samples
+    n_frames = 200
+    rs, rst = o.process(x, halo=26, n_frames=n_frames)
+    gs, gst = e.process(x, n_frames=n_frames)
+    r, g = rst[:, 0], gst[:, 0]
+    specs = [o.spectrum(x[f * 1024: f * 1024 + 1024 + 26], halo=26)[0] for f in range(n_frames)]
+    scale = np.array([sp[:512].max() for sp in specs])
+    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+        assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL, fld
+    for fld, (lo_, hi_) in (("max_freq", (298, 418)), ("max_freq_left", (298, 358)), ("max_freq_right", (358, 418))):
+        bad = np.nonzero(g[fld] != r[fld])[0]
+        assert len(bad) <= 0.1 * n_frames, fld
+        for f in bad:
+            gi = int(round(g[fld][f] * 1024 / 100000.0))
+            cand = [i for i in (gi - 1, gi, gi + 1) if lo_ <= i < hi_]
+            assert min(specs[f][lo_:hi_].max() - specs[f][i] for i in cand) <= MAG_TOL * scale[f]
+    with pytest.raises(uchirp.UchirpError):
+        uchirp.Engine(uchirp.RX_REAL, n=1024)   # only UC_IQ has a 1024-point plan
+
+
+def test_unsupported_configurations_fail_loudly(uchirp):
+    with pytest.raises(uchirp.UchirpError, match="bandwidth2"):
+        uchirp.Engine(uchirp.RX_REAL, f1=25000.0)          # 2*bandwidth = 470 bins > the 191 the kernel evaluates
+    with pytest.raises(uchirp.UchirpError, match="unsupported"):
+        uchirp.Engine(uchirp.RX_REAL, n=4096)
+    with pytest.raises(uchirp.UchirpError):
+        uchirp.Engine(uchirp.RX_REAL, device=99)
+    e = uchirp.Engine(uchirp.COMPRESS)
+    with pytest.raises(uchirp.UchirpError):
+        e.receive(np.zeros(4096, np.float32))               # no up/down state machine for this variant

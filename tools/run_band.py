@@ -18,7 +18,7 @@ nf = 1 << lg
 dev = torch.device("cuda:0")
 frames, bits = make_device_frames(nf, dev, seed=1)
 sym = torch.empty(nf, dtype=torch.uint8, device=dev)
-e = uchirp.Engine(int(os.environ.get("UC_VARIANT", "0")), mag_mean=1000.0)
+e = uchirp.Engine(int(os.environ.get("UC_VARIANT", "0")), mag_mean=1000.0, **({"n": int(os.environ["UC_N"])} if "UC_N" in os.environ else {}))
 for _ in range(iters):
     e.process(frames, want_stats=False, symbols_out=sym)
 torch.cuda.synchronize()

@@ -30,7 +30,7 @@ engines = []
 for waves, grid in configs:
     os.environ["UC_BAND_WAVES"] = str(waves)
     os.environ["UC_GRID"] = str(grid)
-    engines.append(uchirp.Engine(variant, mag_mean=1000.0))
+    engines.append(uchirp.Engine(variant, mag_mean=1000.0, **({"n": int(os.environ["UC_N"])} if "UC_N" in os.environ else {})))
 stream = torch.cuda.current_stream(dev)
 ref = None
 times = {c: [] for c in configs}
@@ -38,7 +38,7 @@ for r in range(rounds + 1):
     for c, e in zip(configs, engines):
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record(stream)
-        e.process(frames, want_stats=False, symbols_out=sym, stream=stream.cuda_stream)
+        e.process(frames, want_stats=False, symbols_out=sym if e.n == 2048 else None, want_symbols=(e.n == 2048), stream=stream.cuda_stream)
         b.record(stream)
         torch.cuda.synchronize()
         if r:

@@ -149,8 +149,9 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   }
   if (cfg->device < 0 || cfg->device >= ndev)
     return fail(-ENODEV, "uc_create: device %d out of range [0,%d)", (int)cfg->device, ndev);
-  if (cfg->n != (uint32_t)uc::kN)
-    return fail(-ENOTSUP, "uc_create: n=%u unsupported (kernels are specialised for n=%d)", cfg->n, uc::kN);
+  if (cfg->n != (uint32_t)uc::kN && !(cfg->variant == UC_IQ && cfg->n == 1024))
+    return fail(-ENOTSUP, "uc_create: n=%u unsupported (kernels are specialised for n=%d; UC_IQ also takes 1024)",
+                cfg->n, uc::kN);
 
   uc_ctx* c = new (std::nothrow) uc_ctx();
   if (!c) return fail(-ENOMEM, "uc_create: out of memory");
@@ -171,7 +172,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 191-bin window the kernel evaluates",
                 c->tab.bandwidth2);
   }
-  if (cfg->variant == UC_IQ && c->tab.bandwidth4 > 256) {
+  if (cfg->variant == UC_IQ && c->tab.bandwidth4 > (cfg->n == 1024 ? 128u : 256u)) {
     delete c;
     return fail(-ENOTSUP, "uc_create: IQ window of %u bins exceeds the 256 the kernel evaluates", c->tab.bandwidth4);
   }
@@ -383,11 +384,11 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
     ip.center = c->tab.center;
     ip.bw2 = c->tab.bandwidth2;
     ip.bw4 = c->tab.bandwidth4;
-    if (c->iq_blocks_per_cu == 0) c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype);
+    if (c->iq_blocks_per_cu == 0) c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype, (int)n);
     size_t grid = (size_t)c->num_cu * (size_t)c->iq_blocks_per_cu;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     if (grid > n_frames) grid = n_frames;
-    int lrc = uc::launch_iq(dtype, ip, (int)grid, stream);
+    int lrc = uc::launch_iq(dtype, ip, (int)grid, stream, (int)n);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "iq kernel launch");
     goto copy_back;
   }

@@ -284,10 +284,197 @@ __global__ __launch_bounds__(T, 3) void iq_kernel(const IqParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// n = 1024 (the README's intention for this experiment, README.md:64-68; BASELINE config 3):
+// ONE WAVE per frame -- 64 threads x 16 samples, 1024 = 16 x 8 x 8.  A single-wave workgroup
+// needs no s_barrier (LDS operations of one wave complete in order), so the whole pipeline
+// (mix, FIR, three FFT passes, windows) runs without a single cross-wave wait.
+// ---------------------------------------------------------------------------------------------
+constexpr int kN1 = 1024;
+constexpr int T1 = 64;
+constexpr int kMixLen1 = kN1 + kHalo;                     // 1050
+constexpr int kMixPad1 = kMixLen1 + (kMixLen1 >> 4) + 2;  // padded image, complex units
+constexpr int kLdsFloats1 = 2 * kMixPad1;
+static_assert(kMixPad1 >= kN1, "the FFT tile aliases the mixed image");
+
+template <int DTYPE>
+__global__ __launch_bounds__(T1, 3) void iq1024_kernel(const IqParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats1];
+  const int j = threadIdx.x;  // = lane
+
+  const size_t nfr = p.n_frames;
+  const size_t chunk = (nfr + gridDim.x - 1) / gridDim.x;
+  size_t f = (size_t)blockIdx.x * chunk;
+  if (f >= nfr) return;
+  const size_t fend = (f + chunk < nfr) ? f + chunk : nfr;
+
+  const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN1 * 8);
+  const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN1 * 8);
+  const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN1 * 8);  // exp(-2 pi i k / 1024)
+  const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
+
+  // pass-2 twiddles W_128^(t k) = W_1024^(8 t k), k = b & 15 = j & 15 for both butterflies b = j, j + 64
+  v2f tw2[8];
+#pragma unroll
+  for (int t = 1; t < 8; t++) tw2[t] = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN1 - 1)) * 8, 0);
+
+  const int s1 = j & 15;
+  const int wr1 = 16 * j;  // natural / exchange-1 layout: + (t ^ s1)
+  int rdn[4];              // natural-order read n = j + 64 t: base for t & 3
+#pragma unroll
+  for (int m = 0; m < 4; m++) rdn[m] = (j & ~15) + ((j & 15) ^ ((j >> 4) + 4 * m));
+  const int lo = (int)p.idx_left_zero, center = (int)p.center;
+  const int bw2 = (int)p.bw2, bw4 = (int)p.bw4;
+
+  for (; f < fend; f++) {
+    int s1v = s1;
+    asm volatile("" : "+v"(s1v));
+    // ---- stage 0: carrier mix into the padded image ------------------------------------
+    {
+      const __amdgpu_buffer_rsrc_t rx =
+          make_rsrc(reinterpret_cast<const char*>(p.frames) + (f * p.stride) * 4 - kHalo * 4, kMixLen1 * 4);
+#pragma unroll
+      for (int u = 0; u < 17; u++) {
+        const int m = j + T1 * u;
+        if (m < kMixLen1) {
+          const float x = cvt1<DTYPE>(buf_ld32(rx, j * 4, T1 * 4 * u));
+          const int i = m - kHalo;
+          const int ci = i < 0 ? kN1 + i : i;
+          const v2f cs = buf_ld64(rs_car, ci * 8, 0);
+          lds_st(lds, mix_idx(m), mkv(x * cs.x, x * cs.y));
+        }
+      }
+    }
+    __syncthreads();  // single wave: no s_barrier is emitted, only the LDS wait
+
+    // ---- stage 1: FIR, 16 consecutive outputs per thread ---------------------------------
+    v2f acc[16];
+    {
+      v2f w[42];
+#pragma unroll
+      for (int d = 0; d < 42; d++) w[d] = lds_ld(lds, 17 * j + d + (d >> 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        v2f a = mkv(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < kFirTapsDev; k++) {
+          const float b = p.fir[k];
+          a = __builtin_elementwise_fma(w[u + kHalo - k], mkv(b, b), a);
+        }
+        acc[u] = a;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), acc[u]);
+    __syncthreads();
+
+    // ---- pass 1: x chirp*hann, radix-16 (Ns = 1) -------------------------------------------
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rdn[t & 3] + 64 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], buf_ld64(rs_ch, j * 8, T1 * 8 * t));
+    pk_dft16(v, K, H);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    __syncthreads();
+
+    // ---- pass 2: radix-8 (Ns = 16), butterflies b = j and j + 64 ----------------------------
+    v2f g[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int b = j + T1 * h;
+      const int be = (b & ~15) + ((b & 15) ^ (b >> 4)), bo = (b & ~15) + ((b & 15) ^ (b >> 4) ^ 8);
+#pragma unroll
+      for (int t = 0; t < 8; t++) g[h][t] = lds_ld(lds, ((t & 1) ? bo : be) + 128 * t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+#pragma unroll
+      for (int t = 1; t < 8; t++) g[h][t] = pk_cmul(g[h][t], tw2[t]);
+      pk_dft8(g[h], H);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int b = j + T1 * h;
+#pragma unroll
+      for (int t = 0; t < 8; t++) lds_st(lds, (b >> 4) * 128 + (b & 15) + 16 * t, g[h][pk_slot8(t)]);
+    }
+    __syncthreads();
+
+    // ---- pass 3 (radix-8, Ns = 128), pruned: bins k = lo + j, lo + 64 + j ---------------------
+    float q[2] = {0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int k = lo + T1 * r + j;
+      if (k < lo + bw4) {
+        const int b = k & 127;
+        v2f a[8];
+#pragma unroll
+        for (int t = 0; t < 8; t++) a[t] = lds_ld(lds, b + 128 * t);
+        const v2f w1 = buf_ld64(rs_tw, (k & (kN1 - 1)) * 8, 0);
+        const v2f w2 = buf_ld64(rs_tw, ((2 * k) & (kN1 - 1)) * 8, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        v2f e = pk_cfma(a[6], w2, a[4]), o = pk_cfma(a[7], w2, a[5]);
+        e = pk_cfma(e, w2, a[2]); o = pk_cfma(o, w2, a[3]);
+        e = pk_cfma(e, w2, a[0]); o = pk_cfma(o, w2, a[1]);
+        const v2f z = pk_cfma(o, w1, e);
+        q[r] = z.x * z.x + z.y * z.y;
+      }
+    }
+    __syncthreads();  // tile free for the next frame
+
+    // ---- windows (one wave: no merge step) -----------------------------------------------------
+    const int k0 = lo + j, k1 = lo + T1 + j;
+    const float q1v = (k1 < lo + bw4) ? q[1] : -INFINITY;
+    float ql, qr;
+    int il, ir;
+    window_first_max(q[0], k0, q1v, k1, lo, lo + bw2, ql, il);
+    window_first_max(q[0], k0, q1v, k1, center, center + bw2, qr, ir);
+    const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
+    const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
+    if (j == 0 && p.stats) {
+      if (nl) { ql = __int_as_float(0x7fc00000); il = lo; }
+      if (nr) { qr = __int_as_float(0x7fc00000); ir = center; }
+      const float ml = sqrtf(ql), mr = sqrtf(qr);
+      float mx = ml;
+      int ix = il;
+      if (!(ml != ml) && mr > ml) { mx = mr; ix = ir; }
+      const float mm = p.mag_mean ? p.mag_mean[2 * f] : p.mag_mean_scalar;
+      const float fsn = p.fs;
+      float4 sa, sb;
+      sa.x = mx; sa.y = ml; sa.z = mr;
+      sa.w = __int_as_float((int)(unsigned)(fsn * (float)ix / (float)kN1));
+      sb.x = __int_as_float((int)(unsigned)(fsn * (float)il / (float)kN1));
+      sb.y = __int_as_float((int)(unsigned)(fsn * (float)ir / (float)kN1));
+      sb.z = mm;
+      sb.w = (mx - mm) / mm;
+      float4* d = reinterpret_cast<float4*>(p.stats + f);
+      d[0] = sa;
+      d[1] = sb;
+    }
+    if (j == 0 && p.symbols) p.symbols[f] = (uint8_t)UC_SYM_NONE;
+  }
+}
+
 }  // namespace
 
-int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream) {
+int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n) {
   if (grid <= 0) return (int)hipSuccess;
+  if (n == kN1) {
+    if (dtype == UC_DTYPE_I32)
+      hipLaunchKernelGGL((iq1024_kernel<UC_DTYPE_I32>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p);
+    else
+      hipLaunchKernelGGL((iq1024_kernel<UC_DTYPE_F32>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p);
+    return (int)hipGetLastError();
+  }
   if (dtype == UC_DTYPE_I32)
     hipLaunchKernelGGL((iq_kernel<UC_DTYPE_I32>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
   else
@@ -295,8 +482,15 @@ int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream) {
   return (int)hipGetLastError();
 }
 
-int iq_max_blocks_per_cu(int dtype) {
+int iq_max_blocks_per_cu(int dtype, int n) {
   int nb = 0;
+  if (n == kN1) {
+    hipError_t e1 = dtype == UC_DTYPE_I32
+                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq1024_kernel<UC_DTYPE_I32>, T1, 0)
+                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq1024_kernel<UC_DTYPE_F32>, T1, 0);
+    if (e1 != hipSuccess || nb <= 0) nb = 8;
+    return nb;
+  }
   hipError_t e = dtype == UC_DTYPE_I32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq_kernel<UC_DTYPE_I32>, T, 0)
                                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq_kernel<UC_DTYPE_F32>, T, 0);
   if (e != hipSuccess || nb <= 0) nb = 4;

@@ -72,7 +72,8 @@ struct IqParams {
   float fs;
   uint32_t idx_left_zero, center, bw2, bw4;
 };
-int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream);
-int iq_max_blocks_per_cu(int dtype);
+// n = 2048 (the committed firmware) or 1024 (one wave per frame)
+int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
+int iq_max_blocks_per_cu(int dtype, int n);
 
 }  // namespace uc
