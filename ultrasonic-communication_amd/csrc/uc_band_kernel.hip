@@ -70,6 +70,13 @@ __device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
 __device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
   *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
 }
+typedef float v4f __attribute__((ext_vector_type(4)));
+// two adjacent complex values with one ds_write_b128 (cidx even)
+__device__ __forceinline__ void lds_st2(float* lds, int cidx, v2f a, v2f b) {
+  v4f q;
+  q.x = a.x; q.y = a.y; q.z = b.x; q.w = b.y;
+  *reinterpret_cast<v4f*>(lds + 2 * cidx) = q;
+}
 
 // ---- wave-wide reductions without LDS ----------------------------------------
 // Six DPP steps (row_ror 1/2/4/8 make every lane of a 16-lane row hold the row
@@ -293,12 +300,16 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const int wave = j >> 6;
   const int bw2 = (int)p.bw2;
 
-  // contiguous chunk of frames per workgroup: [f, fend)
+  // Frames are dealt to workgroups in GROUPS of 64 consecutive frames (512 KiB), round robin:
+  // all resident workgroups together sweep a window of a few hundred MiB through the batch
+  // instead of each walking its own multi-MiB chunk of an 8+ GiB buffer (measured: the
+  // per-frame time grew with the batch size with contiguous chunks), while the finaliser
+  // still owns 64 consecutive frames (coalesced symbol stores).
   const size_t nfr = p.n_frames;
-  const size_t chunk = (nfr + gridDim.x - 1) / gridDim.x;
-  size_t f = (size_t)blockIdx.x * chunk;
-  if (f >= nfr) return;
-  const size_t fend = (f + chunk < nfr) ? f + chunk : nfr;
+  const size_t ngroups = (nfr + kRingFrames - 1) / kRingFrames;
+  size_t grp = blockIdx.x;
+  if (grp >= ngroups) return;
+  size_t f = grp * kRingFrames;
 
   // ---- per-thread constants, resident for the whole batch -----------------
   const __amdgpu_buffer_rsrc_t rs_tab0 = make_rsrc(p.tab0, kN * 8);
@@ -319,10 +330,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);  // SGPR pairs
 
   // LDS addresses (complex units)
-  const int s1 = j & 15;
-  const int wr1 = 16 * j;                                        // + (t ^ s1)
-  const int rd1e = (j & ~15) + ((j & 15) ^ (j >> 4));            // + 128 t, t even
-  const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);        // + 128 t, t odd
+  // exchange 1: element o = 16 j + t lives at o ^ (((o >> 4) & 7) << 1): bit 0 untouched, so the
+  // pairs (t, t+1) stay adjacent and go out as ds_write_b128 (8 instead of 16 stores per thread);
+  // conflict-free for the 8-lane b128 write groups and for the 32-lane b64 read groups
+  const int s1 = (j & 7) << 1;
+  const int wr1 = 16 * j;                                        // + (t ^ s1), t even
+  const int rd1 = j ^ (((j >> 4) & 7) << 1);                     // + 128 t
   const int wr2 = (j >> 4) * 256 + (j & 15);                     // + 16 t
 
   v2f xp[8];  // the frame's 16 samples of this thread, two per register pair (raw words)
@@ -394,14 +407,20 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   size_t ring_f0 = f;  // frame held by ring slot 0
   int ring_n = 0;      // slots filled
 
-  for (; f < fend; f++) {
+  for (;;) {
+    // successor of frame f in this workgroup's visiting order
+    size_t fnext = f + 1;
+    if ((fnext % kRingFrames) == 0 || fnext >= nfr) {
+      grp += gridDim.x;
+      fnext = grp * kRingFrames;
+    }
+    const bool has_next = grp < ngroups;
     // Opaque re-definitions: stop LICM from hoisting the 16 swizzled store
     // addresses and the derived pass-3 twiddles out of the frame loop (they
     // would sit in registers for the whole batch).
     int s1v = s1;
     v2f t3a = tw3_1, t3b = tw3_2;
     asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b));
-    const bool has_next = f + 1 < fend;
     constexpr int kRuns = (MODE == kModeCplx) ? 2 : 1;
     float pv[4] = {0.f, 0.f, 0.f, 0.f};  // this wave's partials: up right/left, down right/left
     unsigned kpack = 0, flags = 0;
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // microseconds; at 3 waves/SIMD the 16 registers are free)
       if (run == kRuns - 1 && has_next) {
         const __amdgpu_buffer_rsrc_t rx =
-            make_rsrc(reinterpret_cast<const char*>(p.frames) + (f + 1) * p.stride * 4, kN * 4);
+            make_rsrc(reinterpret_cast<const char*>(p.frames) + fnext * p.stride * 4, kN * 4);
 #pragma unroll
         for (int m = 0; m < 8; m++)
           xp[m] = mkv(buf_ld32(rx, voff4, T * 4 * (2 * m)), buf_ld32(rx, voff4, T * 4 * (2 * m + 1)));
@@ -442,13 +461,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // It frees the tile (all pruned-pass reads done) and publishes the ring entry.
       __syncthreads();
       UC_STAMP(7);
-      if (run == 0 && ring_n == kRingFrames) {
+      if (run == 0 && ring_n > 0 && (f % kRingFrames) == 0) {  // a new group starts: drain the last one
         if (wave == 0) finalise(ring_f0, ring_n);
         ring_f0 = f;
         ring_n = 0;
       }
 #pragma unroll
-      for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[4 * (t & 3) + (t >> 2)]);
+      for (int t = 0; t < 16; t += 2)
+        lds_st2(lds, wr1 + (t ^ s1v), v[4 * (t & 3) + (t >> 2)], v[4 * ((t + 1) & 3) + ((t + 1) >> 2)]);
       UC_STAMP(1);
       __syncthreads();  // B1
       UC_STAMP(2);
@@ -457,7 +477,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // all 16 reads are issued back to back (the fence keeps hipcc from sinking them
       // next to their uses, which serialises four load->wait round trips)
 #pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
+      for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rd1 + 128 * t);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], tw2[t]);
@@ -593,6 +613,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       UC_STAMP(8);
       if (run == kRuns - 1) ring_n++;
     }
+    if (!has_next) break;
+    f = fnext;
   }
   __syncthreads();
   if (ring_n > 0 && wave == 0) finalise(ring_f0, ring_n);
