@@ -70,6 +70,32 @@ def cpu_baseline(frames_host, mag_mean):
                       "(float32 butterflies), OpenMP %d threads, %.1f s" % (passes, n // passes, cores, dt)}
 
 
+def side_measurement(args, eng, frames, world, rank):
+    """Not the contract line: frames/s of one of the sibling variants on the same synthetic batch."""
+    n = eng.n
+    per_frame = {"sync_cplx": 8193, "compress": 8192 + 32, "dechirp_down": 8192 + 32, "iq": 8192 + 104 + 32,
+                 "iq1024": 4096 + 104 + 32}[args.variant]
+    nfr = (frames.numel() - eng.halo - n) // n + 1
+    want_sym = args.variant == "sync_cplx"
+    stats = None if want_sym else torch.empty((nfr, eng.spf, 8), dtype=torch.float32, device=frames.device)
+    sym = torch.empty(nfr, dtype=torch.uint8, device=frames.device) if want_sym else None
+    for _ in range(args.warmup):
+        eng.process(frames, n_frames=nfr, want_symbols=want_sym, want_stats=not want_sym, symbols_out=sym, stats_out=stats)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.process(frames, n_frames=nfr, want_symbols=want_sym, want_stats=not want_sym, symbols_out=sym, stats_out=stats)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        v = nfr * args.steps / dt
+        print(json.dumps({"metric": "chirp frames/s (%s, side measurement)" % args.variant, "value": v, "unit": "frames/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "frame_len": n, "frames": nfr,
+                          "roofline": {"bound": "hbm", "achieved": v * per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": v * per_frame / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": per_frame}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -78,6 +104,9 @@ def main():
     ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU per step")
     ap.add_argument("--snr", type=float, default=-10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", default="rx_real",
+                    choices=["rx_real", "sync_cplx", "compress", "dechirp_down", "iq", "iq1024"],
+                    help="default rx_real = BASELINE configs[1]; the others are side measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -95,9 +124,14 @@ def main():
 
     import uchirp
     mag_mean = 1000.0
-    eng = uchirp.Engine(uchirp.RX_REAL, device=local_rank, mag_mean=mag_mean)
+    vmap = {"rx_real": (uchirp.RX_REAL, {}), "sync_cplx": (uchirp.SYNC_CPLX, {}), "compress": (uchirp.COMPRESS, {}),
+            "dechirp_down": (uchirp.DECHIRP_DOWN, {}), "iq": (uchirp.IQ, {}), "iq1024": (uchirp.IQ, {"n": 1024})}
+    vid, vkw = vmap[args.variant]
+    eng = uchirp.Engine(vid, device=local_rank, mag_mean=mag_mean, **vkw)
     nf = args.frames
     frames, bits = make_device_frames(nf, device, seed=1234 + rank, snr_db=args.snr)
+    if args.variant != "rx_real":
+        return side_measurement(args, eng, frames, world, rank)
     symbols = torch.empty(nf, dtype=torch.uint8, device=device)
     gathered = torch.empty(world * nf, dtype=torch.uint8, device=device) if world > 1 else None
     stream = torch.cuda.current_stream(device)

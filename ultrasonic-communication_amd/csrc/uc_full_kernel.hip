@@ -26,6 +26,9 @@ namespace uc {
 namespace {
 
 constexpr int T = kBandThreads;  // 128
+#ifndef UC_COMPRESS_WAVES
+#define UC_COMPRESS_WAVES 2
+#endif
 constexpr int kRedOff = 2 * kN;  // floats: per-wave reduction results after the tile
 constexpr int kLdsFloats = kRedOff + 16;
 
@@ -105,7 +108,7 @@ __device__ __forceinline__ void frame_max(const v2f (&y)[16], int j, int lane, f
 }
 
 template <int DTYPE>
-__global__ __launch_bounds__(T, 3) void compress_kernel(const FullParams p) {
+__global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const FullParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   float* red = lds + kRedOff;
 
