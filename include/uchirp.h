@@ -26,6 +26,11 @@
  *   UC_COMPRESS      experiments/chirp_compression_time_domain/Src/chirp.c:78-83
  *   UC_DECHIRP_DOWN  experiments/chirp_compression_freq_domain/Src/main.c:113-160
  *   UC_IQ            experiments/iq_modulation/Src/main.c:117-134 + iq_modem.c:55-75
+ *   UC_STREAM        streaming front-end + overlap-save chirp compression (BASELINE config 4):
+ *                    carrier mix + the 27-tap FIR of iq_modem.c:18,55-75, decimation by
+ *                    cfg.decim, then FFT x H x IFFT as compress_chirp()
+ *                    (chirp_compression_time_domain/Src/chirp.c:78-83) run as overlap-save
+ *                    over a continuous stream -- uc_process_stream()
  *
  * Conventions: 0 on success, negative errno-style code on failure, never
  * aborts.  The caller owns every buffer.  `frames`, `mag_mean`, `symbols`
@@ -45,7 +50,7 @@
 extern "C" {
 #endif
 
-#define UC_ABI_VERSION 1
+#define UC_ABI_VERSION 2
 
 /* pipeline variants */
 enum {
@@ -54,7 +59,8 @@ enum {
   UC_COMPRESS     = 2,
   UC_DECHIRP_DOWN = 3,
   UC_IQ           = 4,
-  UC_NUM_VARIANTS = 5
+  UC_STREAM       = 5,
+  UC_NUM_VARIANTS = 6
 };
 
 /* `typedef enum {DOWN_CHIRP, UP_CHIRP} chirp;`  receiver/Inc/chirp.h:12-14 */
@@ -80,6 +86,9 @@ enum {
                                          ONE fp32 table ref*hann (one rounding) where the
                                          reference rounds (x*ref) then (*hann) */
 
+#define UC_FLAG_STREAM_UP   (1u << 3) /* UC_STREAM: convolve with the UP template (compresses
+                                         down chirps) instead of the default DOWN template */
+
 /* table ids for uc_get_table */
 enum {
   UC_TABLE_UP        = 0, /* n floats (RX_REAL, DECHIRP_DOWN uses DOWN only) or 2n (re,im) */
@@ -89,7 +98,8 @@ enum {
   UC_TABLE_H_DOWN    = 4, /* COMPRESS: packed RFFT of hann*down chirp, n floats */
   UC_TABLE_CARRIER_C = 5, /* IQ: n floats */
   UC_TABLE_CARRIER_S = 6, /* IQ: n floats */
-  UC_TABLE_FIR       = 7  /* IQ: 27 taps */
+  UC_TABLE_FIR       = 7, /* IQ, STREAM: 27 taps */
+  UC_TABLE_TEMPLATE  = 8  /* STREAM: base-band template g, n/decim complex (re,im) pairs */
 };
 
 /* mirrors the compile-time #defines and the derived values of the firmware */
@@ -106,6 +116,8 @@ typedef struct uc_config {
   int32_t  variant;       /* UC_RX_REAL ...                                       */
   int32_t  device;        /* HIP device ordinal, >= 0                             */
   uint32_t flags;         /* UC_FLAG_*                                            */
+  uint32_t decim;         /* UC_STREAM: decimation factor D after the FIR (4, 8 or 16);
+                             0 = default (8).  Ignored by the other variants.      */
 } uc_config;
 
 /* = struct history (receiver/Src/main.c:124-136) minus ticks and rank */
@@ -194,6 +206,45 @@ typedef struct uc_rx_event {      /* one per processed block */
 int uc_receive_stream(uc_ctx* ctx, const void* samples, int dtype, size_t n_samples,
                       char* text, size_t text_cap,
                       uc_rx_event* trace /*nullable*/, size_t trace_cap, size_t* n_trace /*nullable*/);
+
+/*
+ * UC_STREAM -- BASELINE config 4: streaming FIR-LPF decimate front-end + overlap-save
+ * frequency-domain chirp compression over ONE continuous real sample stream x[r].
+ *
+ *   z[p] = sum_k fir[k] * x[r-k] * exp(-j 2 pi carrier (r-k) / fs),  r = halo + p*D   (k < 27)
+ *          -- iq_demodulation(): mix, then the 27-tap low-pass, iq_modem.c:55-75, taps :18; kept
+ *             only at every D-th sample (the decimation is this build's: the reference has none)
+ *   y[q] = sum_{i<L} g[i] * z[q-i],   L = n/D
+ *          -- compress_chirp(): FFT, x H, IFFT (chirp_compression_time_domain/Src/chirp.c:78-83),
+ *             evaluated as overlap-save: FFT size n = 2048, hop = n - (L-1) outputs per block
+ *   g[i] = hann_sym_L[i] * exp(j (2 pi ((f1-carrier) t - k t^2/2) - pi/2)),  t = i*D/fs,
+ *          k = (f1-f0)/(n/fs): the base-band DOWN chirp of one n-sample symbol, symmetric Hann and
+ *          -pi/2 phase as init_ref_chirp() (same file :52-75), WITH the 1/2 in the sweep that
+ *          file's `freq = f + k t` lacks (it sweeps twice the band); UC_FLAG_STREAM_UP mirrors it.
+ *   compressed[q] = |y[q]|,  q = 0 .. n_out-1,   n_out = (n_samples - halo) / D
+ *
+ * The first `halo` = (L-1)*D + 26 samples of the buffer are history (zeros at the start of a
+ * stream, the tail of the previous chunk otherwise), so consecutive calls continue one another
+ * exactly: output q belongs to input sample halo + q*D.
+ * peaks (nullable): one record per overlap-save block b = q / hop: the largest compressed value
+ * of the block (first one on ties) and its offset q - b*hop.
+ * `samples` must be 16-byte aligned when it is a device pointer.  Host or device pointers;
+ * asynchronous on hip_stream with device pointers; fixed shapes, so the call can be captured
+ * into a hipGraph and replayed chunk after chunk.
+ */
+typedef struct uc_peak {
+  float    value;
+  uint32_t offset;
+} uc_peak;
+
+/* sizes for a buffer of n_samples (all nullable): history length, number of compressed outputs,
+ * number of overlap-save blocks (= peak records), outputs per block */
+int uc_stream_geometry(const uc_ctx* ctx, size_t n_samples, size_t* halo, size_t* n_out,
+                       size_t* n_blocks, size_t* hop);
+
+int uc_process_stream(uc_ctx* ctx, const void* samples, int dtype, size_t n_samples,
+                      float* compressed /*n_out, nullable*/, uc_peak* peaks /*n_blocks, nullable*/,
+                      void* hip_stream);
 
 /* human-readable text of the last error on this thread ("" if none) */
 const char* uc_last_error(void);

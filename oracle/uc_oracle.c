@@ -27,6 +27,10 @@ struct uco_ctx {
   float *h_up, *h_down; /* COMPRESS: packed RFFT of windowed reference chirps */
   float *carrier_c, *carrier_s;
   float fir[UCO_FIR_TAPS];
+  /* UC_STREAM */
+  uint32_t decim, tmpl_len; /* D, L = n/D */
+  double *tmpl64;           /* L complex: base-band template g */
+  float  *tmpl32;           /* the same rounded to float32 (uco_get_table) */
   /* twiddles */
   double *tw64;         /* n/2 complex: exp(-2 pi i k / n) */
   float  *tw32;         /* same, float32 */
@@ -367,6 +371,14 @@ int uco_default_config(int32_t variant, uc_config* cfg) {
       cfg->f0 = 16000.0f; cfg->f1 = 19000.0f; /* iq_modulation/Inc/chirp.h */
       cfg->time_frame = 0.0205f;
       return 0;
+    case UC_STREAM:
+      /* the shipping receiver's band and rate, carrier at the band centre */
+      cfg->fs = 78125.0f;
+      cfg->f0 = 16000.0f; cfg->f1 = 19000.0f;
+      cfg->time_frame = 0.0f; /* one symbol = n samples */
+      cfg->carrier = 17500.0f;
+      cfg->decim = 8;
+      return 0;
     default:
       return -EINVAL;
   }
@@ -407,6 +419,13 @@ int uco_create(const uc_config* cfg, uco_ctx** out) {
   } else if (c->bandwidth2 == 0 || c->bandwidth2 > n / 2) {
     free(c);
     return -EINVAL;
+  }
+
+  if (cfg->variant == UC_STREAM) {
+    uint32_t d = cfg->decim ? cfg->decim : 8;
+    if (d != 4 && d != 8 && d != 16) { free(c); return -EINVAL; }
+    c->decim = d;
+    c->tmpl_len = n / d;
   }
 
   c->hann = (float*)malloc(sizeof(float) * n);
@@ -471,6 +490,31 @@ int uco_create(const uc_config* cfg, uco_ctx** out) {
       gen_carrier(c->carrier_c, c->carrier_s, n, cfg->carrier, cfg->fs, tf, libm);
       memcpy(c->fir, fir_taps, sizeof(fir_taps));
       break;
+    case UC_STREAM: {
+      /* base-band template of one n-sample symbol at the decimated rate (include/uchirp.h):
+       * symmetric Hann and -pi/2 phase as chirp_compression_time_domain/Src/chirp.c:52-75,
+       * sweep f1 -> f0 (DOWN) or f0 -> f1 (UP) over T = n/fs, relative to the carrier */
+      uint32_t L = c->tmpl_len;
+      double fsd = (double)cfg->fs, T = (double)n / fsd;
+      double k = ((double)cfg->f1 - (double)cfg->f0) / T;
+      int up = (cfg->flags & UC_FLAG_STREAM_UP) != 0;
+      c->tmpl64 = (double*)malloc(sizeof(double) * 2 * L);
+      c->tmpl32 = (float*)malloc(sizeof(float) * 2 * L);
+      for (uint32_t i = 0; i < L; i++) {
+        double t = (double)i * (double)c->decim / fsd;
+        double w = 0.5 - 0.5 * cos(2.0 * M_PI * (double)i / (double)(L - 1));
+        double ph = up ? 2.0 * M_PI * (((double)cfg->f0 - (double)cfg->carrier) * t + 0.5 * k * t * t)
+                       : 2.0 * M_PI * (((double)cfg->f1 - (double)cfg->carrier) * t - 0.5 * k * t * t);
+        ph -= M_PI / 2.0;
+        c->tmpl64[2 * i] = w * cos(ph);
+        c->tmpl64[2 * i + 1] = w * sin(ph);
+        c->tmpl32[2 * i] = (float)c->tmpl64[2 * i];
+        c->tmpl32[2 * i + 1] = (float)c->tmpl64[2 * i + 1];
+      }
+      uco_hann_periodic(c->hann, n, libm);
+      memcpy(c->fir, fir_taps, sizeof(fir_taps));
+      break;
+    }
   }
   *out = c;
   return 0;
@@ -480,6 +524,7 @@ void uco_destroy(uco_ctx* c) {
   if (!c) return;
   free(c->up); free(c->down); free(c->hann); free(c->h_up); free(c->h_down);
   free(c->carrier_c); free(c->carrier_s);
+  free(c->tmpl64); free(c->tmpl32);
   free(c->tw64); free(c->tw32); free(c->tw32h); free(c->rev); free(c->revh);
   free(c);
 }
@@ -510,7 +555,10 @@ int uco_get_table(const uco_ctx* c, int id, float* out, size_t cap) {
     case UC_TABLE_H_DOWN: src = c->h_down; cnt = c->n; break;
     case UC_TABLE_CARRIER_C: src = c->carrier_c; cnt = c->n; break;
     case UC_TABLE_CARRIER_S: src = c->carrier_s; cnt = c->n; break;
-    case UC_TABLE_FIR: src = c->fir; cnt = UCO_FIR_TAPS; break;
+    case UC_TABLE_FIR:
+      if (c->cfg.variant == UC_IQ || c->cfg.variant == UC_STREAM) { src = c->fir; cnt = UCO_FIR_TAPS; }
+      break;
+    case UC_TABLE_TEMPLATE: src = c->tmpl32; cnt = 2 * (size_t)c->tmpl_len; break;
     default: return -EINVAL;
   }
   if (!src) return -ENOENT;
@@ -875,6 +923,7 @@ int uco_process_batch(uco_ctx* c, const void* frames, int dtype, size_t n_frames
                       size_t stride_elems, const float* mag_mean, uint8_t* symbols,
                       uc_stats* stats, int precision, int threads) {
   if (!c || (!frames && n_frames)) return -EINVAL;
+  if (c->cfg.variant == UC_STREAM) return -EINVAL; /* uco_process_stream */
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return -EINVAL;
   if (precision != UCO_F32 && precision != UCO_F64) return -EINVAL;
   if (stride_elems == 0) stride_elems = c->n;
@@ -910,6 +959,7 @@ int uco_process_batch(uco_ctx* c, const void* frames, int dtype, size_t n_frames
 
 int uco_spectrum(uco_ctx* c, const void* frame, int dtype, int precision, double* out) {
   if (!c || !frame || !out) return -EINVAL;
+  if (c->cfg.variant == UC_STREAM) return -EINVAL;
   scratch s;
   int rc = scratch_alloc(&s, c->n);
   if (rc) { scratch_free(&s); return rc; }
@@ -937,6 +987,96 @@ int uco_spectrum(uco_ctx* c, const void* frame, int dtype, int precision, double
       break;
   }
   scratch_free(&s);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* UC_STREAM: mix + FIR + decimate + linear convolution with the template     */
+/* ------------------------------------------------------------------------- */
+
+int uco_stream_geometry(const uco_ctx* c, size_t n_samples, size_t* halo, size_t* n_out,
+                        size_t* n_blocks, size_t* hop) {
+  if (!c || c->cfg.variant != UC_STREAM) return -EINVAL;
+  size_t L = c->tmpl_len, D = c->decim;
+  size_t h = (L - 1) * D + (UCO_FIR_TAPS - 1);
+  size_t hp = (size_t)c->n - (L - 1);
+  size_t no = n_samples > h ? (n_samples - h) / D : 0;
+  if (halo) *halo = h;
+  if (n_out) *n_out = no;
+  if (n_blocks) *n_blocks = (no + hp - 1) / hp;
+  if (hop) *hop = hp;
+  return 0;
+}
+
+/* The definition of include/uchirp.h evaluated directly, in float64 on the float32 samples:
+ *   z[p] = sum_k fir[k] x[r-k] exp(-j 2 pi fc (r-k) / fs), r = halo + p D
+ *          (mix then low-pass: iq_demodulation(), iq_modulation/Src/iq_modem.c:55-75)
+ *   y[q] = sum_i g[i] z[q-i]
+ *          (what FFT x H x IFFT of compress_chirp(), chirp_compression_time_domain/Src/chirp.c:78-83,
+ *          computes for a filter of support L -- here as a plain time-domain sum, so the
+ *          overlap-save bookkeeping of the product is checked against something that has none)
+ * The carrier phase is taken from sample 0 of the buffer; |y| does not depend on that origin. */
+int uco_process_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samples,
+                       float* compressed, uc_peak* peaks, int threads) {
+  if (!c || c->cfg.variant != UC_STREAM) return -EINVAL;
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return -EINVAL;
+  size_t halo, n_out, n_blocks, hop;
+  uco_stream_geometry(c, n_samples, &halo, &n_out, &n_blocks, &hop);
+  if (n_out == 0) return 0;
+  if (!samples) return -EINVAL;
+  const size_t L = c->tmpl_len, D = c->decim;
+  const size_t nz = n_out + (L - 1); /* z[p], p = -(L-1) .. n_out-1, stored at p + L - 1 */
+  double* z = (double*)malloc(sizeof(double) * 2 * nz);
+  float* mag = (float*)malloc(sizeof(float) * n_out);
+  if (!z || !mag) { free(z); free(mag); return -ENOMEM; }
+  const double cyc = (double)c->cfg.carrier / (double)c->cfg.fs; /* cycles per sample */
+#ifdef _OPENMP
+  if (threads <= 0) threads = omp_get_max_threads();
+#else
+  threads = 1;
+#endif
+#pragma omp parallel for schedule(static) num_threads(threads)
+  for (long long pi = 0; pi < (long long)nz; pi++) {
+    /* p = pi - (L-1); r = halo + p D = 26 + pi D */
+    size_t r = (size_t)(UCO_FIR_TAPS - 1) + (size_t)pi * D;
+    double re = 0.0, im = 0.0;
+    for (int k = 0; k < UCO_FIR_TAPS; k++) {
+      size_t idx = r - (size_t)k;
+      double x = (double)load_sample(samples, dtype, idx);
+      double ph = cyc * (double)idx;
+      ph -= floor(ph);
+      double a = -2.0 * M_PI * ph;
+      re += (double)c->fir[k] * x * cos(a);
+      im += (double)c->fir[k] * x * sin(a);
+    }
+    z[2 * pi] = re;
+    z[2 * pi + 1] = im;
+  }
+#pragma omp parallel for schedule(static) num_threads(threads)
+  for (long long q = 0; q < (long long)n_out; q++) {
+    double re = 0.0, im = 0.0;
+    const double* zq = z + 2 * ((size_t)q + (L - 1)); /* z[q] */
+    for (size_t i = 0; i < L; i++) {
+      double gr = c->tmpl64[2 * i], gi = c->tmpl64[2 * i + 1];
+      double zr = zq[-2 * (long long)i], zi = zq[-2 * (long long)i + 1];
+      re += gr * zr - gi * zi;
+      im += gr * zi + gi * zr;
+    }
+    mag[q] = (float)sqrt(re * re + im * im);
+  }
+  if (compressed) memcpy(compressed, mag, sizeof(float) * n_out);
+  if (peaks) {
+    for (size_t b = 0; b < n_blocks; b++) {
+      size_t q0 = b * hop, q1 = q0 + hop < n_out ? q0 + hop : n_out;
+      float m;
+      uint32_t idx;
+      uco_arm_max_f32(mag + q0, (uint32_t)(q1 - q0), &m, &idx); /* first maximum wins */
+      peaks[b].value = m;
+      peaks[b].offset = idx;
+    }
+  }
+  free(z);
+  free(mag);
   return 0;
 }
 

@@ -68,6 +68,14 @@ int32_t uco_idx2freq(const uco_ctx* ctx, uint32_t idx);
 int uco_receive_stream(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples, int precision,
                        char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace);
 
+/* UC_STREAM (BASELINE config 4): same outputs as uc_stream_geometry / uc_process_stream,
+ * evaluated as the direct float64 time-domain sums of the definition in include/uchirp.h
+ * (build-defined pipeline: UNPINNED by the reference, pinned against numpy in the CPU tests). */
+int uco_stream_geometry(const uco_ctx* ctx, size_t n_samples, size_t* halo, size_t* n_out,
+                        size_t* n_blocks, size_t* hop);
+int uco_process_stream(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples,
+                       float* compressed, uc_peak* peaks, int threads);
+
 /* the CMSIS-DSP primitives, restated (exposed for the golden-vector tests) */
 float uco_arm_cos_f32(float x);
 void  uco_arm_sin_cos_f32(float theta_deg, float* sin_val, float* cos_val);

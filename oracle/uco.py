@@ -12,19 +12,22 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libuc_oracle.so")
 
-RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ = range(5)
+RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ, STREAM = range(6)
 DTYPE_I32, DTYPE_F32 = 0, 1
 F32, F64 = 32, 64
-FLAG_LIBM_TRIG, FLAG_TRUE_DC = 1, 2
-TABLE_UP, TABLE_DOWN, TABLE_HANN, TABLE_H_UP, TABLE_H_DOWN, TABLE_CARRIER_C, TABLE_CARRIER_S, TABLE_FIR = range(8)
+FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP = 1, 2, 8
+TABLE_UP, TABLE_DOWN, TABLE_HANN, TABLE_H_UP, TABLE_H_DOWN, TABLE_CARRIER_C, TABLE_CARRIER_S, TABLE_FIR,\
+    TABLE_TEMPLATE = range(9)
 
 
 class Config(C.Structure):
     _fields_ = [("n", C.c_uint32), ("fs", C.c_float), ("f0", C.c_float), ("f1", C.c_float),
                 ("time_frame", C.c_float), ("phase_deg", C.c_float), ("snr_threshold", C.c_float),
                 ("mag_mean", C.c_float), ("carrier", C.c_float), ("variant", C.c_int32),
-                ("device", C.c_int32), ("flags", C.c_uint32)]
+                ("device", C.c_int32), ("flags", C.c_uint32), ("decim", C.c_uint32)]
 
+
+PEAK_DTYPE = np.dtype([("value", "<f4"), ("offset", "<u4")])
 
 RX_EVENT_DTYPE = np.dtype([("block", "<u4"), ("sync_position", "<u4"), ("state_before", "u1"), ("state_after", "u1"),
                            ("bit", "i1"), ("reserved", "u1"), ("snr_up", "<f4"), ("snr_down", "<f4")])
@@ -61,6 +64,8 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.uco_receive_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t,
                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.uco_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
+        L.uco_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.uco_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.uco_stats_per_frame.argtypes = [C.c_void_p]
         L.uco_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -175,6 +180,28 @@ class Oracle:
         if rc < 0:
             raise RuntimeError("uco_receive_stream rc=%d" % rc)
         return text.value.decode("latin-1"), trace[:nt.value]
+
+    def stream_geometry(self, n_samples):
+        """(halo, n_out, n_blocks, hop) for a buffer of n_samples (UC_STREAM)."""
+        v = [C.c_size_t() for _ in range(4)]
+        rc = lib().uco_stream_geometry(self._h, n_samples, *[C.byref(x) for x in v])
+        if rc:
+            raise ValueError("uco_stream_geometry rc=%d" % rc)
+        return tuple(x.value for x in v)
+
+    def process_stream(self, samples, threads=0):
+        """UC_STREAM over one buffer (first `halo` samples = history) -> (compressed, peaks)."""
+        a = np.ascontiguousarray(samples).reshape(-1)
+        if a.dtype not in (np.int32, np.float32):
+            raise TypeError("samples must be int32 or float32")
+        dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
+        _, n_out, n_blocks, _ = self.stream_geometry(a.size)
+        comp = np.zeros(n_out, np.float32)
+        peaks = np.zeros(n_blocks, PEAK_DTYPE)
+        rc = lib().uco_process_stream(self._h, _ptr(a), dt, a.size, _ptr(comp), _ptr(peaks), threads)
+        if rc:
+            raise RuntimeError("uco_process_stream rc=%d" % rc)
+        return comp, peaks
 
     def spectrum(self, frame, precision=F64, halo=0):
         a = np.ascontiguousarray(frame).reshape(-1)

@@ -32,11 +32,11 @@ def test_every_declared_symbol_is_exported(uchirp):
     missing = [s for s in decl if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(uchirp.EXPORTS) == decl
-    assert L.uc_abi_version() == 1
+    assert L.uc_abi_version() == 2
 
 
 def test_struct_layouts(uchirp):
-    assert C.sizeof(uchirp.Config) == 48
+    assert C.sizeof(uchirp.Config) == 52
     assert uchirp.STATS_DTYPE.itemsize == 32
 
 

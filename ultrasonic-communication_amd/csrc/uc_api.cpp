@@ -72,6 +72,7 @@ bool is_device_ptr(const void* p) {
 struct uc_ctx {
   uc_config cfg;
   uc::Tables tab;
+  uc::StreamTables stab;  // UC_STREAM only
   int device = 0;
   int num_cu = 256;
   // device-resident tables
@@ -84,6 +85,8 @@ struct uc_ctx {
   int band_blocks_per_cu[2] = {0, 0};
   int full_blocks_per_cu = 0;
   int iq_blocks_per_cu = 0;
+  int stream_blocks_per_cu = 0;
+  DevBuf s_comp, s_peaks;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID): not part of the ABI
   int grid_override = 0;
 };
@@ -123,6 +126,14 @@ int uc_default_config(int32_t variant, uc_config* cfg) {
       cfg->f0 = 16000.0f;
       cfg->f1 = 19000.0f;
       cfg->time_frame = 0.0205f;
+      return 0;
+    case UC_STREAM:  // the shipping receiver's band and rate, carrier at the band centre
+      cfg->fs = 78125.0f;
+      cfg->f0 = 16000.0f;
+      cfg->f1 = 19000.0f;
+      cfg->time_frame = 0.0f;  // one symbol = n samples
+      cfg->carrier = 17500.0f;
+      cfg->decim = 8;
       return 0;
     default:
       return fail(-EINVAL, "uc_default_config: unknown variant %d", (int)variant);
@@ -167,7 +178,15 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     delete c;
     return fail(rc, "uc_create: invalid configuration (rc=%d)", rc);
   }
-  if (cfg->variant != UC_IQ && cfg->variant != UC_COMPRESS && c->tab.bandwidth2 > 191) {
+  if (cfg->variant == UC_STREAM) {
+    rc = uc::build_stream_tables(*cfg, c->stab);
+    if (rc) {
+      delete c;
+      return fail(rc, "uc_create: UC_STREAM takes decim 4, 8 or 16 (got %u)", cfg->decim);
+    }
+    c->cfg.decim = c->stab.decim;
+  }
+  if (cfg->variant != UC_IQ && cfg->variant != UC_COMPRESS && cfg->variant != UC_STREAM && c->tab.bandwidth2 > 191) {
     delete c;
     return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 191-bin window the kernel evaluates",
                 c->tab.bandwidth2);
@@ -238,6 +257,11 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
         t1[2 * i + 1] = T.down[2 * i + 1] * T.hann[i];
       }
       break;
+    case UC_STREAM:
+      // t0 <- H/n (spectrum of the zero-padded template), t1 <- per-sample carrier rotation
+      t0 = c->stab.hn;
+      t1 = c->stab.rot;
+      break;
     default:
       break;
   }
@@ -262,6 +286,8 @@ void uc_destroy(uc_ctx* c) {
   c->s_mm.release();
   c->s_sym.release();
   c->s_stats.release();
+  c->s_comp.release();
+  c->s_peaks.release();
   delete c;
 }
 
@@ -295,6 +321,7 @@ int uc_get_table(const uc_ctx* c, int id, float* out, size_t cap) {
     case UC_TABLE_CARRIER_C: v = &c->tab.carrier_c; break;
     case UC_TABLE_CARRIER_S: v = &c->tab.carrier_s; break;
     case UC_TABLE_FIR: v = &c->tab.fir; break;
+    case UC_TABLE_TEMPLATE: v = &c->stab.tmpl; break;
     default: return fail(-EINVAL, "uc_get_table: unknown table %d", id);
   }
   if (v->empty()) return fail(-ENOENT, "uc_get_table: table %d does not exist for this variant", id);
@@ -318,6 +345,8 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   if (!c) return fail(-EINVAL, "uc_process_batch: NULL ctx");
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32)
     return fail(-EINVAL, "uc_process_batch: dtype %d is neither UC_DTYPE_I32 nor UC_DTYPE_F32", dtype);
+  if (c->cfg.variant == UC_STREAM)
+    return fail(-EINVAL, "uc_process_batch: UC_STREAM has no frames, use uc_process_stream");
   if (n_frames == 0) return 0;
   if (!frames) return fail(-EINVAL, "uc_process_batch: frames is NULL");
   const uint32_t n = c->cfg.n;
@@ -453,6 +482,96 @@ copy_back:
     if (stats && d_stats != stats) {
       e = hipMemcpyAsync(stats, d_stats, n_frames * (size_t)spf * sizeof(uc_stats), hipMemcpyDeviceToHost, stream);
       if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(stats)");
+    }
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  }
+  return 0;
+}
+
+int uc_stream_geometry(const uc_ctx* c, size_t n_samples, size_t* halo, size_t* n_out, size_t* n_blocks,
+                       size_t* hop) {
+  if (!c) return fail(-EINVAL, "uc_stream_geometry: NULL ctx");
+  if (c->cfg.variant != UC_STREAM) return fail(-EINVAL, "uc_stream_geometry: the context is not UC_STREAM");
+  const size_t h = c->stab.halo, hp = c->stab.hop, D = c->stab.decim;
+  const size_t no = n_samples > h ? (n_samples - h) / D : 0;
+  if (halo) *halo = h;
+  if (n_out) *n_out = no;
+  if (n_blocks) *n_blocks = (no + hp - 1) / hp;
+  if (hop) *hop = hp;
+  return 0;
+}
+
+int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_samples, float* compressed,
+                      uc_peak* peaks, void* hip_stream) {
+  if (!c) return fail(-EINVAL, "uc_process_stream: NULL ctx");
+  if (c->cfg.variant != UC_STREAM) return fail(-EINVAL, "uc_process_stream: the context is not UC_STREAM");
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32)
+    return fail(-EINVAL, "uc_process_stream: dtype %d is neither UC_DTYPE_I32 nor UC_DTYPE_F32", dtype);
+  size_t n_out = 0, n_blocks = 0;
+  uc_stream_geometry(c, n_samples, nullptr, &n_out, &n_blocks, nullptr);
+  if (n_out == 0) return 0;
+  if (!samples) return fail(-EINVAL, "uc_process_stream: samples is NULL");
+
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+
+  const void* d_samples = samples;
+  if (!is_device_ptr(samples)) {
+    int rc = c->s_frames.ensure(n_samples * 4);
+    if (rc) return rc;
+    e = hipMemcpyAsync(c->s_frames.p, samples, n_samples * 4, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(samples)");
+    d_samples = c->s_frames.p;
+  } else if (((uintptr_t)samples & 15u) != 0) {
+    return fail(-EINVAL, "uc_process_stream: a device `samples` pointer must be 16-byte aligned");
+  }
+  bool any_host_out = false;
+  float* d_comp = compressed;
+  if (compressed && !is_device_ptr(compressed)) {
+    int rc = c->s_comp.ensure(n_out * sizeof(float));
+    if (rc) return rc;
+    d_comp = (float*)c->s_comp.p;
+    any_host_out = true;
+  }
+  uc_peak* d_peaks = peaks;
+  if (peaks && !is_device_ptr(peaks)) {
+    int rc = c->s_peaks.ensure(n_blocks * sizeof(uc_peak));
+    if (rc) return rc;
+    d_peaks = (uc_peak*)c->s_peaks.p;
+    any_host_out = true;
+  }
+
+  uc::StreamParams sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.samples = d_samples;
+  sp.n_samples = n_samples;
+  sp.n_out = n_out;
+  sp.n_blocks = n_blocks;
+  sp.hn = c->d_tab0;
+  sp.rot = c->d_tab1;
+  sp.tw = c->d_tw;
+  sp.compressed = d_comp;
+  sp.peaks = d_peaks;
+  for (int k = 0; k < 2 * uc::kFirTapsDev; k++) sp.ctap[k] = c->stab.ctap[k];
+  const int D = (int)c->stab.decim;
+  if (c->stream_blocks_per_cu == 0) c->stream_blocks_per_cu = uc::stream_max_blocks_per_cu(dtype, D);
+  size_t grid = (size_t)c->num_cu * (size_t)c->stream_blocks_per_cu;
+  if (c->grid_override > 0) grid = (size_t)c->grid_override;
+  const size_t groups = (n_blocks + uc::stream_group_blocks() - 1) / uc::stream_group_blocks();
+  if (grid > groups) grid = groups;
+  int lrc = uc::launch_stream(dtype, D, sp, (int)grid, stream);
+  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "stream kernel launch");
+
+  if (any_host_out) {
+    if (compressed && d_comp != compressed) {
+      e = hipMemcpyAsync(compressed, d_comp, n_out * sizeof(float), hipMemcpyDeviceToHost, stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(compressed)");
+    }
+    if (peaks && d_peaks != peaks) {
+      e = hipMemcpyAsync(peaks, d_peaks, n_blocks * sizeof(uc_peak), hipMemcpyDeviceToHost, stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(peaks)");
     }
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");

@@ -76,4 +76,21 @@ struct IqParams {
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
 int iq_max_blocks_per_cu(int dtype, int n);
 
+// UC_STREAM: FIR-LPF decimating front-end + overlap-save chirp compression (include/uchirp.h).
+struct StreamParams {
+  const void* samples;   // device, 16-byte aligned; the first `halo` samples are history
+  size_t n_samples;
+  size_t n_out;          // compressed outputs = (n_samples - halo) / D
+  size_t n_blocks;       // ceil(n_out / hop)
+  const float2* hn;      // FFT_n(template zero-padded) / n
+  const float2* rot;     // e^{-j 2 pi carrier D i / fs}, i < n
+  const float2* tw;
+  float* compressed;     // device or nullptr
+  uc_peak* peaks;        // device or nullptr
+  float ctap[2 * kFirTapsDev];  // fir[k] e^{+j 2 pi carrier k / fs}, (re, im)
+};
+int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream);
+int stream_max_blocks_per_cu(int dtype, int decim);
+int stream_group_blocks();  // consecutive blocks a workgroup takes at a time
+
 }  // namespace uc

@@ -1,0 +1,405 @@
+// uc_stream_kernel.hip -- UC_STREAM: FIR-LPF decimating front-end + overlap-save chirp compression
+// over one continuous sample stream (BASELINE config 4; definition in include/uchirp.h).
+//
+// Reference lines the stages restate:
+//   carrier mix + 27-tap low-pass      experiments/iq_modulation/Src/iq_modem.c:55-75, taps :18
+//   FFT, x H, inverse FFT (1/N)        experiments/chirp_compression_time_domain/Src/chirp.c:78-83
+//   maximum + index of the result      experiments/chirp_compression_time_domain/Src/main.c:186-189
+// The decimation and the overlap-save blocking are this build's (the firmware works frame by frame).
+//
+// Design (MI355X): one 2-wave workgroup per overlap-save block of 2048 decimated samples,
+// persistent over groups of consecutive blocks (a block re-reads the (L-1) D + 26 input samples it
+// shares with its predecessor: consecutive blocks on one CU find them in L2).
+//   * The carrier is folded into the taps: sum_k fir[k] x[r-k] e^{-jw(r-k)} = e^{-jwr} sum_k c[k] x[r-k]
+//     with 27 complex constants c[k] = fir[k] e^{jwk} held in SGPR pairs -- the FIR runs on the REAL
+//     samples (one packed FMA per tap for I and Q together) and only the D-th outputs are computed;
+//     e^{-jwr} is one table multiply per decimated sample (the block-constant part of that phase
+//     drops out of |y|).
+//   * Input is streamed in sub-tiles of 4096 samples: coalesced 16-byte loads into registers one
+//     sub-tile ahead (the next block's first sub-tile is in flight during the FFTs), written to a
+//     padded LDS image (36-float rows per 32 samples: the per-thread sliding windows, 128 B apart,
+//     are read with conflict-free ds_read_b128), 32/D consecutive outputs per thread.
+//   * The decimated samples land in the FFT tile in natural order (linear writes, linear reads);
+//     forward 16 x 16 x 8, x H/N in registers, inverse 8 x 16 x 16 exactly as uc_full_kernel.hip.
+//   * |y| for the hop = 2049 - L valid outputs leaves as coalesced dword stores; the block maximum
+//     is a DPP wave reduction on squared magnitudes.
+// HBM traffic per input sample: 4 B in + 4/D B out (+ 8 B of peak record per block).
+#include "uc_kernels.hpp"
+#include "uc_pk.hpp"
+
+namespace uc {
+
+namespace {
+
+constexpr int T = kBandThreads;  // 128
+constexpr int kSubIn = 4096;     // input samples per sub-tile (32 per thread)
+constexpr int kImgF4 = (kSubIn + 28) / 4 + ((kSubIn + 28) / 4 >> 3) + 1;  // padded image, float4 units
+constexpr int kTileOff = kImgF4 * 4;                                        // floats
+constexpr int kRedOff = kTileOff + 2 * kN;
+constexpr int kLdsFloats = kRedOff + 16;
+
+constexpr float kSqrtHalfF = 0.70710678118654752440f;
+constexpr float kCos8 = 0.92387953251128675613f;
+constexpr float kSin8 = 0.38268343236508977173f;
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+constexpr int kRsrcFlags = 0x00020000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+}
+__device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return mkv(__uint_as_float(w.x), __uint_as_float(w.y));
+}
+__device__ __forceinline__ v4u buf_ld128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
+  return *reinterpret_cast<const v2f*>(lds + 2 * cidx);
+}
+__device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
+  *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
+}
+
+#define UC_DPP_REDUCE(OP, v)                                                                       \
+  do {                                                                                             \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));         \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));         \
+  } while (0)
+__device__ __forceinline__ float wave_max_f32(float v) {
+  UC_DPP_REDUCE("v_max_f32_dpp", v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_u32(int v) {
+  UC_DPP_REDUCE("v_min_u32_dpp", v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+
+// acc += c * x.lo / c * x.hi: complex constant (SGPR pair) times a real sample broadcast from one
+// half of a register pair -- one packed FMA for the I and the Q branch of the FIR
+__device__ __forceinline__ void pk_fma_c_xlo(v2f& acc, v2f c, v2f x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "s"(c), "v"(x));
+}
+__device__ __forceinline__ void pk_fma_c_xhi(v2f& acc, v2f c, v2f x) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "s"(c), "v"(x));
+}
+
+template <int DTYPE>
+__device__ __forceinline__ v4f cvt4(v4u raw) {
+  v4f r;
+  if (DTYPE == UC_DTYPE_I32) {
+    r.x = (float)(int)raw.x; r.y = (float)(int)raw.y; r.z = (float)(int)raw.z; r.w = (float)(int)raw.w;
+  } else {
+    r.x = __uint_as_float(raw.x); r.y = __uint_as_float(raw.y);
+    r.z = __uint_as_float(raw.z); r.w = __uint_as_float(raw.w);
+  }
+  return r;
+}
+
+constexpr int kGroup = 16;  // consecutive blocks one workgroup takes before it jumps
+
+template <int DTYPE, int D>
+__global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
+  constexpr int L = kN / D;            // template length (decimated samples)
+  constexpr int HOP = kN - (L - 1);    // valid outputs per block
+  constexpr int OPT = 32 / D;          // FIR outputs per thread per sub-tile
+  constexpr int NSUB = D / 2;          // sub-tiles per block: 2048 D / 4096
+  constexpr int SUBOUT = kSubIn / D;   // decimated samples per sub-tile
+  constexpr int WIN = 32 - D + kFirTapsDev;  // samples one thread's OPT outputs look at
+  constexpr int WIN4 = (WIN + 3) / 4;
+  static_assert(D == 4 || D == 8 || D == 16, "decimation");
+
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  v4f* img = reinterpret_cast<v4f*>(lds);
+  float* tile = lds + kTileOff;
+  float* red = lds + kRedOff;
+
+  const int j = threadIdx.x;
+  const int wave = j >> 6;
+
+  const size_t nb = p.n_blocks;
+  size_t b = (size_t)blockIdx.x * kGroup;
+  if (b >= nb) return;
+
+  const __amdgpu_buffer_rsrc_t rs_hn = make_rsrc(p.hn, kN * 8);
+  const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
+  const __amdgpu_buffer_rsrc_t rs_rot = make_rsrc(p.rot, kN * 8);
+  const int voff8 = j * 8, voff16 = j * 16;
+  const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
+
+  const v2f tw3_1 = buf_ld64(rs_tw, (j & (kN - 1)) * 8, 0);        // W_2048^j
+  const v2f tw3_2 = buf_ld64(rs_tw, ((2 * j) & (kN - 1)) * 8, 0);  // W_2048^2j
+  const v2f tw3_4 = buf_ld64(rs_tw, ((4 * j) & (kN - 1)) * 8, 0);  // W_2048^4j
+
+  // LDS addresses of the transform (complex units), as uc_full_kernel.hip
+  const int s1 = j & 15;
+  const int wr1 = 16 * j;
+  const int rd1e = (j & ~15) + ((j & 15) ^ (j >> 4));
+  const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);
+  const int wr2 = (j >> 4) * 256 + (j & 15);
+  const int rdA = j ^ ((j >> 4) & 7);
+  const int wrBe = (j >> 3) * 128 + (j & 7) + 8 * ((j >> 3) & 1);
+  const int wrBo = (j >> 3) * 128 + (j & 7) - 8 * ((j >> 3) & 1);
+  const int rdBe = j, rdBo = j ^ 8;
+
+  // one sub-tile of input: 4096 + 28 samples starting at sample (blk HOP D + sub 4096) of the buffer
+  // (that sample is 26 taps behind the first output of the sub-tile); loads past the end of the
+  // buffer, and the tail load of threads >= 7, fall outside the resource and return 0
+  v4u stg[9];
+  auto issue_loads = [&](size_t blk, int sub) {
+    const size_t first = blk * (size_t)(HOP * D) + (size_t)sub * kSubIn;
+    const size_t left = p.n_samples > first ? p.n_samples - first : 0;
+    const int recs = left < (size_t)(kSubIn + 28) ? (int)left : kSubIn + 28;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.samples) + first * 4, recs * 4);
+#pragma unroll
+    for (int r = 0; r < 8; r++) stg[r] = buf_ld128(rx, voff16, T * 16 * r);
+    stg[8] = buf_ld128(rx, voff16, kSubIn * 4);
+  };
+
+  issue_loads(b, 0);
+
+  while (true) {
+    int s1v = s1;
+    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
+    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
+    // next block of this workgroup: kGroup consecutive ones, then the next group of the grid
+    size_t bn = b + 1;
+    if ((bn % kGroup) == 0) bn += (size_t)(gridDim.x - 1) * kGroup;
+    const bool more = bn < nb;
+
+    // ---- front end: FIR + decimation, sub-tile by sub-tile, into the FFT tile ----------------
+#pragma unroll
+    for (int s = 0; s < NSUB; s++) {
+      __syncthreads();  // the windows of the previous sub-tile (and the previous block's last pass) are read
+#pragma unroll
+      for (int r = 0; r < 8; r++) {
+        const int q = j + T * r;  // float4 index inside the sub-tile
+        img[q + (q >> 3)] = cvt4<DTYPE>(stg[r]);
+      }
+      if (j < 7) {
+        const int q = kSubIn / 4 + j;
+        img[q + (q >> 3)] = cvt4<DTYPE>(stg[8]);
+      }
+      if (s + 1 < NSUB) issue_loads(b, s + 1);
+      else if (more) issue_loads(bn, 0);
+      __syncthreads();
+
+      // window: samples 32 j .. 32 j + WIN of the sub-tile image; output u sits on sample 26 + D u
+      v2f xs[2 * WIN4];
+#pragma unroll
+      for (int d = 0; d < WIN4; d++) {
+        const v4f w4 = img[9 * j + d + (d >> 3)];
+        xs[2 * d] = mkv(w4.x, w4.y);
+        xs[2 * d + 1] = mkv(w4.z, w4.w);
+      }
+      v4u rr[OPT / 2];  // e^{-jw D m} of this thread's outputs, m = s SUBOUT + OPT j + u
+#pragma unroll
+      for (int h = 0; h < OPT / 2; h++) rr[h] = buf_ld128(rs_rot, j * (OPT * 8) + 16 * h, s * SUBOUT * 8);
+      __builtin_amdgcn_sched_barrier(0);
+      v2f acc[OPT];
+#pragma unroll
+      for (int u = 0; u < OPT; u++) acc[u] = mkv(0.f, 0.f);
+#pragma unroll
+      for (int w = 0; w < WIN; w++) {
+#pragma unroll
+        for (int u = 0; u < OPT; u++) {
+          const int k = (kFirTapsDev - 1) + D * u - w;  // tap that multiplies sample w for output u
+          if (k >= 0 && k < kFirTapsDev) {
+            const v2f c = mkv(p.ctap[2 * k], p.ctap[2 * k + 1]);
+            if (w & 1) pk_fma_c_xhi(acc[u], c, xs[w >> 1]);
+            else pk_fma_c_xlo(acc[u], c, xs[w >> 1]);
+          }
+        }
+      }
+      // rotate and store 2 complex samples per ds_write_b128, natural order
+#pragma unroll
+      for (int h = 0; h < OPT / 2; h++) {
+        const v2f z0 = pk_cmul(acc[2 * h], mkv(__uint_as_float(rr[h].x), __uint_as_float(rr[h].y)));
+        const v2f z1 = pk_cmul(acc[2 * h + 1], mkv(__uint_as_float(rr[h].z), __uint_as_float(rr[h].w)));
+        v4f o;
+        o.x = z0.x; o.y = z0.y; o.z = z1.x; o.w = z1.y;
+        *reinterpret_cast<v4f*>(tile + 2 * (s * SUBOUT + OPT * j + 2 * h)) = o;
+      }
+    }
+    __syncthreads();
+
+    // ---- forward pass 1 -------------------------------------------------------------------------
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, j + T * t);
+    __builtin_amdgcn_sched_barrier(0);
+    pk_dft16(v, K, H);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(tile, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    __syncthreads();
+
+    // ---- forward pass 2: twiddles W_256^(t k), k = j & 15 ------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) {
+      const v2f w = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN - 1)) * 8, 0);
+      v[t] = pk_cmul(v[t], w);
+    }
+    pk_dft16(v, K, H);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(tile, wr2 + 16 * t, v[pk_slot16(t)]);
+    __syncthreads();
+
+    // ---- forward pass 3 (radix-8), x H/N, inverse pass A (radix-8) ----------------------------------
+    v2f y8[2][8];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int bf = j + T * h;
+      v2f u[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) u[t] = lds_ld(tile, bf + 256 * t);
+      __builtin_amdgcn_sched_barrier(0);
+      v2f w[8];
+      if (h == 0) {
+        w[1] = t3a; w[2] = t3b; w[4] = t3c;
+      } else {  // W_2048^(t (j+128)) = W_2048^(t j) W_16^t
+        w[1] = pk_mul_w1(t3a, K); w[2] = pk_mul_w2(t3b, H); w[4] = pk_mul_mj(t3c);
+      }
+      w[3] = pk_cmul(w[1], w[2]);
+      w[5] = pk_cmul(w[1], w[4]);
+      w[6] = pk_cmul(w[2], w[4]);
+      w[7] = pk_cmul(w[3], w[4]);
+#pragma unroll
+      for (int t = 1; t < 8; t++) u[t] = pk_cmul(u[t], w[t]);
+      pk_dft8(u, H);
+#pragma unroll
+      for (int t = 0; t < 8; t++) {
+        const v2f hk = buf_ld64(rs_hn, voff8 + T * 8 * h, 256 * 8 * t);
+        u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hk);
+      }
+      v2f g[8];
+#pragma unroll
+      for (int t = 0; t < 8; t++) g[t] = u[pk_slot8(t)];
+      pk_dft8(g, H);
+#pragma unroll
+      for (int t = 0; t < 8; t++) y8[h][t] = g[pk_slot8((8 - t) & 7)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int bf = j + T * h;
+#pragma unroll
+      for (int t = 0; t < 8; t++) lds_st(tile, 8 * bf + (t ^ ((bf >> 1) & 7)), y8[h][t]);
+    }
+    __syncthreads();
+
+    // ---- inverse pass B: radix-16, conj twiddles W_128^(t k), k = j & 7 -------------------------------
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, rdA + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) {
+      const v2f w = buf_ld64(rs_tw, ((16 * t * (j & 7)) & (kN - 1)) * 8, 0);
+      v[t] = pk_cmulc(v[t], w);
+    }
+    pk_dft16(v, K, H);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(tile, ((t & 1) ? wrBo : wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
+    __syncthreads();
+
+    // ---- inverse pass C: radix-16, conj twiddles W_2048^(t j) ------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rdBo : rdBe) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) {
+      const v2f w = buf_ld64(rs_tw, ((t * j) & (kN - 1)) * 8, 0);
+      v[t] = pk_cmulc(v[t], w);
+    }
+    pk_dft16(v, K, H);
+
+    // ---- |y[i]|, i = j + 128 t; outputs i >= L-1 are free of circular wrap-around ---------------------
+    const size_t q0 = b * (size_t)HOP;                       // first output of this block
+    const size_t room = p.n_out - q0;                        // > 0
+    const int valid = room < (size_t)HOP ? (int)room : HOP;  // outputs of this block that exist
+    float best = -1.0f;
+    int best_i = 0x7fffffff;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const v2f y = v[pk_slot16((16 - t) & 15)];
+      const float m2 = y.x * y.x + y.y * y.y;
+      const int o = j + T * t - (L - 1);  // offset inside the block's hop
+      if (o >= 0 && o < valid) {
+        if (p.compressed) p.compressed[q0 + (size_t)o] = __builtin_sqrtf(m2);
+        if (m2 > best) { best = m2; best_i = o; }  // ascending t = ascending offset: first maximum
+      }
+    }
+    if (p.peaks) {
+      const float wm = wave_max_f32(best);
+      const int cand = (best == wm) ? best_i : 0x7fffffff;
+      const int wi = wave_min_u32(cand);
+      if ((j & 63) == 0) {
+        red[2 * wave] = wm;
+        red[2 * wave + 1] = __int_as_float(wi);
+      }
+      __syncthreads();
+      if (j == 0) {
+        const float v0 = red[0], v1 = red[2];
+        const int i0 = __float_as_int(red[1]), i1 = __float_as_int(red[3]);
+        const bool second = v1 > v0 || (v1 == v0 && i1 < i0);
+        uc_peak pk;
+        pk.value = __builtin_sqrtf(second ? v1 : v0);
+        pk.offset = (uint32_t)(second ? i1 : i0);
+        p.peaks[b] = pk;
+      }
+    }
+    if (!more) break;
+    b = bn;
+  }
+}
+
+template <int DTYPE, int D>
+int launch_one(const StreamParams& p, int grid, hipStream_t stream) {
+  hipLaunchKernelGGL((stream_kernel<DTYPE, D>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+template <int DTYPE, int D>
+int occupancy_one() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, stream_kernel<DTYPE, D>, T, 0) != hipSuccess || nb <= 0) nb = 4;
+  return nb;
+}
+
+}  // namespace
+
+int stream_group_blocks() { return kGroup; }
+
+int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream) {
+  if (grid <= 0) return (int)hipSuccess;
+  const bool i32 = dtype == UC_DTYPE_I32;
+  switch (decim) {
+    case 4: return i32 ? launch_one<UC_DTYPE_I32, 4>(p, grid, stream) : launch_one<UC_DTYPE_F32, 4>(p, grid, stream);
+    case 8: return i32 ? launch_one<UC_DTYPE_I32, 8>(p, grid, stream) : launch_one<UC_DTYPE_F32, 8>(p, grid, stream);
+    case 16: return i32 ? launch_one<UC_DTYPE_I32, 16>(p, grid, stream) : launch_one<UC_DTYPE_F32, 16>(p, grid, stream);
+    default: return (int)hipErrorInvalidValue;
+  }
+}
+
+int stream_max_blocks_per_cu(int dtype, int decim) {
+  const bool i32 = dtype == UC_DTYPE_I32;
+  switch (decim) {
+    case 4: return i32 ? occupancy_one<UC_DTYPE_I32, 4>() : occupancy_one<UC_DTYPE_F32, 4>();
+    case 8: return i32 ? occupancy_one<UC_DTYPE_I32, 8>() : occupancy_one<UC_DTYPE_F32, 8>();
+    case 16: return i32 ? occupancy_one<UC_DTYPE_I32, 16>() : occupancy_one<UC_DTYPE_F32, 16>();
+    default: return 4;
+  }
+}
+
+}  // namespace uc

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <complex>
+#include <utility>
 
 namespace uc {
 
@@ -143,17 +144,16 @@ void build_twiddles(uint32_t n, std::vector<float>& out) {
   }
 }
 
-void packed_rfft_double(const std::vector<float>& in, std::vector<float>& packed) {
-  const size_t n = in.size();
-  std::vector<std::complex<double>> a(n);
-  // bit-reversal copy + iterative radix-2 (init-time only, double precision)
+// in-place forward DFT, iterative radix-2, double precision (init time only)
+static void fft_double(std::vector<std::complex<double>>& a) {
+  const size_t n = a.size();
   size_t bits = 0;
   while (((size_t)1 << bits) < n) bits++;
   for (size_t i = 0; i < n; i++) {
     size_t r = 0;
     for (size_t b = 0; b < bits; b++)
       if (i & ((size_t)1 << b)) r |= (size_t)1 << (bits - 1 - b);
-    a[r] = std::complex<double>((double)in[i], 0.0);
+    if (r > i) std::swap(a[i], a[r]);
   }
   for (size_t len = 2; len <= n; len <<= 1) {
     const double ang = -2.0 * kPi / (double)len;
@@ -166,6 +166,13 @@ void packed_rfft_double(const std::vector<float>& in, std::vector<float>& packed
       }
     }
   }
+}
+
+void packed_rfft_double(const std::vector<float>& in, std::vector<float>& packed) {
+  const size_t n = in.size();
+  std::vector<std::complex<double>> a(n);
+  for (size_t i = 0; i < n; i++) a[i] = std::complex<double>((double)in[i], 0.0);
+  fft_double(a);
   packed.resize(n);
   packed[0] = (float)a[0].real();
   packed[1] = (float)a[n / 2].real();
@@ -175,11 +182,75 @@ void packed_rfft_double(const std::vector<float>& in, std::vector<float>& packed
   }
 }
 
+int build_stream_tables(const uc_config& cfg, StreamTables& out) {
+  const uint32_t n = cfg.n;
+  const uint32_t D = cfg.decim ? cfg.decim : 8;
+  if (D != 4 && D != 8 && D != 16) return -EINVAL;
+  if (!(cfg.fs > 0.0f) || !pow2(n)) return -EINVAL;
+  const uint32_t L = n / D;
+  out = StreamTables();
+  out.decim = D;
+  out.tmpl_len = L;
+  out.hop = n - (L - 1);
+  out.halo = (L - 1) * D + (kFirTaps - 1);
+  const double fs = (double)cfg.fs, T = (double)n / fs;
+  const double k = ((double)cfg.f1 - (double)cfg.f0) / T;
+  const bool up = (cfg.flags & UC_FLAG_STREAM_UP) != 0;
+  // template g: one symbol at base band, decimated rate (include/uchirp.h, UC_STREAM)
+  std::vector<std::complex<double>> g(n, std::complex<double>(0.0, 0.0));
+  out.tmpl.resize(2 * (size_t)L);
+  for (uint32_t i = 0; i < L; i++) {
+    const double t = (double)i * (double)D / fs;
+    const double w = 0.5 - 0.5 * std::cos(2.0 * kPi * (double)i / (double)(L - 1));
+    double ph = up ? 2.0 * kPi * (((double)cfg.f0 - (double)cfg.carrier) * t + 0.5 * k * t * t)
+                   : 2.0 * kPi * (((double)cfg.f1 - (double)cfg.carrier) * t - 0.5 * k * t * t);
+    ph -= kPi / 2.0;
+    g[i] = std::complex<double>(w * std::cos(ph), w * std::sin(ph));
+    out.tmpl[2 * (size_t)i] = (float)g[i].real();
+    out.tmpl[2 * (size_t)i + 1] = (float)g[i].imag();
+  }
+  // H/n: spectrum of the zero-padded template with the inverse transform's 1/n folded in
+  fft_double(g);
+  out.hn.resize(2 * (size_t)n);
+  for (uint32_t i = 0; i < n; i++) {
+    out.hn[2 * (size_t)i] = (float)(g[i].real() / (double)n);
+    out.hn[2 * (size_t)i + 1] = (float)(g[i].imag() / (double)n);
+  }
+  // the carrier folded into the taps: sum_k fir[k] x[r-k] e^{-jw(r-k)} = e^{-jwr} sum_k (fir[k] e^{jwk}) x[r-k]
+  const double cyc = (double)cfg.carrier / fs;  // cycles per input sample
+  out.fir.assign(kFir, kFir + kFirTaps);
+  out.ctap.resize(2 * (size_t)kFirTaps);
+  for (int t = 0; t < kFirTaps; t++) {
+    double ph = cyc * (double)t;
+    ph -= std::floor(ph);
+    out.ctap[2 * t] = (float)((double)kFir[t] * std::cos(2.0 * kPi * ph));
+    out.ctap[2 * t + 1] = (float)((double)kFir[t] * std::sin(2.0 * kPi * ph));
+  }
+  // e^{-jw D i}, i < n: rotation of decimated sample i relative to the first one of its block
+  out.rot.resize(2 * (size_t)n);
+  for (uint32_t i = 0; i < n; i++) {
+    double ph = cyc * (double)D * (double)i;
+    ph -= std::floor(ph);
+    out.rot[2 * (size_t)i] = (float)std::cos(-2.0 * kPi * ph);
+    out.rot[2 * (size_t)i + 1] = (float)std::sin(-2.0 * kPi * ph);
+  }
+  return 0;
+}
+
 int build_tables(const uc_config& cfg, Tables& out) {
   if (!pow2(cfg.n) || cfg.n < 64 || cfg.n > 65536) return -EINVAL;
   if (cfg.variant < 0 || cfg.variant >= UC_NUM_VARIANTS) return -EINVAL;
   if (!(cfg.fs > 0.0f)) return -EINVAL;
   const uint32_t n = cfg.n;
+  if (cfg.variant == UC_STREAM) {  // no per-frame tables: see build_stream_tables
+    out = Tables();
+    out.n = n;
+    out.bandwidth = (uint32_t)((cfg.f1 - cfg.f0) * (float)n / cfg.fs);
+    out.bandwidth2 = out.bandwidth * 2;
+    out.idx_left_zero = n - out.bandwidth2;
+    out.fir.assign(kFir, kFir + kFirTaps);
+    return 0;
+  }
   const Trig tr{(cfg.flags & UC_FLAG_LIBM_TRIG) != 0};
   const float tf = cfg.time_frame > 0.0f ? cfg.time_frame : (float)n / cfg.fs;
 

@@ -33,6 +33,17 @@ struct Tables {
   std::vector<float> fir;                     // IQ, 27 taps
 };
 
+// UC_STREAM (include/uchirp.h): everything the overlap-save kernel reads
+struct StreamTables {
+  uint32_t decim = 0, tmpl_len = 0, hop = 0, halo = 0;
+  std::vector<float> tmpl;  // L complex: template g
+  std::vector<float> hn;    // n complex: FFT_n(g zero-padded) / n
+  std::vector<float> fir;   // 27 real taps (iq_modulation/Src/iq_modem.c:18)
+  std::vector<float> ctap;  // 27 complex: fir[k] e^{+j 2 pi carrier k / fs}
+  std::vector<float> rot;   // n complex: e^{-j 2 pi carrier D i / fs}
+};
+int build_stream_tables(const uc_config& cfg, StreamTables& out);
+
 // returns 0 or a negative errno
 int build_tables(const uc_config& cfg, Tables& out);
 
