@@ -556,11 +556,14 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
   sp.peaks = d_peaks;
   for (int k = 0; k < 2 * uc::kFirTapsDev; k++) sp.ctap[k] = c->stab.ctap[k];
   const int D = (int)c->stab.decim;
+  for (int sub = 0; sub < D / 2; sub++) {
+    sp.rots[2 * sub] = c->stab.rot[2 * (size_t)(sub * (4096 / D))];
+    sp.rots[2 * sub + 1] = c->stab.rot[2 * (size_t)(sub * (4096 / D)) + 1];
+  }
   if (c->stream_blocks_per_cu == 0) c->stream_blocks_per_cu = uc::stream_max_blocks_per_cu(dtype, D);
   size_t grid = (size_t)c->num_cu * (size_t)c->stream_blocks_per_cu;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
-  const size_t groups = (n_blocks + uc::stream_group_blocks() - 1) / uc::stream_group_blocks();
-  if (grid > groups) grid = groups;
+  if (grid > n_blocks) grid = n_blocks;
   int lrc = uc::launch_stream(dtype, D, sp, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "stream kernel launch");
 

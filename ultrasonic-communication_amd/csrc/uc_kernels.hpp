@@ -88,9 +88,9 @@ struct StreamParams {
   float* compressed;     // device or nullptr
   uc_peak* peaks;        // device or nullptr
   float ctap[2 * kFirTapsDev];  // fir[k] e^{+j 2 pi carrier k / fs}, (re, im)
+  float rots[16];               // rot[s * 4096 / D], s < D/2: rotation of sub-tile s, (re, im)
 };
 int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream);
 int stream_max_blocks_per_cu(int dtype, int decim);
-int stream_group_blocks();  // consecutive blocks a workgroup takes at a time
 
 }  // namespace uc

@@ -8,24 +8,29 @@
 // The decimation and the overlap-save blocking are this build's (the firmware works frame by frame).
 //
 // Design (MI355X): one 2-wave workgroup per overlap-save block of 2048 decimated samples,
-// persistent over groups of consecutive blocks (a block re-reads the (L-1) D + 26 input samples it
+// persistent over a contiguous run of blocks (a block re-reads the (L-1) D + 26 input samples it
 // shares with its predecessor: consecutive blocks on one CU find them in L2).
 //   * The carrier is folded into the taps: sum_k fir[k] x[r-k] e^{-jw(r-k)} = e^{-jwr} sum_k c[k] x[r-k]
 //     with 27 complex constants c[k] = fir[k] e^{jwk} held in SGPR pairs -- the FIR runs on the REAL
 //     samples (one packed FMA per tap for I and Q together) and only the D-th outputs are computed;
 //     e^{-jwr} is one table multiply per decimated sample (the block-constant part of that phase
 //     drops out of |y|).
-//   * Input is streamed in sub-tiles of 4096 samples: coalesced 16-byte loads into registers one
-//     sub-tile ahead (the next block's first sub-tile is in flight during the FFTs), written to a
+//   * Input is streamed in sub-tiles of 4096 samples: coalesced 16-byte loads into registers TWO
+//     sub-tiles ahead (the next block's first two are in flight during the FFTs), written to a
 //     padded LDS image (36-float rows per 32 samples: the per-thread sliding windows, 128 B apart,
 //     are read with conflict-free ds_read_b128), 32/D consecutive outputs per thread.
 //   * The decimated samples land in the FFT tile in natural order (linear writes, linear reads);
-//     forward 16 x 16 x 8, x H/N in registers, inverse 8 x 16 x 16 exactly as uc_full_kernel.hip.
+//     forward 16 x 16 x 8, x H/N in registers, inverse 8 x 16 x 16 as uc_full_kernel.hip, but
+//     ping-ponging between the tile and the (then idle) image area: one barrier per exchange.
 //   * |y| for the hop = 2049 - L valid outputs leaves as coalesced dword stores; the block maximum
 //     is a DPP wave reduction on squared magnitudes.
 // HBM traffic per input sample: 4 B in + 4/D B out (+ 8 B of peak record per block).
 #include "uc_kernels.hpp"
 #include "uc_pk.hpp"
+
+#ifndef UC_STREAM_EXP
+#define UC_STREAM_EXP 0  // diagnostic builds: 1 = no transforms, 2 = no input loads
+#endif
 
 namespace uc {
 
@@ -36,7 +41,9 @@ constexpr int kSubIn = 4096;     // input samples per sub-tile (32 per thread)
 constexpr int kImgF4 = (kSubIn + 28) / 4 + ((kSubIn + 28) / 4 >> 3) + 1;  // padded image, float4 units
 constexpr int kTileOff = kImgF4 * 4;                                        // floats
 constexpr int kRedOff = kTileOff + 2 * kN;
-constexpr int kLdsFloats = kRedOff + 16;
+constexpr int kTw2Off = kRedOff + 16;         // W_256^(t k), t < 16, k < 16: forward pass 2
+constexpr int kTwBOff = kTw2Off + 2 * 256;    // W_128^(t k), t < 16, k < 8: inverse pass B
+constexpr int kLdsFloats = kTwBOff + 2 * 128;
 
 constexpr float kSqrtHalfF = 0.70710678118654752440f;
 constexpr float kCos8 = 0.92387953251128675613f;
@@ -102,8 +109,6 @@ __device__ __forceinline__ v4f cvt4(v4u raw) {
   return r;
 }
 
-constexpr int kGroup = 16;  // consecutive blocks one workgroup takes before it jumps
-
 template <int DTYPE, int D>
 __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   constexpr int L = kN / D;            // template length (decimated samples)
@@ -123,9 +128,12 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   const int j = threadIdx.x;
   const int wave = j >> 6;
 
-  const size_t nb = p.n_blocks;
-  size_t b = (size_t)blockIdx.x * kGroup;
-  if (b >= nb) return;
+  // balanced contiguous partition of the blocks: workgroup w takes base (+1 for the first `rem`) blocks
+  const size_t base = p.n_blocks / gridDim.x, rem = p.n_blocks % gridDim.x;
+  const size_t w_ = blockIdx.x;
+  size_t b = w_ * base + (w_ < rem ? w_ : rem);
+  const size_t bend = b + base + (w_ < rem ? 1 : 0);
+  if (b >= bend) return;
 
   const __amdgpu_buffer_rsrc_t rs_hn = make_rsrc(p.hn, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
@@ -133,9 +141,35 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   const int voff8 = j * 8, voff16 = j * 16;
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
 
+  // Vector-memory loads return in order: a table load issued inside the block loop could not
+  // complete before the input prefetch issued ahead of it, and would serialise the memory latency
+  // into the transforms.  So everything the loop needs is made resident here -- registers for the
+  // per-thread values, two small LDS tables for the pass-2 / pass-B twiddles -- and the loop's only
+  // vector loads are the input stream itself.
   const v2f tw3_1 = buf_ld64(rs_tw, (j & (kN - 1)) * 8, 0);        // W_2048^j
   const v2f tw3_2 = buf_ld64(rs_tw, ((2 * j) & (kN - 1)) * 8, 0);  // W_2048^2j
   const v2f tw3_4 = buf_ld64(rs_tw, ((4 * j) & (kN - 1)) * 8, 0);  // W_2048^4j
+  const v2f tw3_8 = buf_ld64(rs_tw, ((8 * j) & (kN - 1)) * 8, 0);  // W_2048^8j
+  v2f hres[2][8];  // H[k]/N at this thread's bins k = j + 128 h + 256 t
+#pragma unroll
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int t = 0; t < 8; t++) hres[h][t] = buf_ld64(rs_hn, voff8 + T * 8 * h, 256 * 8 * t);
+  v2f rotu[OPT];   // e^{-jw D (OPT j + u)}: rotation of this thread's outputs inside a sub-tile
+#pragma unroll
+  for (int u = 0; u < OPT; u++) rotu[u] = buf_ld64(rs_rot, (OPT * j + u) * 8, 0);
+  {
+    float* tw2t = lds + kTw2Off;
+    float* twBt = lds + kTwBOff;
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+      const int e = j + T * r;  // t = e >> 4, k = e & 15
+      lds_st(tw2t, e, buf_ld64(rs_tw, ((8 * (e >> 4) * (e & 15)) & (kN - 1)) * 8, 0));
+    }
+    lds_st(twBt, j, buf_ld64(rs_tw, ((16 * (j >> 3) * (j & 7)) & (kN - 1)) * 8, 0));  // t = j >> 3, k = j & 7
+  }
+  const float* tw2t = lds + kTw2Off;
+  const float* twBt = lds + kTwBOff;
 
   // LDS addresses of the transform (complex units), as uc_full_kernel.hip
   const int s1 = j & 15;
@@ -150,44 +184,52 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
 
   // one sub-tile of input: 4096 + 28 samples starting at sample (blk HOP D + sub 4096) of the buffer
   // (that sample is 26 taps behind the first output of the sub-tile); loads past the end of the
-  // buffer, and the tail load of threads >= 7, fall outside the resource and return 0
-  v4u stg[9];
-  auto issue_loads = [&](size_t blk, int sub) {
+  // buffer, and the tail load of threads >= 7, fall outside the resource and return 0.
+  // Two register sets: the loads run TWO sub-tiles ahead of the FIR (and through the transforms).
+  v4u stg[2][9];
+  auto issue_loads = [&](size_t blk, int sub, v4u (&dst)[9]) {
     const size_t first = blk * (size_t)(HOP * D) + (size_t)sub * kSubIn;
     const size_t left = p.n_samples > first ? p.n_samples - first : 0;
     const int recs = left < (size_t)(kSubIn + 28) ? (int)left : kSubIn + 28;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.samples) + first * 4, recs * 4);
+#if UC_STREAM_EXP == 2
+    if (blk > 1u << 30)
+#endif
+    {
 #pragma unroll
-    for (int r = 0; r < 8; r++) stg[r] = buf_ld128(rx, voff16, T * 16 * r);
-    stg[8] = buf_ld128(rx, voff16, kSubIn * 4);
+      for (int r = 0; r < 8; r++) dst[r] = buf_ld128(rx, voff16, T * 16 * r);
+      dst[8] = buf_ld128(rx, voff16, kSubIn * 4);
+    }
   };
 
-  issue_loads(b, 0);
+  issue_loads(b, 0, stg[0]);
+  issue_loads(b, 1, stg[1]);
+
+  float* tb = lds;  // second transform tile: the image area is free once the last window is read
 
   while (true) {
     int s1v = s1;
-    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
-    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
-    // next block of this workgroup: kGroup consecutive ones, then the next group of the grid
-    size_t bn = b + 1;
-    if ((bn % kGroup) == 0) bn += (size_t)(gridDim.x - 1) * kGroup;
-    const bool more = bn < nb;
+    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4, t3d = tw3_8;
+    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c), "+v"(t3d));
+    const size_t bn = b + 1;
+    const bool more = bn < bend;
 
     // ---- front end: FIR + decimation, sub-tile by sub-tile, into the FFT tile ----------------
 #pragma unroll
     for (int s = 0; s < NSUB; s++) {
-      __syncthreads();  // the windows of the previous sub-tile (and the previous block's last pass) are read
+      v4u (&cur)[9] = stg[s & 1];
+      __syncthreads();  // the windows of the previous sub-tile (and the previous block's transforms) are read
 #pragma unroll
       for (int r = 0; r < 8; r++) {
         const int q = j + T * r;  // float4 index inside the sub-tile
-        img[q + (q >> 3)] = cvt4<DTYPE>(stg[r]);
+        img[q + (q >> 3)] = cvt4<DTYPE>(cur[r]);
       }
       if (j < 7) {
         const int q = kSubIn / 4 + j;
-        img[q + (q >> 3)] = cvt4<DTYPE>(stg[8]);
+        img[q + (q >> 3)] = cvt4<DTYPE>(cur[8]);
       }
-      if (s + 1 < NSUB) issue_loads(b, s + 1);
-      else if (more) issue_loads(bn, 0);
+      if (s + 2 < NSUB) issue_loads(b, s + 2, cur);
+      else if (more) issue_loads(bn, s + 2 - NSUB, cur);
       __syncthreads();
 
       // window: samples 32 j .. 32 j + WIN of the sub-tile image; output u sits on sample 26 + D u
@@ -198,9 +240,6 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
         xs[2 * d] = mkv(w4.x, w4.y);
         xs[2 * d + 1] = mkv(w4.z, w4.w);
       }
-      v4u rr[OPT / 2];  // e^{-jw D m} of this thread's outputs, m = s SUBOUT + OPT j + u
-#pragma unroll
-      for (int h = 0; h < OPT / 2; h++) rr[h] = buf_ld128(rs_rot, j * (OPT * 8) + 16 * h, s * SUBOUT * 8);
       __builtin_amdgcn_sched_barrier(0);
       v2f acc[OPT];
 #pragma unroll
@@ -217,11 +256,13 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
           }
         }
       }
-      // rotate and store 2 complex samples per ds_write_b128, natural order
+      // rotate by e^{-jw D m}, m = s SUBOUT + OPT j + u (the sub-tile's part of it is wave-uniform), and
+      // store 2 complex samples per ds_write_b128, natural order
+      const v2f rs = mkv(p.rots[2 * s], p.rots[2 * s + 1]);
 #pragma unroll
       for (int h = 0; h < OPT / 2; h++) {
-        const v2f z0 = pk_cmul(acc[2 * h], mkv(__uint_as_float(rr[h].x), __uint_as_float(rr[h].y)));
-        const v2f z1 = pk_cmul(acc[2 * h + 1], mkv(__uint_as_float(rr[h].z), __uint_as_float(rr[h].w)));
+        const v2f z0 = pk_cmul(pk_cmul(acc[2 * h], rotu[2 * h]), rs);
+        const v2f z1 = pk_cmul(pk_cmul(acc[2 * h + 1], rotu[2 * h + 1]), rs);
         v4f o;
         o.x = z0.x; o.y = z0.y; o.z = z1.x; o.w = z1.y;
         *reinterpret_cast<v4f*>(tile + 2 * (s * SUBOUT + OPT * j + 2 * h)) = o;
@@ -229,34 +270,33 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     }
     __syncthreads();
 
+    // The transforms ping-pong between the two tiles (tile -> tb -> tile -> tb -> tile): every
+    // exchange is write, ONE barrier, read.
     // ---- forward pass 1 -------------------------------------------------------------------------
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, j + T * t);
     __builtin_amdgcn_sched_barrier(0);
+#if UC_STREAM_EXP == 1
+    if (p.n_out != 12345) goto outputs;
+#endif
     pk_dft16(v, K, H);
-    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(tile, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    for (int t = 0; t < 16; t++) lds_st(tb, wr1 + (t ^ s1v), v[pk_slot16(t)]);
     __syncthreads();
 
     // ---- forward pass 2: twiddles W_256^(t k), k = j & 15 ------------------------------------------
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tb, ((t & 1) ? rd1o : rd1e) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 1; t < 16; t++) {
-      const v2f w = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN - 1)) * 8, 0);
-      v[t] = pk_cmul(v[t], w);
-    }
+    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2t, 16 * t + (j & 15)));
     pk_dft16(v, K, H);
-    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 16; t++) lds_st(tile, wr2 + 16 * t, v[pk_slot16(t)]);
     __syncthreads();
 
     // ---- forward pass 3 (radix-8), x H/N, inverse pass A (radix-8) ----------------------------------
-    v2f y8[2][8];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int bf = j + T * h;
@@ -278,37 +318,24 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
       for (int t = 1; t < 8; t++) u[t] = pk_cmul(u[t], w[t]);
       pk_dft8(u, H);
 #pragma unroll
-      for (int t = 0; t < 8; t++) {
-        const v2f hk = buf_ld64(rs_hn, voff8 + T * 8 * h, 256 * 8 * t);
-        u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hk);
-      }
+      for (int t = 0; t < 8; t++) u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hres[h][t]);
       v2f g[8];
 #pragma unroll
       for (int t = 0; t < 8; t++) g[t] = u[pk_slot8(t)];
       pk_dft8(g, H);
+      // IDFT8[t] = DFT8[(8 - t) & 7]; element 8 bf + t, swizzled phys = o ^ ((o >> 4) & 7)
 #pragma unroll
-      for (int t = 0; t < 8; t++) y8[h][t] = g[pk_slot8((8 - t) & 7)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int bf = j + T * h;
-#pragma unroll
-      for (int t = 0; t < 8; t++) lds_st(tile, 8 * bf + (t ^ ((bf >> 1) & 7)), y8[h][t]);
+      for (int t = 0; t < 8; t++) lds_st(tb, 8 * bf + (t ^ ((bf >> 1) & 7)), g[pk_slot8((8 - t) & 7)]);
     }
     __syncthreads();
 
     // ---- inverse pass B: radix-16, conj twiddles W_128^(t k), k = j & 7 -------------------------------
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, rdA + 128 * t);
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tb, rdA + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 1; t < 16; t++) {
-      const v2f w = buf_ld64(rs_tw, ((16 * t * (j & 7)) & (kN - 1)) * 8, 0);
-      v[t] = pk_cmulc(v[t], w);
-    }
+    for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], lds_ld(twBt, 8 * t + (j & 7)));
     pk_dft16(v, K, H);
-    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 16; t++) lds_st(tile, ((t & 1) ? wrBo : wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
     __syncthreads();
@@ -317,13 +344,29 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rdBo : rdBe) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
+    {
+      // W_2048^(t j), t = 1..15, as products of the four resident powers (at most two factors deep)
+      v2f w[16];
+      w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = t3d;
+      w[3] = pk_cmul(w[1], w[2]);
+      w[5] = pk_cmul(w[1], w[4]);
+      w[6] = pk_cmul(w[2], w[4]);
+      w[9] = pk_cmul(w[1], w[8]);
+      w[10] = pk_cmul(w[2], w[8]);
+      w[12] = pk_cmul(w[4], w[8]);
+      w[7] = pk_cmul(w[3], w[4]);
+      w[11] = pk_cmul(w[3], w[8]);
+      w[13] = pk_cmul(w[5], w[8]);
+      w[14] = pk_cmul(w[6], w[8]);
+      w[15] = pk_cmul(w[7], w[8]);
 #pragma unroll
-    for (int t = 1; t < 16; t++) {
-      const v2f w = buf_ld64(rs_tw, ((t * j) & (kN - 1)) * 8, 0);
-      v[t] = pk_cmulc(v[t], w);
+      for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], w[t]);
     }
     pk_dft16(v, K, H);
 
+#if UC_STREAM_EXP == 1
+  outputs:
+#endif
     // ---- |y[i]|, i = j + 128 t; outputs i >= L-1 are free of circular wrap-around ---------------------
     const size_t q0 = b * (size_t)HOP;                       // first output of this block
     const size_t room = p.n_out - q0;                        // > 0
@@ -378,8 +421,6 @@ int occupancy_one() {
 }
 
 }  // namespace
-
-int stream_group_blocks() { return kGroup; }
 
 int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream) {
   if (grid <= 0) return (int)hipSuccess;
