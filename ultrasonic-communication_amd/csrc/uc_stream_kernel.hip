@@ -149,7 +149,6 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   const v2f tw3_1 = buf_ld64(rs_tw, (j & (kN - 1)) * 8, 0);        // W_2048^j
   const v2f tw3_2 = buf_ld64(rs_tw, ((2 * j) & (kN - 1)) * 8, 0);  // W_2048^2j
   const v2f tw3_4 = buf_ld64(rs_tw, ((4 * j) & (kN - 1)) * 8, 0);  // W_2048^4j
-  const v2f tw3_8 = buf_ld64(rs_tw, ((8 * j) & (kN - 1)) * 8, 0);  // W_2048^8j
   v2f hres[2][8];  // H[k]/N at this thread's bins k = j + 128 h + 256 t
 #pragma unroll
   for (int h = 0; h < 2; h++)
@@ -209,8 +208,8 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
 
   while (true) {
     int s1v = s1;
-    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4, t3d = tw3_8;
-    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c), "+v"(t3d));
+    v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
+    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
     const size_t bn = b + 1;
     const bool more = bn < bend;
 
@@ -345,9 +344,9 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rdBo : rdBe) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
     {
-      // W_2048^(t j), t = 1..15, as products of the four resident powers (at most two factors deep)
+      // W_2048^(t j), t = 1..15, as products of the three resident powers (at most three factors deep)
       v2f w[16];
-      w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = t3d;
+      w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = pk_cmul(t3c, t3c);
       w[3] = pk_cmul(w[1], w[2]);
       w[5] = pk_cmul(w[1], w[4]);
       w[6] = pk_cmul(w[2], w[4]);
