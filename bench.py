@@ -70,8 +70,35 @@ def cpu_baseline(frames_host, mag_mean):
                       "(float32 butterflies), OpenMP %d threads, %.1f s" % (passes, n // passes, cores, dt)}
 
 
+def stream_measurement(args, eng, frames, rank):
+    """BASELINE config 4 (side measurement): the batch read as ONE continuous stream through UC_STREAM."""
+    x = frames.reshape(-1)
+    halo, n_out, n_blocks, hop = eng.stream_geometry(x.numel())
+    comp = torch.empty(n_out, dtype=torch.float32, device=x.device)
+    pk = torch.empty((n_blocks, 2), dtype=torch.int32, device=x.device)
+    for _ in range(args.warmup):
+        eng.process_stream(x, compressed_out=comp, peaks_out=pk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        eng.process_stream(x, compressed_out=comp, peaks_out=pk)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    byts = x.numel() * 4 + n_out * 4 + n_blocks * 8
+    if rank == 0:
+        print(json.dumps({"metric": "input samples/s (stream: FIR decimate + overlap-save compression, side measurement)",
+                          "value": x.numel() / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": dt * 1e3, "decim": int(eng.cfg.decim),
+                          "blocks": n_blocks, "blocks_per_s": n_blocks / dt,
+                          "roofline": {"bound": "hbm", "achieved": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": byts / dt / 1e9 / HBM_PEAK_GBS,
+                                       "bytes_per_sample": byts / x.numel()}}), flush=True)
+
+
 def side_measurement(args, eng, frames, world, rank):
     """Not the contract line: frames/s of one of the sibling variants on the same synthetic batch."""
+    if args.variant == "stream":
+        return stream_measurement(args, eng, frames, rank)
     n = eng.n
     per_frame = {"sync_cplx": 8193, "compress": 8192 + 32, "dechirp_down": 8192 + 32, "iq": 8192 + 104 + 32,
                  "iq1024": 4096 + 104 + 32}[args.variant]
@@ -105,7 +132,7 @@ def main():
     ap.add_argument("--snr", type=float, default=-10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--variant", default="rx_real",
-                    choices=["rx_real", "sync_cplx", "compress", "dechirp_down", "iq", "iq1024"],
+                    choices=["rx_real", "sync_cplx", "compress", "dechirp_down", "iq", "iq1024", "stream"],
                     help="default rx_real = BASELINE configs[1]; the others are side measurements")
     args = ap.parse_args()
 
@@ -125,7 +152,7 @@ def main():
     import uchirp
     mag_mean = 1000.0
     vmap = {"rx_real": (uchirp.RX_REAL, {}), "sync_cplx": (uchirp.SYNC_CPLX, {}), "compress": (uchirp.COMPRESS, {}),
-            "dechirp_down": (uchirp.DECHIRP_DOWN, {}), "iq": (uchirp.IQ, {}), "iq1024": (uchirp.IQ, {"n": 1024})}
+            "dechirp_down": (uchirp.DECHIRP_DOWN, {}), "iq": (uchirp.IQ, {}), "iq1024": (uchirp.IQ, {"n": 1024}), "stream": (uchirp.STREAM, {})}
     vid, vkw = vmap[args.variant]
     eng = uchirp.Engine(vid, device=local_rank, mag_mean=mag_mean, **vkw)
     nf = args.frames

@@ -61,6 +61,65 @@ def _worker(rank, world, port, n_frames, q):
         dist.destroy_process_group()
 
 
+def test_stream_span_tiles_the_stream():
+    halo, hop, D = 2066, 1793, 8
+    for n_samples in (0, halo, halo + 8, halo + 8 * hop * 5 + 16, 1 << 22):
+        n_out = max(0, (n_samples - halo) // D) if n_samples > halo else 0
+        for w in (1, 2, 3, 8):
+            spans = [shard.stream_span(n_samples, w, r, halo, hop, D) for r in range(w)]
+            assert spans[0][2] == 0 and spans[-1][3] == n_out
+            for a, b in zip(spans, spans[1:]):
+                assert a[3] == b[2]
+            for s0, s1, q0, q1 in spans:
+                if q1 > q0:
+                    assert q0 % hop == 0 and s0 == q0 * D and s1 == halo + q1 * D and s1 <= n_samples
+
+
+def _stream_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from test_stream import make_stream
+        from oracle import uco
+        x, _ = make_stream(40, seed=5, snr_db=0.0)
+        o = uco.Oracle(uco.STREAM)
+        halo, n_out, n_blocks, hop = o.stream_geometry(x.size)
+        s0, s1, q0, q1 = shard.stream_span(x.size, world, rank, halo, hop, o.cfg.decim)
+        comp, peaks = o.process_stream(x[s0:s1], threads=1)
+        assert comp.size == q1 - q0
+        # gather the per-block peak offsets (the "decoded" stream of this variant): 4 bytes per block
+        mine = torch.from_numpy(peaks["offset"].astype(np.int32))
+        sizes = [shard.partition(n_blocks, world, r) for r in range(world)]
+        mx = max(h - l for l, h in sizes)
+        pad = torch.full((mx,), -1, dtype=torch.int32)
+        pad[:mine.numel()] = mine
+        out = torch.empty(world * mx, dtype=torch.int32)
+        dist.all_gather_into_tensor(out, pad)
+        full = torch.cat([out[r * mx:r * mx + (h - l)] for r, (l, h) in enumerate(sizes)]).numpy()
+        ref_c, ref_p = o.process_stream(x, threads=1)
+        ok = bool(np.array_equal(full, ref_p["offset"].astype(np.int32)))
+        ok = ok and bool(np.abs(comp - ref_c[q0:q1]).max() <= 1e-6 * ref_c.max())
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stream_sharded_by_blocks_world2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_stream_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
+
+
 @pytest.mark.parametrize("n_frames", [64, 37])
 def test_frame_sharded_decode_with_symbol_gather_world2(n_frames):
     world = 2

@@ -28,6 +28,20 @@ def frame_span(lo, hi, n, stride, halo=0):
     return lo * stride - halo, (hi - 1) * stride + n
 
 
+def stream_span(n_samples, world, rank, halo, hop, decim):
+    """UC_STREAM: the overlap-save BLOCKS are independent, so a stream shards like frames do.
+    Returns (s0, s1, q0, q1): rank processes samples[s0:s1] (its first `halo` samples are the
+    history it shares, read-only, with the previous rank) and produces outputs [q0, q1) of the
+    whole stream; block boundaries coincide with the single-GPU run, so the results are identical."""
+    n_out = (n_samples - halo) // decim if n_samples > halo else 0
+    n_blocks = -(-n_out // hop)
+    b0, b1 = partition(n_blocks, world, rank)
+    q0, q1 = min(b0 * hop, n_out), min(b1 * hop, n_out)
+    if q1 <= q0:
+        return 0, 0, q0, q0
+    return q0 * decim, halo + q1 * decim, q0, q1
+
+
 def gather_symbols(local_symbols, n_frames, dist=None, group=None):
     """All-gather the per-rank symbol bytes into the full stream (every rank gets it).
 
