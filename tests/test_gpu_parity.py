@@ -245,6 +245,44 @@ def test_dechirp_down_variant(uchirp):
     assert same.mean() >= 0.98
 
 
+@pytest.mark.parametrize("n_frames,stride,dtype", [(97, 0, np.float32), (1, 0, np.float32), (64, 512, np.int32),
+                                                  (131, 2048 + 256, np.float32)])
+def test_dechirp_down_frame_pairs_ragged_strided_per_frame_floor(uchirp, n_frames, stride, dtype):
+    """DECHIRP_DOWN has one real reference, so the kernel transforms frames two at a time (re = frame 2u,
+    im = frame 2u+1).  The pairing must be invisible: odd counts, overlapping / gapped strides, int32 words
+    and a per-frame noise floor give what the frame-by-frame oracle gives; a frame's result does not depend
+    on its partner."""
+    o = uco.Oracle(uco.DECHIRP_DOWN)
+    e = uchirp.Engine(uchirp.DECHIRP_DOWN)
+    st = stride or 2048
+    total = (n_frames - 1) * st + 2048
+    src, _ = synth.make_frames(-(-total // 2048), seed=5 + n_frames, snr_db=-3.0, fs=100000.0, f0=17000.0,
+                               f1=18000.0, dtype=dtype)
+    buf = src.reshape(-1)[:total]
+    rng = np.random.default_rng(n_frames)
+    mm = rng.uniform(100.0, 5000.0, size=(n_frames, 2)).astype(np.float32)
+    rs, rst = o.process(buf, n_frames=n_frames, stride=stride, mag_mean=mm)
+    gs, gst = e.process(buf, n_frames=n_frames, stride=stride, mag_mean=mm)
+    assert gst.shape == rst.shape == (n_frames, 1) and (gs == uchirp.SYM_NONE).all()
+    r, g = rst[:, 0], gst[:, 0]
+    scale = np.maximum(r["mag_max"].astype(np.float64), 1e-30)
+    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+        assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL
+    assert np.array_equal(g["mag_mean"], mm[:, 0])
+    assert np.allclose(g["snr"], r["snr"], rtol=1e-4, atol=1e-4)
+    same = (g["max_freq_right"] == r["max_freq_right"]) & (g["max_freq_left"] == r["max_freq_left"])
+    assert same.mean() >= 0.97
+    if n_frames >= 4 and stride == 0:
+        # partner independence: swap the partners of every pair, each frame's record must not move
+        perm = np.arange(n_frames)
+        perm[:n_frames // 2 * 2] = perm[:n_frames // 2 * 2].reshape(-1, 2)[:, ::-1].reshape(-1)
+        _, g2 = e.process(np.ascontiguousarray(buf.reshape(n_frames, 2048)[perm]), mag_mean=mm[perm])
+        back = np.empty_like(g2[:, 0])
+        back[perm] = g2[:, 0]
+        for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+            assert (np.abs(back[fld].astype(np.float64) - g[fld]) / scale).max() <= MAG_TOL
+
+
 def test_device_tensors_async_and_properties_at_scale(uchirp):
     """Size-independent properties on a large device-resident batch:
     decode == transmitted bits, exact x2 linearity, shard-invariance."""

@@ -82,7 +82,7 @@ struct uc_ctx {
   float* d_aux = nullptr;  // variant-specific (COMPRESS: H_down packed; IQ: carrier/fir/...)
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
-  int band_blocks_per_cu[2] = {0, 0};
+  int band_blocks_per_cu[3] = {0, 0, 0};
   int full_blocks_per_cu = 0;
   int iq_blocks_per_cu = 0;
   int stream_blocks_per_cu = 0;
@@ -460,10 +460,10 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   p.bw2 = c->tab.bandwidth2;
   p.ifs = (uint32_t)(int32_t)c->cfg.fs;
   p.true_dc = (c->cfg.flags & UC_FLAG_TRUE_DC) ? 1u : 0u;
-  p.single = (variant == UC_DECHIRP_DOWN) ? 1u : 0u;
   p.debug = nullptr;
   if (const char* d = getenv("UC_DEBUG_PTR")) p.debug = (unsigned long long*)strtoull(d, nullptr, 0);
-  const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx : uc::kModeRxReal;
+  const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
+                   : (variant == UC_DECHIRP_DOWN) ? uc::kModePair : uc::kModeRxReal;
   int& bpc = c->band_blocks_per_cu[mode];
   if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, c->band_waves);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;

@@ -305,7 +305,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // instead of each walking its own multi-MiB chunk of an 8+ GiB buffer (measured: the
   // per-frame time grew with the batch size with contiguous chunks), while the finaliser
   // still owns 64 consecutive frames (coalesced symbol stores).
-  const size_t nfr = p.n_frames;
+  // kModePair: the unit of work is a PAIR of frames (2u, 2u+1) riding in one complex transform
+  constexpr bool kPair = MODE == kModePair;
+  constexpr bool kReal = MODE != kModeCplx;  // real reference(s): Hermitian split in the pruned pass
+  const size_t nfr = kPair ? (p.n_frames + 1) / 2 : p.n_frames;
   const size_t ngroups = (nfr + kRingFrames - 1) / kRingFrames;
   size_t grp = blockIdx.x;
   if (grp >= ngroups) return;
@@ -319,6 +322,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   if (MODE == kModeRxReal) {
 #pragma unroll
     for (int t = 0; t < 16; t++) wt[t] = buf_ld64(rs_tab0, voff8, T * 8 * t);
+  }
+  v2f wr[8];   // PAIR only: the REAL window*chirp table, two samples per register pair
+  if (kPair) {
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+      wr[m] = mkv(buf_ld32(rs_tab0, voff8, T * 8 * (2 * m)), buf_ld32(rs_tab0, voff8, T * 8 * (2 * m + 1)));
   }
   // pass-2 twiddles W_256^(t*k), k = j & 15: all 15 resident (at 3 waves/SIMD the
   // registers are there; the factored form wa[n2]*wb[n1] costs 9 more products per frame)
@@ -338,13 +347,27 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const int rd1 = j ^ (((j >> 4) & 7) << 1);                     // + 128 t
   const int wr2 = (j >> 4) * 256 + (j & 15);                     // + 16 t
 
-  v2f xp[8];  // the frame's 16 samples of this thread, two per register pair (raw words)
-  {
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + f * p.stride * 4, kN * 4);
+  // the unit's 16 samples of this thread as raw words: two per register pair, or (PAIR) sample t of
+  // frame 2u in the low and of frame 2u+1 in the high half of pair t
+  constexpr int NX = kPair ? 16 : 8;
+  v2f xp[NX];
+  auto load_unit = [&](size_t u) {
+    if (kPair) {
+      const bool has_b = 2 * u + 1 < p.n_frames;  // a ragged last pair: frame b reads as zeros
+      const __amdgpu_buffer_rsrc_t ra =
+          make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u) * p.stride * 4, kN * 4);
+      const __amdgpu_buffer_rsrc_t rb = make_rsrc(
+          reinterpret_cast<const char*>(p.frames) + (2 * u + (has_b ? 1 : 0)) * p.stride * 4, has_b ? kN * 4 : 0);
 #pragma unroll
-    for (int m = 0; m < 8; m++)
-      xp[m] = mkv(buf_ld32(rx, voff4, T * 4 * (2 * m)), buf_ld32(rx, voff4, T * 4 * (2 * m + 1)));
-  }
+      for (int t = 0; t < NX; t++) xp[t] = mkv(buf_ld32(ra, voff4, T * 4 * t), buf_ld32(rb, voff4, T * 4 * t));
+    } else {
+      const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + u * p.stride * 4, kN * 4);
+#pragma unroll
+      for (int m = 0; m < 8; m++)
+        xp[m] = mkv(buf_ld32(rx, voff4, T * 4 * (2 * m)), buf_ld32(rx, voff4, T * 4 * (2 * m + 1)));
+    }
+  };
+  load_unit(f);
 
   // Finaliser, vectorised over frames: lane L turns ring slot L into history[0],
   // history[1] and the symbol of frame f0 + L (receiver/Src/main.c:209-229, 518-531).
@@ -353,13 +376,17 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       const float* e = ring + lane * kRingStride;
       const size_t ff = f0 + (size_t)lane;
       float mm_up = p.mag_mean_scalar, mm_dn = p.mag_mean_scalar;
-      if (p.mag_mean) { mm_up = p.mag_mean[2 * ff]; mm_dn = p.mag_mean[2 * ff + 1]; }
+      if (p.mag_mean) {
+        // two floats per frame; the single-history pipeline of PAIR uses the first of each frame
+        mm_up = p.mag_mean[kPair ? 4 * ff : 2 * ff];
+        mm_dn = p.mag_mean[kPair ? ((2 * ff + 1 < p.n_frames) ? 4 * ff + 2 : 4 * ff) : 2 * ff + 1];
+      }
       float mr, ml;
       int kr, kl;
       // the ring holds squared magnitudes (x4 for RX_REAL): |X| = mscale * sqrt(q)
-      const float mscale = (MODE == kModeRxReal) ? 0.5f : 1.0f;
+      const float mscale = kReal ? 0.5f : 1.0f;
       unsigned kp0, kp1, fl = 0;
-      if (MODE == kModeRxReal) {
+      if (kReal) {
         // per wave: [M_up, M_dn, kpack, edge_up, edge_dn]; wave 0's edge = bin 0, wave 1's = bin bw2
         kp0 = __float_as_uint(e[2]);
         kp1 = __float_as_uint(e[6 + 2]);
@@ -374,12 +401,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       mr = mscale * sqrtf(mr);
       ml = mscale * sqrtf(ml);
-      const Hist h0 = make_hist(mr, kr, ml, kl, mm_up, p.ifs, p.single != 0);
-      if (p.single) {
-        if (p.stats) store_hist(p.stats + ff, h0, mm_up);
-        if (p.symbols) p.symbols[ff] = (uint8_t)UC_SYM_NONE;
-      } else {
-        if (MODE == kModeRxReal) {
+      const Hist h0 = make_hist(mr, kr, ml, kl, mm_up, p.ifs, kPair);
+      {
+        if (kReal) {
           resolve_windows(e[1], (kp0 >> 16) & 255, (kp0 >> 24) & 255, e[6 + 1], (kp1 >> 16) & 255, (kp1 >> 24) & 255,
                           e[4], e[6 + 4], bw2, mr, kr, ml, kl);
         } else {
@@ -388,7 +412,20 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         }
         mr = mscale * sqrtf(mr);
         ml = mscale * sqrtf(ml);
-        const Hist h1 = make_hist(mr, kr, ml, kl, mm_dn, p.ifs, false);
+        const Hist h1 = make_hist(mr, kr, ml, kl, mm_dn, p.ifs, kPair);
+        if (kPair) {
+          // h0 = the only history of frame 2 ff, h1 = of frame 2 ff + 1 (raw bin indices,
+          // chirp_compression_freq_domain/Src/main.c:152-156); no symbol in this variant
+          const bool has_b = 2 * ff + 1 < p.n_frames;
+          if (p.stats) {
+            store_hist(p.stats + 2 * ff, h0, mm_up);
+            if (has_b) store_hist(p.stats + 2 * ff + 1, h1, mm_dn);
+          }
+          if (p.symbols) {
+            p.symbols[2 * ff] = (uint8_t)UC_SYM_NONE;
+            if (has_b) p.symbols[2 * ff + 1] = (uint8_t)UC_SYM_NONE;
+          }
+        } else {
         if (p.stats) {
           store_hist(p.stats + 2 * ff, h0, mm_up);
           store_hist(p.stats + 2 * ff + 1, h1, mm_dn);
@@ -399,6 +436,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           if ((h0.snr >= p.snr_threshold) || (h1.snr >= p.snr_threshold))
             sym = (h1.snr > h0.snr) ? (uint8_t)UC_SYM_DOWN : (uint8_t)UC_SYM_UP;
           p.symbols[ff] = sym;
+        }
         }
       }
     }
@@ -436,6 +474,13 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           v[2 * m] = pk_scale_lo(wt[2 * m], x2);
           v[2 * m + 1] = pk_scale_hi(wt[2 * m + 1], x2);
         }
+      } else if (kPair) {
+        // re = frame a * ref * hann, im = frame b * ref * hann: two real spectra in one transform
+#pragma unroll
+        for (int m = 0; m < 8; m++) {
+          v[2 * m] = pk_scale_lo(cvt_pair<DTYPE>(xp[2 * m]), wr[m]);
+          v[2 * m + 1] = pk_scale_hi(cvt_pair<DTYPE>(xp[2 * m + 1]), wr[m]);
+        }
       } else {
         const __amdgpu_buffer_rsrc_t rt = run == 0 ? rs_tab0 : rs_tab1;
 #pragma unroll
@@ -447,13 +492,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       // prefetch the next frame a whole frame time ahead (HBM latency under load is
       // microseconds; at 3 waves/SIMD the 16 registers are free)
-      if (run == kRuns - 1 && has_next) {
-        const __amdgpu_buffer_rsrc_t rx =
-            make_rsrc(reinterpret_cast<const char*>(p.frames) + fnext * p.stride * 4, kN * 4);
-#pragma unroll
-        for (int m = 0; m < 8; m++)
-          xp[m] = mkv(buf_ld32(rx, voff4, T * 4 * (2 * m)), buf_ld32(rx, voff4, T * 4 * (2 * m + 1)));
-      }
+      if (run == kRuns - 1 && has_next) load_unit(fnext);
       pk_dft16(v, K, H);
       UC_STAMP(0);
       // B4, placed AFTER the register-only part of pass 1: the wave that finished the previous
@@ -520,7 +559,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             w2 = pk_mul_w1(t3b, K);
           }
           constexpr bool do_a = true, do_b = true;
-          if (MODE == kModeRxReal) {
+          if (kReal) {
             // A[k] = (Z[k] + conj Z[n-k]) / 2,  B[k] = (Z[k] - conj Z[n-k]) / 2j
             // Z[k] = sum a_t w_t and Z[n-k] = sum b_t conj(w_t) first (2 packed FMAs per term each),
             // then sa = Z[k] + conj Z[n-k] = 2 A[k], sb = Z[k] - conj Z[n-k] = 2j B[k]
@@ -574,7 +613,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // (bins beyond bw2 fail the window predicates inside window_partial)
       const int k1 = 128 + lane;
       float* e = ring + ring_n * kRingStride + wave * 6;
-      if (MODE == kModeRxReal) {
+      if (kReal) {
         // up history looks at m_a, down history at m_b; wave 1 also holds slot 1
         Common up, dn;
         if (wave == 0) {
@@ -643,6 +682,10 @@ static int occupancy_one() {
 
 #define UC_DISPATCH(FN, ...)                                                              \
   do {                                                                                    \
+    if (mode == kModePair) { /* one build: 3 waves/SIMD */                                \
+      if (dtype == UC_DTYPE_I32) return FN<kModePair, UC_DTYPE_I32, 3>(__VA_ARGS__);      \
+      return FN<kModePair, UC_DTYPE_F32, 3>(__VA_ARGS__);                                 \
+    }                                                                                     \
     if (mode == kModeRxReal) {                                                            \
       if (dtype == UC_DTYPE_I32) {                                                        \
         if (waves == 3) return FN<kModeRxReal, UC_DTYPE_I32, 3>(__VA_ARGS__);             \

@@ -17,7 +17,7 @@ struct BandParams {
   const void* frames;     // device, int32 or float
   size_t n_frames;
   size_t stride;          // elements between frame starts
-  const float2* tab0;     // RX_REAL: (up*hann, down*hann)[n]   CPLX: (cos,sin)*hann of UP
+  const float2* tab0;     // RX_REAL: (up*hann, down*hann)[n]   CPLX: (cos,sin)*hann of UP   PAIR: (down*hann, 0)
   const float2* tab1;     // CPLX: (cos,sin)*hann of DOWN
   const float2* tw;       // exp(-2 pi i k / 2048), k < 2048
   const float* mag_mean;  // device, 2 per frame {up,down}, or nullptr
@@ -28,11 +28,12 @@ struct BandParams {
   uint32_t bw2;           // window length (<= 255)
   uint32_t ifs;           // (uint32_t)(int32_t)fs for idx2freq
   uint32_t true_dc;       // UC_FLAG_TRUE_DC
-  uint32_t single;        // 1: only history[0] exists (DECHIRP_DOWN), raw-index stats
   unsigned long long* debug;  // diagnostic builds only (UC_STAMPS), else nullptr
 };
 
-enum BandMode { kModeRxReal = 0, kModeCplx = 1 };
+// kModePair (DECHIRP_DOWN): ONE real reference, so two frames share a complex transform; one
+// history per frame with raw bin indices, stats[frame], symbols = UC_SYM_NONE
+enum BandMode { kModeRxReal = 0, kModeCplx = 1, kModePair = 2 };
 
 // returns hipError_t as int
 // `waves` = min waves per SIMD the kernel was compiled for (2, 3 or 4): a tuning knob
