@@ -246,6 +246,21 @@ int uc_process_stream(uc_ctx* ctx, const void* samples, int dtype, size_t n_samp
                       float* compressed /*n_out, nullable*/, uc_peak* peaks /*n_blocks, nullable*/,
                       void* hip_stream);
 
+/*
+ * The DFSDM peripheral in front of the ISR, as configured in receiver/Src/dfsdm.c:59-61 (SINC5,
+ * Oversampling 32, IntOversampling 1), :69 (bit clock = 80 MHz / 32 = 2.5 MHz -> 78125 words/s) and
+ * :78 (RightBitShift 2): sinc^5 filter, decimation by 32, of the microphone's 1-bit PDM stream.
+ * pdm_words: n_words x 32 bits, bit t of the stream = bit (t & 31) of word t >> 5, 1 -> +1, 0 -> -1.
+ * words_out: n_words - 4 int32 words, 24-bit result in bits 31:8 (what `buf[]` of receiver/Src/main.c:91
+ * holds: feed them to uc_process_batch / uc_receive_stream / uc_process_stream as UC_DTYPE_I32).
+ * The first 4 words only fill the filter (history of the previous chunk, or anything at stream start):
+ * words_out[q] is the conversion that ends with pdm_words[q + 4].  Integer arithmetic, exact.
+ * Any context will do (the variant is irrelevant).  Host or device pointers (device: 16-byte aligned);
+ * asynchronous on hip_stream with device pointers.
+ */
+int uc_dfsdm_sinc5(uc_ctx* ctx, const uint32_t* pdm_words, size_t n_words, int32_t* words_out,
+                   void* hip_stream);
+
 /* human-readable text of the last error on this thread ("" if none) */
 const char* uc_last_error(void);
 

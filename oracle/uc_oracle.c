@@ -1081,6 +1081,64 @@ int uco_process_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samp
 }
 
 /* ------------------------------------------------------------------------- */
+/* DFSDM front end: sinc^5 decimate-by-32 of the 1-bit PDM stream              */
+/* ------------------------------------------------------------------------- */
+
+/* receiver/Src/dfsdm.c:59-61 (SINC5, Oversampling 32, IntOversampling 1), :69 (clock divider 32:
+ * 80 MHz / 32 = 2.5 MHz bit clock -> 78125 words/s), :78 (RightBitShift 2); the 24-bit result sits
+ * in bits 31:8 of the data register (agent/ *.raw values are multiples of 256).
+ * Hogenauer form: five integrators at the bit rate, decimate, five combs, int64 (no wrap needed).
+ * Bit t of the stream is bit (t & 31) of word t >> 5 (LSB first), 1 -> +1, 0 -> -1.
+ * The first 4 words only fill the filter: out[q] is the conversion that ends with word q + 4.
+ * The hardware block itself is not in the reference (it is silicon): UNPINNED by the reference;
+ * the CPU tests pin this against the direct 156-tap convolution in numpy. */
+int uco_dfsdm_sinc5(const uint32_t* pdm, size_t n_words, int32_t* out) {
+  if (n_words <= 4) return 0;
+  if (!pdm || !out) return -EINVAL;
+  int64_t i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
+  int64_t d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
+  for (size_t w = 0; w < n_words; w++) {
+    uint32_t bits = pdm[w];
+    for (int b = 0; b < 32; b++) {
+      int64_t sgn = ((bits >> b) & 1u) ? 1 : -1;
+      i1 += sgn; i2 += i1; i3 += i2; i4 += i3; i5 += i4;
+    }
+    int64_t c1 = i5 - d1; d1 = i5;
+    int64_t c2 = c1 - d2; d2 = c1;
+    int64_t c3 = c2 - d3; d3 = c2;
+    int64_t c4 = c3 - d4; d4 = c3;
+    int64_t c5 = c4 - d5; d5 = c4;
+    if (w >= 4) {
+      /* floor shift; the 24-bit register clips the single value +2^23 (all-ones input) */
+      int64_t v = c5 >> 2;
+      if (v > 8388607) v = 8388607;
+      if (v < -8388608) v = -8388608;
+      out[w - 4] = (int32_t)(v * 256);
+    }
+  }
+  return 0;
+}
+
+/* Test helper (not reference behaviour): second-order delta-sigma modulator, x in [-1, 1] at the bit
+ * rate -> packed PDM words (LSB first), the kind of stream a MEMS microphone feeds the DFSDM. */
+int uco_pdm_modulate(const float* x, size_t n_bits, uint32_t* words) {
+  if (!x || !words || (n_bits & 31)) return -EINVAL;
+  double s1 = 0.0, s2 = 0.0;
+  for (size_t w = 0; w < n_bits / 32; w++) {
+    uint32_t acc = 0;
+    for (int b = 0; b < 32; b++) {
+      double in = 0.5 * (double)x[32 * w + b]; /* half scale: keeps the loop stable */
+      double y = (s2 >= 0.0) ? 1.0 : -1.0;
+      s1 += in - y;
+      s2 += s1 - y;
+      if (y > 0.0) acc |= (1u << b);
+    }
+    words[w] = acc;
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- */
 /* the receiver's main loop, literally                                        */
 /* ------------------------------------------------------------------------- */
 

@@ -76,6 +76,11 @@ int uco_stream_geometry(const uco_ctx* ctx, size_t n_samples, size_t* halo, size
 int uco_process_stream(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples,
                        float* compressed, uc_peak* peaks, int threads);
 
+/* DFSDM sinc^5 / 32 model (receiver/Src/dfsdm.c:59-61,69,78): same outputs as uc_dfsdm_sinc5 */
+int uco_dfsdm_sinc5(const uint32_t* pdm, size_t n_words, int32_t* out);
+/* test helper: 2nd-order delta-sigma modulator, n_bits (multiple of 32) samples in [-1,1] -> words */
+int uco_pdm_modulate(const float* x, size_t n_bits, uint32_t* words);
+
 /* the CMSIS-DSP primitives, restated (exposed for the golden-vector tests) */
 float uco_arm_cos_f32(float x);
 void  uco_arm_sin_cos_f32(float theta_deg, float* sin_val, float* cos_val);

@@ -66,6 +66,8 @@ def lib():
                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.uco_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
         L.uco_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
+        L.uco_dfsdm_sinc5.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
+        L.uco_pdm_modulate.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
         L.uco_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.uco_stats_per_frame.argtypes = [C.c_void_p]
         L.uco_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
@@ -213,6 +215,28 @@ class Oracle:
         if rc:
             raise RuntimeError("uco_spectrum rc=%d" % rc)
         return out.reshape(-1, self.n)
+
+
+def dfsdm_sinc5(pdm_words):
+    """sinc^5 / 32 of a packed PDM stream (first 4 words = history) -> int32 DFSDM words."""
+    w = np.ascontiguousarray(pdm_words, np.uint32).reshape(-1)
+    out = np.zeros(max(w.size - 4, 0), np.int32)
+    rc = lib().uco_dfsdm_sinc5(_ptr(w), w.size, _ptr(out))
+    if rc:
+        raise RuntimeError("uco_dfsdm_sinc5 rc=%d" % rc)
+    return out
+
+
+def pdm_modulate(x):
+    """Test helper: 2nd-order delta-sigma modulation of x in [-1, 1] -> packed uint32 words."""
+    x = np.ascontiguousarray(x, np.float32).reshape(-1)
+    if x.size % 32:
+        raise ValueError("length must be a multiple of 32")
+    w = np.zeros(x.size // 32, np.uint32)
+    rc = lib().uco_pdm_modulate(_ptr(x), x.size, _ptr(w))
+    if rc:
+        raise RuntimeError("uco_pdm_modulate rc=%d" % rc)
+    return w
 
 
 def arm_cos(x):

@@ -80,6 +80,10 @@ struct uc_ctx {
   float2* d_tab1 = nullptr;
   float2* d_tw = nullptr;
   float* d_aux = nullptr;  // variant-specific (COMPRESS: H_down packed; IQ: carrier/fir/...)
+  int32_t* d_cic4 = nullptr;  // sinc^5 byte tables, built on first use of uc_dfsdm_sinc5
+  int32_t* d_cic1 = nullptr;
+  int cic_blocks_per_cu = 0;
+  DevBuf s_cic_in, s_cic_out;
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
   int band_blocks_per_cu[3] = {0, 0, 0};
@@ -282,6 +286,10 @@ void uc_destroy(uc_ctx* c) {
   if (c->d_tab1) (void)hipFree(c->d_tab1);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_aux) (void)hipFree(c->d_aux);
+  if (c->d_cic4) (void)hipFree(c->d_cic4);
+  if (c->d_cic1) (void)hipFree(c->d_cic1);
+  c->s_cic_in.release();
+  c->s_cic_out.release();
   c->s_frames.release();
   c->s_mm.release();
   c->s_sym.release();
@@ -483,6 +491,62 @@ copy_back:
       e = hipMemcpyAsync(stats, d_stats, n_frames * (size_t)spf * sizeof(uc_stats), hipMemcpyDeviceToHost, stream);
       if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(stats)");
     }
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  }
+  return 0;
+}
+
+int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t* words_out, void* hip_stream) {
+  if (!c) return fail(-EINVAL, "uc_dfsdm_sinc5: NULL ctx");
+  if (n_words <= 4) return 0;
+  if (!pdm_words || !words_out) return fail(-EINVAL, "uc_dfsdm_sinc5: NULL buffer");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (!c->d_cic4) {
+    std::vector<int32_t> t4, t1;
+    uc::build_sinc5_tables(t4, t1);
+    int rc = upload((void**)&c->d_cic4, t4.data(), t4.size() * sizeof(int32_t));
+    if (!rc) rc = upload((void**)&c->d_cic1, t1.data(), t1.size() * sizeof(int32_t));
+    if (rc) return rc;
+  }
+  const size_t n_out = n_words - 4;
+  const uint32_t* d_in = pdm_words;
+  if (!is_device_ptr(pdm_words)) {
+    int rc = c->s_cic_in.ensure(n_words * 4);
+    if (rc) return rc;
+    e = hipMemcpyAsync(c->s_cic_in.p, pdm_words, n_words * 4, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(pdm)");
+    d_in = (const uint32_t*)c->s_cic_in.p;
+  } else if (((uintptr_t)pdm_words & 15u) != 0) {
+    return fail(-EINVAL, "uc_dfsdm_sinc5: a device `pdm_words` pointer must be 16-byte aligned");
+  }
+  int32_t* d_out = words_out;
+  const bool host_out = !is_device_ptr(words_out);
+  if (host_out) {
+    int rc = c->s_cic_out.ensure(n_out * 4);
+    if (rc) return rc;
+    d_out = (int32_t*)c->s_cic_out.p;
+  } else if (((uintptr_t)words_out & 15u) != 0) {
+    return fail(-EINVAL, "uc_dfsdm_sinc5: a device `words_out` pointer must be 16-byte aligned");
+  }
+  uc::CicParams cp;
+  cp.pdm = d_in;
+  cp.n_words = n_words;
+  cp.out = d_out;
+  cp.t4 = c->d_cic4;
+  cp.t1 = c->d_cic1;
+  if (c->cic_blocks_per_cu == 0) c->cic_blocks_per_cu = uc::sinc5_max_blocks_per_cu();
+  size_t grid = (size_t)c->num_cu * (size_t)c->cic_blocks_per_cu;
+  if (c->grid_override > 0) grid = (size_t)c->grid_override;
+  const size_t need = (n_out + uc::sinc5_tile_outputs() - 1) / uc::sinc5_tile_outputs();
+  if (grid > need) grid = need;
+  int lrc = uc::launch_sinc5(cp, (int)grid, stream);
+  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "sinc5 kernel launch");
+  if (host_out) {
+    e = hipMemcpyAsync(words_out, d_out, n_out * 4, hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(words_out)");
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
   }

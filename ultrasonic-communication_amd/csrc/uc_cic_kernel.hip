@@ -1,0 +1,126 @@
+// uc_cic_kernel.hip -- the DFSDM front end as a kernel: sinc^5, decimate by 32, of a 1-bit PDM stream.
+//
+// Models the peripheral configured in receiver/Src/dfsdm.c:59-61 (SINC5, Oversampling 32,
+// IntOversampling 1), :69 (bit clock 80 MHz / 32), :78 (RightBitShift 2) whose output words
+// (24-bit result in bits 31:8) the ISR hands to the DSP (receiver/Src/main.c:659-668).
+// Integer arithmetic, bit-exact against oracle/uc_oracle.c::uco_dfsdm_sinc5.
+//
+// Design (MI355X): one output word per input word (32 PDM bits), 4 B in + 4 B out: HBM-bound
+// integer work.  y[m] = sum_j h[j] s[32 m + 31 - j] (156 taps, s = +-1) touches words m-4 .. m.
+// A lane owns FOUR consecutive words (one 16-byte load).  For each of its words it looks up, per byte,
+// the contribution of that byte to each of the five outputs the word takes part in (a 20 KiB
+// table in LDS: [byte position][byte value] -> 5 partial sums, read as one b128 + one b32), adds
+// them up, and passes the four partial sums that belong to the NEXT lane's outputs along with one
+// DPP wave shift each.  A wave covers 256 words and stores 252 outputs (lane 0 only feeds lane 1:
+// its own outputs belong to the previous tile), coalesced 16-byte stores.
+#include "uc_kernels.hpp"
+
+namespace uc {
+
+namespace {
+
+constexpr int TC = 256;          // 4 waves
+constexpr int kTileWords = 256;  // words one wave loads
+constexpr int kTileOut = 252;    // outputs one wave stores
+
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr int kRsrcFlags = 0x00020000;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+}
+
+// value of lane - 1 (lane 0 receives 0)
+__device__ __forceinline__ int from_prev_lane(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+}
+
+__global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
+  __shared__ v4i t4[1024];  // [byte position b][value v] -> contributions to outputs m, m+1, m+2, m+3 of word m
+  __shared__ int t1[1024];  //                           -> contribution to output m+4
+  for (int i = threadIdx.x; i < 1024; i += TC) {
+    t4[i] = reinterpret_cast<const v4i*>(p.t4)[i];
+    t1[i] = p.t1[i];
+  }
+  __syncthreads();
+
+  const int lane = threadIdx.x & 63;
+  const size_t n_out = p.n_words - 4;
+  const size_t tiles = (n_out + kTileOut - 1) / kTileOut;
+  const size_t wave0 = (size_t)blockIdx.x * (TC / 64) + (threadIdx.x >> 6);
+  const size_t nwaves = (size_t)gridDim.x * (TC / 64);
+
+  for (size_t tile = wave0; tile < tiles; tile += nwaves) {
+    const size_t base = tile * kTileOut;  // first word of the tile = first output of the tile + 4 - 4
+    // words base + 4 lane .. + 3; past the end of the buffer the resource returns 0 (those outputs are not stored)
+    const size_t left = p.n_words - base;
+    const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.pdm + base, recs * 4);
+    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, 0);
+    const unsigned wd[4] = {w.x, w.y, w.z, w.w};
+    int g[4][5];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int idx = b * 256 + (int)((wd[c] >> (8 * b)) & 255u);
+        const v4i q = t4[idx];
+        a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
+        a4 += t1[idx];
+      }
+      g[c][0] = a0; g[c][1] = a1; g[c][2] = a2; g[c][3] = a3; g[c][4] = a4;
+    }
+    // sums over this lane's own words, and what its words add to the next lane's four outputs
+    int y0 = g[0][0];
+    int y1 = g[1][0] + g[0][1];
+    int y2 = g[2][0] + g[1][1] + g[0][2];
+    int y3 = g[3][0] + g[2][1] + g[1][2] + g[0][3];
+    const int c0 = g[3][1] + g[2][2] + g[1][3] + g[0][4];
+    const int c1 = g[3][2] + g[2][3] + g[1][4];
+    const int c2 = g[3][3] + g[2][4];
+    const int c3 = g[3][4];
+    y0 += from_prev_lane(c0);
+    y1 += from_prev_lane(c1);
+    y2 += from_prev_lane(c2);
+    y3 += from_prev_lane(c3);
+    // B = sum of the taps that met a 1 bit: y = 2 B - 2^25; result = clip(y >> 2) << 8
+    auto word = [](int bsum) {
+      int v = (bsum - (1 << 24)) >> 1;
+      v = v > 8388607 ? 8388607 : v;
+      v = v < -8388608 ? -8388608 : v;
+      return v * 256;
+    };
+    if (lane > 0) {
+      // outputs base + 4 (lane - 1) .. + 3
+      const size_t o = base + 4 * (size_t)(lane - 1);
+      if (o + 3 < n_out) {
+        v4i r;
+        r.x = word(y0); r.y = word(y1); r.z = word(y2); r.w = word(y3);
+        *reinterpret_cast<v4i*>(p.out + o) = r;
+      } else {
+        if (o < n_out) p.out[o] = word(y0);
+        if (o + 1 < n_out) p.out[o + 1] = word(y1);
+        if (o + 2 < n_out) p.out[o + 2] = word(y2);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_sinc5(const CicParams& p, int grid, hipStream_t stream) {
+  if (grid <= 0 || p.n_words <= 4) return (int)hipSuccess;
+  hipLaunchKernelGGL(sinc5_kernel, dim3((unsigned)grid), dim3((unsigned)TC), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+int sinc5_max_blocks_per_cu() {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel, TC, 0) != hipSuccess || nb <= 0) nb = 4;
+  return nb;
+}
+
+int sinc5_tile_outputs() { return kTileOut * (TC / 64); }
+
+}  // namespace uc

@@ -94,4 +94,16 @@ struct StreamParams {
 int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream);
 int stream_max_blocks_per_cu(int dtype, int decim);
 
+// DFSDM model: sinc^5, decimate by 32, of a packed 1-bit PDM stream (receiver/Src/dfsdm.c:59-61,69,78).
+struct CicParams {
+  const uint32_t* pdm;   // device, 16-byte aligned; bit t of the stream = bit (t & 31) of word t >> 5
+  size_t n_words;        // the first 4 words are history
+  int32_t* out;          // device, 16-byte aligned, n_words - 4 words: 24-bit result in bits 31:8
+  const int32_t* t4;     // [4][256][4] per-byte contributions to outputs m .. m+3 of word m
+  const int32_t* t1;     // [4][256]    per-byte contribution to output m+4
+};
+int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
+int sinc5_max_blocks_per_cu();
+int sinc5_tile_outputs();
+
 }  // namespace uc

@@ -182,6 +182,29 @@ void packed_rfft_double(const std::vector<float>& in, std::vector<float>& packed
   }
 }
 
+void build_sinc5_tables(std::vector<int32_t>& t4, std::vector<int32_t>& t1) {
+  std::vector<long long> h(1, 1);
+  for (int rep = 0; rep < 5; rep++) {  // h <- h * boxcar(32)
+    std::vector<long long> o(h.size() + 31, 0);
+    for (size_t i = 0; i < h.size(); i++)
+      for (int k = 0; k < 32; k++) o[i + k] += h[i];
+    h.swap(o);
+  }  // 156 taps, sum 2^25
+  t4.assign(4 * 256 * 4, 0);
+  t1.assign(4 * 256, 0);
+  for (int w = 0; w < 5; w++)
+    for (int b = 0; b < 4; b++)
+      for (int v = 0; v < 256; v++) {
+        long long acc = 0;
+        for (int k = 0; k < 8; k++) {
+          const int j = 32 * w + 31 - (8 * b + k);
+          if (((v >> k) & 1) && j >= 0 && j < (int)h.size()) acc += h[(size_t)j];
+        }
+        if (w < 4) t4[(size_t)(b * 256 + v) * 4 + w] = (int32_t)acc;
+        else t1[(size_t)(b * 256 + v)] = (int32_t)acc;
+      }
+}
+
 int build_stream_tables(const uc_config& cfg, StreamTables& out) {
   const uint32_t n = cfg.n;
   const uint32_t D = cfg.decim ? cfg.decim : 8;

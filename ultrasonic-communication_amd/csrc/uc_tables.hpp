@@ -44,6 +44,11 @@ struct StreamTables {
 };
 int build_stream_tables(const uc_config& cfg, StreamTables& out);
 
+// sinc^5 / 32 of a +-1 bit stream as per-byte lookup tables (uc_cic_kernel.hip):
+// t4[(b*256+v)*4 + w] (w < 4) and t1[b*256+v] (w = 4) = sum_k bit_k(v) * h[32 w + 31 - (8 b + k)],
+// h = the 156-tap five-fold convolution of a 32-sample boxcar
+void build_sinc5_tables(std::vector<int32_t>& t4, std::vector<int32_t>& t1);
+
 // returns 0 or a negative errno
 int build_tables(const uc_config& cfg, Tables& out);
 

@@ -30,7 +30,7 @@ FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP = 1, 2, 8
 EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", "uc_destroy",
            "uc_process_frame", "uc_process_batch", "uc_stats_per_frame", "uc_iq_halo",
            "uc_get_table", "uc_get_windows", "uc_idx2freq", "uc_receive_stream",
-           "uc_stream_geometry", "uc_process_stream"]
+           "uc_stream_geometry", "uc_process_stream", "uc_dfsdm_sinc5"]
 
 
 class Config(C.Structure):
@@ -103,6 +103,7 @@ def lib():
                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.uc_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
     L.uc_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.uc_dfsdm_sinc5.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -233,6 +234,28 @@ class Engine:
                                        pk.ctypes.data_as(C.c_void_p) if pk is not None else None, None),
                "uc_process_stream")
         return comp, pk
+
+    def dfsdm(self, pdm_words, out=None, stream=None):
+        """uc_dfsdm_sinc5: packed 1-bit PDM words (first 4 = history) -> int32 DFSDM words (n - 4).
+        numpy uint32 in -> numpy int32 out; torch int32 device tensor in -> torch int32 out (asynchronous)."""
+        if _is_torch(pdm_words):
+            import torch
+            t = pdm_words
+            if not t.is_contiguous() or t.dtype != torch.int32 or t.device.type != "cuda":
+                raise ValueError("pdm_words must be a contiguous int32 GPU tensor (bit pattern of the uint32 words)")
+            n = t.numel()
+            if out is None:
+                out = torch.empty(max(n - 4, 0), dtype=torch.int32, device=t.device)
+            if stream is None:
+                stream = torch.cuda.current_stream(t.device).cuda_stream
+            _check(lib().uc_dfsdm_sinc5(self._h, C.c_void_p(t.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                        C.c_void_p(stream)), "uc_dfsdm_sinc5")
+            return out
+        a = np.ascontiguousarray(pdm_words, np.uint32).reshape(-1)
+        res = np.zeros(max(a.size - 4, 0), np.int32)
+        _check(lib().uc_dfsdm_sinc5(self._h, a.ctypes.data_as(C.c_void_p), a.size, res.ctypes.data_as(C.c_void_p),
+                                    None), "uc_dfsdm_sinc5")
+        return res
 
     def process_frame(self, pcm, mag_mean=1.0):
         """uc_process_frame: n int32 DFSDM words -> (symbol, stats[spf])."""
