@@ -208,7 +208,10 @@ def main():
         traffic = None
         try:
             import glob
-            tf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json")))[-1]
+            # the band kernel's own passes are named rNN_vM_hbm_traffic.json (other kernels carry their name)
+            import re
+            tf = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))
+                        if re.fullmatch(r"r\d+_v\d+_hbm_traffic\.json", os.path.basename(f)))[-1]
             traffic = json.load(open(tf))["hbm_bytes_per_frame"] * nf
         except Exception:
             traffic = None

@@ -3,7 +3,7 @@
 // Models the peripheral configured in receiver/Src/dfsdm.c:59-61 (SINC5, Oversampling 32,
 // IntOversampling 1), :69 (bit clock 80 MHz / 32), :78 (RightBitShift 2) whose output words
 // (24-bit result in bits 31:8) the ISR hands to the DSP (receiver/Src/main.c:659-668).
-// Integer arithmetic, bit-exact against oracle/uc_oracle.c::uco_dfsdm_sinc5.
+// Integer arithmetic: the result is exact (the parity tests demand bit equality with the CPU restatement).
 //
 // Design (MI355X): one output word per input word (32 PDM bits), 4 B in + 4 B out: HBM-bound
 // integer work.  y[m] = sum_j h[j] s[32 m + 31 - j] (156 taps, s = +-1) touches words m-4 .. m.
