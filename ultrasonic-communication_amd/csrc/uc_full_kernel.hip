@@ -14,10 +14,12 @@
 // spectrum is multiplied by H/N in registers and -- because a Stockham first
 // pass consumes exactly the stride-256 octets the forward last pass produced --
 // the inverse transform (8 x 16 x 16) starts in the same registers: 4 LDS
-// exchanges per pair.  Inverse butterflies reuse the forward ones through
-// IDFT_R[k] = DFT_R[-k mod R] with conjugated twiddles.
-// HBM traffic: 2 x 8 KiB in, 2 x 32 B stats out per pair; H/N (16 KiB), Hann and
-// twiddles come from L2.
+// exchanges per pair, ping-ponging between two tiles (one barrier each).
+// Inverse butterflies reuse the forward ones through IDFT_R[k] = DFT_R[-k mod R]
+// with conjugated twiddles.  The next pair is prefetched a whole pair time ahead
+// and nothing else is loaded from memory inside the loop (Hann, H/N and the
+// twiddle seeds are register-resident, the small twiddle tables sit in LDS).
+// HBM traffic: 2 x 8 KiB in, 2 x 32 B stats out per pair.
 #include "uc_kernels.hpp"
 #include "uc_pk.hpp"
 
@@ -29,8 +31,10 @@ constexpr int T = kBandThreads;  // 128
 #ifndef UC_COMPRESS_WAVES
 #define UC_COMPRESS_WAVES 2
 #endif
-constexpr int kRedOff = 2 * kN;  // floats: per-wave reduction results after the tile
-constexpr int kLdsFloats = kRedOff + 16;
+constexpr int kRedOff = 4 * kN;  // floats: per-wave reduction results after the two tiles
+constexpr int kTw2Off = kRedOff + 16;
+constexpr int kTwBOff = kTw2Off + 2 * 256;
+constexpr int kLdsFloats = kTwBOff + 2 * 128;
 
 constexpr float kSqrtHalfF = 0.70710678118654752440f;
 constexpr float kCos8 = 0.92387953251128675613f;
@@ -74,8 +78,8 @@ __device__ __forceinline__ int wave_min_u32(int v) {
 }
 
 template <int DTYPE>
-__device__ __forceinline__ float cvt1(float raw) {
-  if (DTYPE == UC_DTYPE_I32) return (float)__float_as_int(raw);
+__device__ __forceinline__ v2f cvt_pair(v2f raw) {
+  if (DTYPE == UC_DTYPE_I32) return mkv((float)__float_as_int(raw.x), (float)__float_as_int(raw.y));
   return raw;
 }
 
@@ -110,36 +114,52 @@ __device__ __forceinline__ void frame_max(const v2f (&y)[16], int j, int lane, f
 template <int DTYPE>
 __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const FullParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  float* ta = lds;             // the transforms ping-pong between two tiles: one barrier per exchange
+  float* tb = lds + 2 * kN;
   float* red = lds + kRedOff;
+  float* tw2t = lds + kTw2Off;  // W_256^(t k), t < 16, k < 16: forward pass 2
+  float* twBt = lds + kTwBOff;  // W_128^(t k), t < 16, k < 8: inverse pass B
 
   const int j = threadIdx.x;
   const int lane = j & 63;
   const int wave = j >> 6;
 
   const size_t npairs = (p.n_frames + 1) / 2;
-  const size_t chunk = (npairs + gridDim.x - 1) / gridDim.x;
-  size_t q = (size_t)blockIdx.x * chunk;
-  if (q >= npairs) return;
-  const size_t qend = (q + chunk < npairs) ? q + chunk : npairs;
+  // balanced contiguous partition of the pairs
+  const size_t base = npairs / gridDim.x, rem = npairs % gridDim.x;
+  const size_t w_ = blockIdx.x;
+  size_t q = w_ * base + (w_ < rem ? w_ : rem);
+  const size_t qend = q + base + (w_ < rem ? 1 : 0);
+  if (q >= qend) return;
 
   const __amdgpu_buffer_rsrc_t rs_hn = make_rsrc(p.hn, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
   const int voff8 = j * 8, voff4 = j * 4;
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
 
-  // resident per-thread constants
-  float hw[16];  // symmetric Hann at this thread's samples
+  // Everything the loop needs besides the frames is resident (vector loads return in order: a table
+  // load issued behind the next pair's prefetch would wait for it): Hann and H/N at this thread's
+  // positions and three pass-3/C twiddle seeds in registers, the pass-2 / pass-B twiddles in LDS.
+  v2f hw[8];  // symmetric Hann at this thread's samples j + 128 t, two per register pair
   {
     const __amdgpu_buffer_rsrc_t rs_h = make_rsrc(p.hann, kN * 4);
 #pragma unroll
-    for (int t = 0; t < 16; t++) hw[t] = buf_ld32(rs_h, voff4, T * 4 * t);
+    for (int m = 0; m < 8; m++) hw[m] = mkv(buf_ld32(rs_h, voff4, T * 4 * (2 * m)), buf_ld32(rs_h, voff4, T * 4 * (2 * m + 1)));
   }
-  v2f tw2[16];  // forward pass 2: W_256^(t k), k = j & 15
+  v2f hres[2][8];  // H[k]/N at this thread's bins k = j + 128 h + 256 t
 #pragma unroll
-  for (int t = 1; t < 16; t++) tw2[t] = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN - 1)) * 8, 0);
+  for (int h = 0; h < 2; h++)
+#pragma unroll
+    for (int t = 0; t < 8; t++) hres[h][t] = buf_ld64(rs_hn, voff8 + T * 8 * h, 256 * 8 * t);
   const v2f tw3_1 = buf_ld64(rs_tw, (j & (kN - 1)) * 8, 0);        // W_2048^j
   const v2f tw3_2 = buf_ld64(rs_tw, ((2 * j) & (kN - 1)) * 8, 0);  // W_2048^2j
   const v2f tw3_4 = buf_ld64(rs_tw, ((4 * j) & (kN - 1)) * 8, 0);  // W_2048^4j
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int e = j + T * r;  // t = e >> 4, k = e & 15
+    lds_st(tw2t, e, buf_ld64(rs_tw, ((8 * (e >> 4) * (e & 15)) & (kN - 1)) * 8, 0));
+  }
+  lds_st(twBt, j, buf_ld64(rs_tw, ((16 * (j >> 3) * (j & 7)) & (kN - 1)) * 8, 0));  // t = j >> 3, k = j & 7
 
   // LDS addresses (complex units)
   const int s1 = j & 15;
@@ -156,53 +176,83 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
 
   const bool has_mm = p.mag_mean != nullptr;
 
+  // raw words of the pair: sample j + 128 t of frame 2q in the low, of frame 2q+1 in the high half
+  v2f xp[16];
+  auto load_pair = [&](size_t u) {
+    const bool hb = 2 * u + 1 < p.n_frames;  // a ragged last pair: frame b reads as zeros
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u) * p.stride * 4, kN * 4);
+    const __amdgpu_buffer_rsrc_t rb =
+        make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u + (hb ? 1 : 0)) * p.stride * 4, hb ? kN * 4 : 0);
+#pragma unroll
+    for (int t = 0; t < 16; t++) xp[t] = mkv(buf_ld32(ra, voff4, T * 4 * t), buf_ld32(rb, voff4, T * 4 * t));
+  };
+  load_pair(q);
+
+  // result of one pair: merged by thread 0/1 after the NEXT barrier (red is rewritten three barriers later)
+  auto publish = [&](size_t qq) {
+    const bool hb = 2 * qq + 1 < p.n_frames;
+    if (j < 2 && (j == 0 || hb) && p.stats) {
+      // merge the two waves: value, then smallest index; a NaN partial only survives
+      // if element 0 was NaN (wave 0 reports it with index 0)
+      const float v0 = red[2 * j], v1 = red[4 + 2 * j];
+      const int i0 = __float_as_int(red[2 * j + 1]), i1 = __float_as_int(red[4 + 2 * j + 1]);
+      float mx;
+      int mi;
+      if (v0 != v0) { mx = v0; mi = i0; }
+      else if (v1 > v0 || (v1 == v0 && i1 < i0)) { mx = v1; mi = i1; }
+      else { mx = v0; mi = i0; }
+      const size_t ff = 2 * qq + j;
+      const float mm = has_mm ? p.mag_mean[2 * ff] : p.mag_mean_scalar;
+      float4 a, bq;
+      a.x = mx; a.y = 0.0f; a.z = mx; a.w = __int_as_float(mi);
+      bq.x = __int_as_float(0); bq.y = __int_as_float(mi); bq.z = mm; bq.w = (mx - mm) / mm;
+      float4* d = reinterpret_cast<float4*>(p.stats + ff);
+      d[0] = a;
+      d[1] = bq;
+    }
+    if (j < 2 && (j == 0 || hb) && p.symbols) p.symbols[2 * qq + j] = (uint8_t)UC_SYM_NONE;
+  };
+
+  bool pending = false;
   for (; q < qend; q++) {
     int s1v = s1;
     v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
     asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
-    const size_t fa = 2 * q, fb = 2 * q + 1;
-    const bool has_b = fb < p.n_frames;
 
-    // ---- load both frames, window, forward pass 1 ----------------------------
+    // ---- window, forward pass 1 (registers -> tile A) -------------------------------
     v2f v[16];
-    {
-      const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const char*>(p.frames) + fa * p.stride * 4, kN * 4);
-      const __amdgpu_buffer_rsrc_t rb =
-          make_rsrc(reinterpret_cast<const char*>(p.frames) + (has_b ? fb : fa) * p.stride * 4, has_b ? kN * 4 : 0);
 #pragma unroll
-      for (int t = 0; t < 16; t++) {
-        // hann * x, one float32 rounding, as windowing() does (chirp.c:47-50)
-        const float xa = cvt1<DTYPE>(buf_ld32(ra, voff4, T * 4 * t));
-        const float xb = cvt1<DTYPE>(buf_ld32(rb, voff4, T * 4 * t));  // zero records -> 0.0 when there is no frame b
-        v[t] = mkv(xa * hw[t], xb * hw[t]);
-      }
+    for (int m = 0; m < 8; m++) {
+      // hann * x, one float32 rounding, as windowing() does (chirp.c:47-50)
+      v[2 * m] = pk_scale_lo(cvt_pair<DTYPE>(xp[2 * m]), hw[m]);
+      v[2 * m + 1] = pk_scale_hi(cvt_pair<DTYPE>(xp[2 * m + 1]), hw[m]);
     }
+    if (q + 1 < qend) load_pair(q + 1);  // a whole pair time ahead
     pk_dft16(v, K, H);
 #pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    for (int t = 0; t < 16; t++) lds_st(ta, wr1 + (t ^ s1v), v[pk_slot16(t)]);
     __syncthreads();
+    if (pending) publish(q - 1);
 
-    // ---- forward pass 2 ---------------------------------------------------------
+    // ---- forward pass 2 (A -> B) ----------------------------------------------------
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(ta, ((t & 1) ? rd1o : rd1e) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], tw2[t]);
+    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2t, 16 * t + (j & 15)));
     pk_dft16(v, K, H);
-    __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[pk_slot16(t)]);
+    for (int t = 0; t < 16; t++) lds_st(tb, wr2 + 16 * t, v[pk_slot16(t)]);
     __syncthreads();
 
-    // ---- forward pass 3 (full radix-8), x H/N, inverse pass A (radix-8) --------
+    // ---- forward pass 3 (full radix-8), x H/N, inverse pass A (radix-8) (B -> A) ----
     // butterfly b = j (h = 0) and b = j + 128 (h = 1): X[b + 256 t], t = 0..7
-    v2f y8[2][8];
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int b = j + T * h;
       v2f u[8];
 #pragma unroll
-      for (int t = 0; t < 8; t++) u[t] = lds_ld(lds, b + 256 * t);
+      for (int t = 0; t < 8; t++) u[t] = lds_ld(tb, b + 256 * t);
       __builtin_amdgcn_sched_barrier(0);
       v2f w[8];
       if (h == 0) {
@@ -219,53 +269,51 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
       pk_dft8(u, H);
       // spectrum bin k = b + 256 t sits in u[slot8(t)]: multiply by H_down[k] / N
 #pragma unroll
-      for (int t = 0; t < 8; t++) {
-        const v2f hk = buf_ld64(rs_hn, voff8 + T * 8 * h, 256 * 8 * t);
-        u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hk);
-      }
+      for (int t = 0; t < 8; t++) u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hres[h][t]);
       // inverse radix-8, Ns = 1 (no twiddles): inputs in natural t order
       v2f g[8];
 #pragma unroll
       for (int t = 0; t < 8; t++) g[t] = u[pk_slot8(t)];
       pk_dft8(g, H);
-      // IDFT8[t] = DFT8[(8 - t) & 7]
+      // IDFT8[t] = DFT8[(8 - t) & 7]; inverse exchange A: element 8 b + t, swizzled phys = o ^ ((o >> 4) & 7)
 #pragma unroll
-      for (int t = 0; t < 8; t++) y8[h][t] = g[pk_slot8((8 - t) & 7)];
-    }
-    __syncthreads();  // all forward pass-3 reads done before the tile is overwritten
-    // inverse exchange A: element 8 b + t, swizzled phys = o ^ ((o >> 4) & 7)
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int b = j + T * h;
-#pragma unroll
-      for (int t = 0; t < 8; t++) lds_st(lds, 8 * b + (t ^ ((b >> 1) & 7)), y8[h][t]);
+      for (int t = 0; t < 8; t++) lds_st(ta, 8 * b + (t ^ ((b >> 1) & 7)), g[pk_slot8((8 - t) & 7)]);
     }
     __syncthreads();
 
-    // ---- inverse pass B: radix-16, Ns = 8, conj twiddles W_128^(t k), k = j & 7
+    // ---- inverse pass B: radix-16, Ns = 8, conj twiddles W_128^(t k), k = j & 7 (A -> B)
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rdA + 128 * t);
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(ta, rdA + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 1; t < 16; t++) {
-      const v2f w = buf_ld64(rs_tw, ((16 * t * (j & 7)) & (kN - 1)) * 8, 0);
-      v[t] = pk_cmulc(v[t], w);
-    }
+    for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], lds_ld(twBt, 8 * t + (j & 7)));
     pk_dft16(v, K, H);
-    __syncthreads();
     // output t of the inverse = forward output (16 - t) & 15; element (j>>3)*128 + (j&7) + 8 t
 #pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(lds, ((t & 1) ? wrBo : wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
+    for (int t = 0; t < 16; t++) lds_st(tb, ((t & 1) ? wrBo : wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
     __syncthreads();
 
-    // ---- inverse pass C: radix-16, Ns = 128, conj twiddles W_2048^(t j) ---------
+    // ---- inverse pass C: radix-16, Ns = 128, conj twiddles W_2048^(t j) (B -> registers)
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rdBo : rdBe) + 128 * t);
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tb, ((t & 1) ? rdBo : rdBe) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
+    {
+      // W_2048^(t j), t = 1..15, as products of the three resident powers (at most three factors deep)
+      v2f w[16];
+      w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = pk_cmul(t3c, t3c);
+      w[3] = pk_cmul(w[1], w[2]);
+      w[5] = pk_cmul(w[1], w[4]);
+      w[6] = pk_cmul(w[2], w[4]);
+      w[9] = pk_cmul(w[1], w[8]);
+      w[10] = pk_cmul(w[2], w[8]);
+      w[12] = pk_cmul(w[4], w[8]);
+      w[7] = pk_cmul(w[3], w[4]);
+      w[11] = pk_cmul(w[3], w[8]);
+      w[13] = pk_cmul(w[5], w[8]);
+      w[14] = pk_cmul(w[6], w[8]);
+      w[15] = pk_cmul(w[7], w[8]);
 #pragma unroll
-    for (int t = 1; t < 16; t++) {
-      const v2f w = buf_ld64(rs_tw, ((t * j) & (kN - 1)) * 8, 0);
-      v[t] = pk_cmulc(v[t], w);
+      for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], w[t]);
     }
     pk_dft16(v, K, H);
     // y[j + 128 t] = inverse output t = v[slot16((16 - t) & 15)]; re = frame a, im = frame b
@@ -284,28 +332,10 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
       red[4 * wave + 2] = vb;
       red[4 * wave + 3] = __int_as_float(ib);
     }
-    __syncthreads();  // also frees the tile for the next pair
-    if (j < 2 && (j == 0 || has_b) && p.stats) {
-      // merge the two waves: value, then smallest index; a NaN partial only survives
-      // if element 0 was NaN (wave 0 reports it with index 0)
-      const float v0 = red[2 * j], v1 = red[4 + 2 * j];
-      const int i0 = __float_as_int(red[2 * j + 1]), i1 = __float_as_int(red[4 + 2 * j + 1]);
-      float mx;
-      int mi;
-      if (v0 != v0) { mx = v0; mi = i0; }
-      else if (v1 > v0 || (v1 == v0 && i1 < i0)) { mx = v1; mi = i1; }
-      else { mx = v0; mi = i0; }
-      const size_t ff = 2 * q + j;
-      const float mm = has_mm ? p.mag_mean[2 * ff] : p.mag_mean_scalar;
-      float4 a, bq;
-      a.x = mx; a.y = 0.0f; a.z = mx; a.w = __int_as_float(mi);
-      bq.x = __int_as_float(0); bq.y = __int_as_float(mi); bq.z = mm; bq.w = (mx - mm) / mm;
-      float4* d = reinterpret_cast<float4*>(p.stats + ff);
-      d[0] = a;
-      d[1] = bq;
-    }
-    if (j < 2 && (j == 0 || has_b) && p.symbols) p.symbols[2 * q + j] = (uint8_t)UC_SYM_NONE;
+    pending = true;
   }
+  __syncthreads();
+  if (pending) publish(qend - 1);
 }
 
 }  // namespace
