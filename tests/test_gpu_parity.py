@@ -283,6 +283,93 @@ def test_dechirp_down_frame_pairs_ragged_strided_per_frame_floor(uchirp, n_frame
             assert (np.abs(back[fld].astype(np.float64) - g[fld]) / scale).max() <= MAG_TOL
 
 
+def _random_configs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        fs = float(rng.choice([62500.0, 78125.0, 100000.0, 125000.0]))
+        f0 = float(rng.integers(8000, 20000))
+        bwid = float(rng.integers(300, 4200))
+        f1 = f0 + bwid
+        if f1 >= 0.45 * fs:
+            continue
+        variant = int(rng.choice([uco.RX_REAL, uco.SYNC_CPLX, uco.DECHIRP_DOWN]))
+        bw = int(bwid * 2048 / fs)
+        bw2 = bw * (8 if variant == uco.DECHIRP_DOWN else 2)
+        if bw2 < 2 or bw2 > 191:
+            continue
+        cfg = dict(fs=fs, f0=f0, f1=f1, phase_deg=float(rng.choice([-90.0, 0.0, 37.5])),
+                   time_frame=float(rng.choice([0.0205, 2048 / fs, 0.018])),
+                   flags=int(rng.choice([0, uco.FLAG_LIBM_TRIG, uco.FLAG_TRUE_DC, uco.FLAG_LIBM_TRIG | uco.FLAG_TRUE_DC])),
+                   snr_threshold=float(rng.choice([2.0, 0.5, 8.0])), mag_mean=float(rng.choice([500.0, 1000.0, 4000.0])))
+        if variant == uco.DECHIRP_DOWN:
+            cfg["time_frame"] = 0.0
+        out.append((variant, cfg))
+    return out
+
+
+@pytest.mark.parametrize("case", range(16))
+def test_randomised_configurations(uchirp, case):
+    """The reference's compile-time constants (fs, F0, F1, TIME_FRAME, phase, threshold) as run-time
+    configuration: for random draws the product's tables equal the oracle's bit for bit and the
+    per-frame results agree to the usual bars."""
+    variant, cfg = _random_configs(16, seed=2024)[case]
+    o = uco.Oracle(variant, **cfg)
+    e = uchirp.Engine(variant, **cfg)
+    assert (e.bandwidth, e.bandwidth2, e.idx_left_zero) == (o.bandwidth, o.bandwidth2, o.idx_left_zero)
+    for tid in (uco.TABLE_UP, uco.TABLE_DOWN, uco.TABLE_HANN):
+        assert np.array_equal(e.table(tid).view(np.uint32), o.table(tid).view(np.uint32)), (cfg, tid)
+    for idx in (0, 1, 3, 77, 1023, 1024, 1025, 2047):
+        assert e.idx2freq(idx) == o.idx2freq(idx)
+    frames, bits = synth.make_frames(96, seed=100 + case, snr_db=-3.0, fs=cfg["fs"], f0=cfg["f0"], f1=cfg["f1"],
+                                     sweep_time=cfg["time_frame"] or None)
+    rs, rst = o.process(frames)
+    gs, gst = e.process(frames)
+    for h in range(o.spf):
+        r, g = rst[:, h], gst[:, h]
+        scale = np.maximum(np.maximum(r["mag_max_left"], r["mag_max_right"]).astype(np.float64), 1e-30)
+        for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+            assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL, (cfg, fld)
+        same = (g["max_freq_right"] == r["max_freq_right"]) & (g["max_freq_left"] == r["max_freq_left"])
+        assert same.mean() >= 0.95, cfg
+    if o.spf == 2:
+        su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+        thr = cfg["snr_threshold"]
+        margin = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30)
+        near_thr = (np.abs(su - thr) < 1e-3 * np.abs(thr)) | (np.abs(sd - thr) < 1e-3 * np.abs(thr))
+        clear = (margin >= MARGIN) & ~near_thr
+        assert np.array_equal(gs[clear], rs[clear]), cfg
+    else:
+        assert (gs == uchirp.SYM_NONE).all()
+
+
+def test_two_contexts_on_two_streams_do_not_interfere(uchirp):
+    """Distinct contexts are independent (include/uchirp.h): two variants enqueued back to back on two HIP
+    streams over the same input give what each gives alone."""
+    import torch
+    dev = torch.device("cuda:0")
+    frames, _ = synth.make_frames(4096, seed=77, snr_db=-5.0)
+    fr = torch.from_numpy(frames).to(dev)
+    ea = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+    eb = uchirp.Engine(uchirp.SYNC_CPLX, mag_mean=1000.0)
+    ra, sa = ea.process(fr)
+    rb, sb = eb.process(fr)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for _ in range(4):
+        with torch.cuda.stream(s1):
+            a = ea.process(fr, stream=s1.cuda_stream)
+        with torch.cuda.stream(s2):
+            b = eb.process(fr, stream=s2.cuda_stream)
+        outs.append((a, b))
+    torch.cuda.synchronize()
+    for (a, b) in outs:
+        # (bit patterns: the int32 frequency fields of uc_stats are NaNs when read as float)
+        assert torch.equal(a[0], ra) and torch.equal(a[1].view(torch.int32), sa.view(torch.int32))
+        assert torch.equal(b[0], rb) and torch.equal(b[1].view(torch.int32), sb.view(torch.int32))
+
+
 def test_device_tensors_async_and_properties_at_scale(uchirp):
     """Size-independent properties on a large device-resident batch:
     decode == transmitted bits, exact x2 linearity, shard-invariance."""
