@@ -13,6 +13,7 @@
 // them up, and passes the four partial sums that belong to the NEXT lane's outputs along with one
 // DPP wave shift each.  A wave covers 256 words and stores 252 outputs (lane 0 only feeds lane 1:
 // its own outputs belong to the previous tile), coalesced 16-byte stores.
+#include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 
 namespace uc {
@@ -23,12 +24,7 @@ constexpr int TC = 256;          // 4 waves
 constexpr int kTileWords = 256;  // words one wave loads
 constexpr int kTileOut = 252;    // outputs one wave stores
 
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
-constexpr int kRsrcFlags = 0x00020000;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
-}
 
 // value of lane - 1 (lane 0 receives 0)
 __device__ __forceinline__ int from_prev_lane(int v) {

@@ -1,0 +1,85 @@
+// uc_dev.hpp -- device-side helpers shared by the gfx950 kernels: buffer loads, LDS accessors for
+// complex pairs, DPP wave reductions, the fixed radix-16 constants.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "uc_pk.hpp"
+#include "../../include/uchirp.h"
+
+namespace uc {
+
+constexpr float kSqrtHalfF = 0.70710678118654752440f;
+constexpr float kCos8 = 0.92387953251128675613f;   // cos(pi/8)
+constexpr float kSin8 = 0.38268343236508977173f;   // sin(pi/8)
+
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+// Buffer loads (SGPR resource + ONE VGPR byte offset + SGPR/immediate offset): the strided loads of
+// a thread share a single address register (global_load would keep a 64-bit VGPR pointer per 4 KiB
+// of span, which hipcc hoists and then spills), and reads past `bytes` return 0 without a branch.
+constexpr int kRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
+}
+// raw 32-bit word; int32 words are converted when consumed (the ISR's (float) cast, receiver/Src/main.c:664)
+__device__ __forceinline__ float buf_ld32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
+  return mkv(__uint_as_float(w.x), __uint_as_float(w.y));
+}
+__device__ __forceinline__ v4u buf_ld128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+template <int DTYPE>
+__device__ __forceinline__ v2f cvt_pair(v2f raw) {
+  if (DTYPE == UC_DTYPE_I32) return mkv((float)__float_as_int(raw.x), (float)__float_as_int(raw.y));
+  return raw;
+}
+
+// one complex value (re, im) at complex index cidx of an LDS tile
+__device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
+  return *reinterpret_cast<const v2f*>(lds + 2 * cidx);
+}
+__device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
+  *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
+}
+
+// ---- wave-wide reductions without LDS ----------------------------------------
+// Six DPP steps (row_ror 1/2/4/8 make every lane of a 16-lane row hold the row
+// result, row_bcast:15 / :31 fold the rows into lane 63) and one v_readlane.
+// hipcc does not see inside asm, so each step carries the 2 wait states a DPP
+// read of a just-written VGPR needs (s_nop 1).
+#define UC_DPP_REDUCE(OP, v)                                                                       \
+  do {                                                                                             \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));         \
+    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));         \
+  } while (0)
+
+__device__ __forceinline__ float wave_max_f32(float v) {
+  UC_DPP_REDUCE("v_max_f32_dpp", v);
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+__device__ __forceinline__ int wave_min_u32(int v) {
+  UC_DPP_REDUCE("v_min_u32_dpp", v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+__device__ __forceinline__ int wave_max_i32(int v) {
+  UC_DPP_REDUCE("v_max_i32_dpp", v);
+  return __builtin_amdgcn_readlane(v, 63);
+}
+// IEEE maxNum without the canonicalising moves fmaxf() drags in
+__device__ __forceinline__ float max_f32(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
+}  // namespace uc

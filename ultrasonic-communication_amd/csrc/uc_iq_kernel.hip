@@ -17,8 +17,8 @@
 // Only the 4*bandwidth bins the three windows look at are evaluated in the last pass.
 // This variant is compute-bound (the FIR alone is ~110 kflop per frame, as much as
 // the FFT); HBM traffic is 8 KiB + 104 B of history in, 32 B of stats out per frame.
+#include "uc_dev.hpp"
 #include "uc_kernels.hpp"
-#include "uc_pk.hpp"
 
 namespace uc {
 
@@ -31,52 +31,6 @@ constexpr int kMixPad = kMixLen + (kMixLen >> 4) + 2;  // padded image (complex 
 constexpr int kRedOff = 2 * kMixPad;     // floats
 constexpr int kLdsFloats = kRedOff + 32;
 static_assert(kMixPad >= kN, "the FFT tile aliases the mixed image");
-
-constexpr float kSqrtHalfF = 0.70710678118654752440f;
-constexpr float kCos8 = 0.92387953251128675613f;
-constexpr float kSin8 = 0.38268343236508977173f;
-
-typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-constexpr int kRsrcFlags = 0x00020000;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
-}
-__device__ __forceinline__ float buf_ld32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
-}
-__device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  return mkv(__uint_as_float(w.x), __uint_as_float(w.y));
-}
-__device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
-  return *reinterpret_cast<const v2f*>(lds + 2 * cidx);
-}
-__device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
-  *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
-}
-
-#define UC_DPP_REDUCE(OP, v)                                                                       \
-  do {                                                                                             \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));         \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));         \
-  } while (0)
-__device__ __forceinline__ float wave_max_f32(float v) {
-  UC_DPP_REDUCE("v_max_f32_dpp", v);
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ int wave_min_u32(int v) {
-  UC_DPP_REDUCE("v_min_u32_dpp", v);
-  return __builtin_amdgcn_readlane(v, 63);
-}
-__device__ __forceinline__ float max_f32(float a, float b) {
-  float r;
-  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-  return r;
-}
 
 template <int DTYPE>
 __device__ __forceinline__ float cvt1(float raw) {

@@ -25,8 +25,8 @@
 //   * |y| for the hop = 2049 - L valid outputs leaves as coalesced dword stores; the block maximum
 //     is a DPP wave reduction on squared magnitudes.
 // HBM traffic per input sample: 4 B in + 4/D B out (+ 8 B of peak record per block).
+#include "uc_dev.hpp"
 #include "uc_kernels.hpp"
-#include "uc_pk.hpp"
 
 #ifndef UC_STREAM_EXP
 #define UC_STREAM_EXP 0  // diagnostic builds: 1 = no transforms, 2 = no input loads
@@ -44,49 +44,6 @@ constexpr int kRedOff = kTileOff + 2 * kN;
 constexpr int kTw2Off = kRedOff + 16;         // W_256^(t k), t < 16, k < 16: forward pass 2
 constexpr int kTwBOff = kTw2Off + 2 * 256;    // W_128^(t k), t < 16, k < 8: inverse pass B
 constexpr int kLdsFloats = kTwBOff + 2 * 128;
-
-constexpr float kSqrtHalfF = 0.70710678118654752440f;
-constexpr float kCos8 = 0.92387953251128675613f;
-constexpr float kSin8 = 0.38268343236508977173f;
-
-typedef unsigned int v2u __attribute__((ext_vector_type(2)));
-typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-typedef float v4f __attribute__((ext_vector_type(4)));
-constexpr int kRsrcFlags = 0x00020000;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
-}
-__device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
-  return mkv(__uint_as_float(w.x), __uint_as_float(w.y));
-}
-__device__ __forceinline__ v4u buf_ld128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
-  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
-}
-__device__ __forceinline__ v2f lds_ld(const float* lds, int cidx) {
-  return *reinterpret_cast<const v2f*>(lds + 2 * cidx);
-}
-__device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
-  *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
-}
-
-#define UC_DPP_REDUCE(OP, v)                                                                       \
-  do {                                                                                             \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf" : "+v"(v));            \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf" : "+v"(v));         \
-    asm("s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf" : "+v"(v));         \
-  } while (0)
-__device__ __forceinline__ float wave_max_f32(float v) {
-  UC_DPP_REDUCE("v_max_f32_dpp", v);
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
-}
-__device__ __forceinline__ int wave_min_u32(int v) {
-  UC_DPP_REDUCE("v_min_u32_dpp", v);
-  return __builtin_amdgcn_readlane(v, 63);
-}
 
 // acc += c * x.lo / c * x.hi: complex constant (SGPR pair) times a real sample broadcast from one
 // half of a register pair -- one packed FMA for the I and the Q branch of the FIR
