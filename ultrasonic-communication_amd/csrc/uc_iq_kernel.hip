@@ -244,85 +244,183 @@ __global__ __launch_bounds__(T, 3) void iq_kernel(const IqParams p) {
 // ONE WAVE per frame -- 64 threads x 16 samples, 1024 = 16 x 8 x 8.  A single-wave workgroup
 // needs no s_barrier (LDS operations of one wave complete in order), so the whole pipeline
 // (mix, FIR, three FFT passes, windows) runs without a single cross-wave wait.
+//
+// The loop touches HBM only for the frames themselves: the next frame's 1050 samples are
+// prefetched into 17 registers a whole frame time ahead, and every table is resident (carrier
+// 17 entries, chirp*hann 16, pass-2 and pass-3 twiddles) -- vector loads return in order, so a
+// table load behind the prefetch would put the HBM latency into the arithmetic.  The FIR keeps
+// eight independent accumulators in flight (a dependent v_pk_fma_f32 chain costs a wait state per
+// tap), and the history record is finalised for 64 frames at once (ring of window partials in
+// LDS, one lane per frame: square roots, idx2freq, snr, coalesced 32-byte stores).
 // ---------------------------------------------------------------------------------------------
 constexpr int kN1 = 1024;
 constexpr int T1 = 64;
 constexpr int kMixLen1 = kN1 + kHalo;                     // 1050
-constexpr int kMixPad1 = kMixLen1 + (kMixLen1 >> 4) + 2;  // padded image, complex units
-constexpr int kLdsFloats1 = 2 * kMixPad1;
-static_assert(kMixPad1 >= kN1, "the FFT tile aliases the mixed image");
+constexpr int kImg1 = T1 * 17 + ((T1 * 17) >> 4) + 4;     // 1160: every m = j + 64 u, u < 17, has a slot
+constexpr int kRing1 = 64;                                // frames per finaliser drain
+constexpr int kRingStride1 = 5;                           // ql, il, qr, ir, flags (odd: conflict-free)
+constexpr int kRingOff1 = 2 * kImg1;
+constexpr int kLdsFloats1 = kRingOff1 + kRing1 * kRingStride1;
+static_assert(kImg1 >= kN1, "the FFT tile aliases the mixed image");
 
 template <int DTYPE>
-__global__ __launch_bounds__(T1, 3) void iq1024_kernel(const IqParams p) {
+__global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats1];
+  float* ring = lds + kRingOff1;
   const int j = threadIdx.x;  // = lane
 
+  // frames are dealt in groups of G consecutive frames, round robin over the workgroups
   const size_t nfr = p.n_frames;
-  const size_t chunk = (nfr + gridDim.x - 1) / gridDim.x;
-  size_t f = (size_t)blockIdx.x * chunk;
-  if (f >= nfr) return;
-  const size_t fend = (f + chunk < nfr) ? f + chunk : nfr;
+  const size_t G = p.group;
+  const size_t ngroups = (nfr + G - 1) / G;
+  size_t grp = blockIdx.x;
+  if (grp >= ngroups) return;
+  size_t f = grp * G;
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN1 * 8);
   const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN1 * 8);
   const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN1 * 8);  // exp(-2 pi i k / 1024)
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
 
+  const int lo = (int)p.idx_left_zero, center = (int)p.center;
+  const int bw2 = (int)p.bw2, bw4 = (int)p.bw4;
+
+  // ---- resident tables ---------------------------------------------------------------------
+  // carrier of mixed sample m = j + 64 u (frame index i = m - 26).  History was mixed with the
+  // TAIL of the table, as the previous back-to-back block's samples were (iq_modem.c:60-61 with
+  // the state carried in i_state / q_state).  m >= 1050 reads past the table: (0, 0).
+  v2f cs[17];
+#pragma unroll
+  for (int u = 0; u < 17; u++) {
+    const int i = j + T1 * u - kHalo;
+    const int ci = i < 0 ? kN1 + i : i;
+    cs[u] = buf_ld64(rs_car, ci * 8, 0);
+  }
+  v2f ch[16];  // chirp*hann of sample n = j + 64 t
+#pragma unroll
+  for (int t = 0; t < 16; t++) ch[t] = buf_ld64(rs_ch, j * 8, T1 * 8 * t);
   // pass-2 twiddles W_128^(t k) = W_1024^(8 t k), k = b & 15 = j & 15 for both butterflies b = j, j + 64
   v2f tw2[8];
 #pragma unroll
   for (int t = 1; t < 8; t++) tw2[t] = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN1 - 1)) * 8, 0);
+  // pass-3 twiddles of bins k = lo + j and lo + 64 + j: W^k and W^2k (Horner form)
+  v2f t3w1[2], t3w2[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int k = lo + T1 * r + j;
+    t3w1[r] = buf_ld64(rs_tw, (k & (kN1 - 1)) * 8, 0);
+    t3w2[r] = buf_ld64(rs_tw, ((2 * k) & (kN1 - 1)) * 8, 0);
+  }
+
+  // the 27 real taps, two per SGPR pair
+  v2f taps[14];
+#pragma unroll
+  for (int i = 0; i < 14; i++) taps[i] = mkv(p.fir[2 * i], 2 * i + 1 < kFirTapsDev ? p.fir[2 * i + 1] : 0.f);
 
   const int s1 = j & 15;
   const int wr1 = 16 * j;  // natural / exchange-1 layout: + (t ^ s1)
   int rdn[4];              // natural-order read n = j + 64 t: base for t & 3
 #pragma unroll
   for (int m = 0; m < 4; m++) rdn[m] = (j & ~15) + ((j & 15) ^ ((j >> 4) + 4 * m));
-  const int lo = (int)p.idx_left_zero, center = (int)p.center;
-  const int bw2 = (int)p.bw2, bw4 = (int)p.bw4;
 
-  for (; f < fend; f++) {
+  // the frame's 1050 samples (26 of history first) as raw words, one frame ahead
+  float xn[17];
+  auto load_frame = [&](size_t fr) {
+    const __amdgpu_buffer_rsrc_t rx =
+        make_rsrc(reinterpret_cast<const char*>(p.frames) + (fr * p.stride) * 4 - kHalo * 4, kMixLen1 * 4);
+#pragma unroll
+    for (int u = 0; u < 17; u++) xn[u] = buf_ld32(rx, j * 4, T1 * 4 * u);  // past the end: 0
+  };
+  load_frame(f);
+
+  // finaliser: lane L turns ring slot L into the history record of frame f0 + L
+  // (experiments/iq_modulation/Src/main.c:283-303)
+  auto finalise = [&](size_t f0, int count) {
+    if (j < count) {
+      const float* e = ring + j * kRingStride1;
+      const size_t ff = f0 + (size_t)j;
+      float ql = e[0], qr = e[2];
+      int il = __float_as_int(e[1]), ir = __float_as_int(e[3]);
+      const int flags = __float_as_int(e[4]);
+      if (flags & 1) { ql = __int_as_float(0x7fc00000); il = lo; }
+      if (flags & 2) { qr = __int_as_float(0x7fc00000); ir = center; }
+      const float ml = sqrtf(ql), mr = sqrtf(qr);
+      // full window [lo, lo + bw4) = left then right: the right part wins only if strictly greater
+      float mx = ml;
+      int ix = il;
+      if (!(ml != ml) && mr > ml) { mx = mr; ix = ir; }
+      if (p.stats) {
+        const float mm = p.mag_mean ? p.mag_mean[2 * ff] : p.mag_mean_scalar;
+        // idx2freq of this experiment: (uint32)(sampling_rate * idx / n), Src/main.c:112-114
+        const float fsn = p.fs;
+        float4 sa, sb;
+        sa.x = mx; sa.y = ml; sa.z = mr;
+        sa.w = __int_as_float((int)(unsigned)(fsn * (float)ix / (float)kN1));
+        sb.x = __int_as_float((int)(unsigned)(fsn * (float)il / (float)kN1));
+        sb.y = __int_as_float((int)(unsigned)(fsn * (float)ir / (float)kN1));
+        sb.z = mm;
+        sb.w = (mx - mm) / mm;
+        float4* d = reinterpret_cast<float4*>(p.stats + ff);
+        d[0] = sa;
+        d[1] = sb;
+      }
+      if (p.symbols) p.symbols[ff] = (uint8_t)UC_SYM_NONE;
+    }
+  };
+
+  size_t ring_f0 = f;
+  int ring_n = 0;
+
+  for (;;) {
+    size_t fnext = f + 1;
+    if ((fnext % G) == 0 || fnext >= nfr) {
+      grp += gridDim.x;
+      fnext = grp * G;
+    }
+    const bool has_next = grp < ngroups;
     int s1v = s1;
     asm volatile("" : "+v"(s1v));
-    // ---- stage 0: carrier mix into the padded image ------------------------------------
-    {
-      const __amdgpu_buffer_rsrc_t rx =
-          make_rsrc(reinterpret_cast<const char*>(p.frames) + (f * p.stride) * 4 - kHalo * 4, kMixLen1 * 4);
+
+    // ---- stage 0: carrier mix into the padded image (iq_modem.c:60-61) ------------------------
 #pragma unroll
-      for (int u = 0; u < 17; u++) {
-        const int m = j + T1 * u;
-        if (m < kMixLen1) {
-          const float x = cvt1<DTYPE>(buf_ld32(rx, j * 4, T1 * 4 * u));
-          const int i = m - kHalo;
-          const int ci = i < 0 ? kN1 + i : i;
-          const v2f cs = buf_ld64(rs_car, ci * 8, 0);
-          lds_st(lds, mix_idx(m), mkv(x * cs.x, x * cs.y));
-        }
-      }
+    for (int u = 0; u < 17; u++) {
+      const float x = cvt1<DTYPE>(xn[u]);
+      lds_st(lds, mix_idx(j + T1 * u), mkv(x * cs[u].x, x * cs[u].y));
     }
+    if (has_next) load_frame(fnext);
     __syncthreads();  // single wave: no s_barrier is emitted, only the LDS wait
 
-    // ---- stage 1: FIR, 16 consecutive outputs per thread ---------------------------------
-    v2f acc[16];
+    // ---- stage 1: FIR (iq_modem.c:64-65), 16 consecutive outputs per thread --------------------
+    // output o = 16 j + u needs mixed[o + 26 - k], k = 0..26: window w[d] = mixed[16 j + d], d < 42.
+    // Two halves of eight outputs; within a half the eight accumulators advance tap by tap.
+    v2f accA[8], accB[8];
     {
       v2f w[42];
 #pragma unroll
-      for (int d = 0; d < 42; d++) w[d] = lds_ld(lds, 17 * j + d + (d >> 4));
+      for (int d = 0; d < 34; d++) w[d] = lds_ld(lds, 17 * j + d + (d >> 4));
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        v2f a = mkv(0.f, 0.f);
+      for (int u = 0; u < 8; u++) accA[u] = pk_mul_slo(w[0 + u + kHalo], taps[0]);
 #pragma unroll
-        for (int k = 0; k < kFirTapsDev; k++) {
-          const float b = p.fir[k];
-          a = __builtin_elementwise_fma(w[u + kHalo - k], mkv(b, b), a);
-        }
-        acc[u] = a;
-      }
+      for (int k = 1; k < kFirTapsDev; k += 2)  // taps k (high half of pair k/2) and k + 1 (low half of the next)
+        pk_tap8x2(accA, &w[0 + kHalo - k - 1], taps[k >> 1], taps[(k >> 1) + 1]);
+#pragma unroll
+      for (int d = 34; d < 42; d++) w[d] = lds_ld(lds, 17 * j + d + (d >> 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; u++) accB[u] = pk_mul_slo(w[8 + u + kHalo], taps[0]);
+#pragma unroll
+      for (int k = 1; k < kFirTapsDev; k += 2)  // taps k (high half of pair k/2) and k + 1 (low half of the next)
+        pk_tap8x2(accB, &w[8 + kHalo - k - 1], taps[k >> 1], taps[(k >> 1) + 1]);
     }
     __syncthreads();
+    if (ring_n > 0 && (f % G) == 0) {  // a new group starts: drain the last one
+      finalise(ring_f0, ring_n);
+      ring_f0 = f;
+      ring_n = 0;
+    }
 #pragma unroll
-    for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), acc[u]);
+    for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
     __syncthreads();
 
     // ---- pass 1: x chirp*hann, radix-16 (Ns = 1) -------------------------------------------
@@ -331,7 +429,7 @@ __global__ __launch_bounds__(T1, 3) void iq1024_kernel(const IqParams p) {
     for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rdn[t & 3] + 64 * t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], buf_ld64(rs_ch, j * 8, T1 * 8 * t));
+    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
     pk_dft16(v, K, H);
     __syncthreads();
 #pragma unroll
@@ -365,20 +463,21 @@ __global__ __launch_bounds__(T1, 3) void iq1024_kernel(const IqParams p) {
 
     // ---- pass 3 (radix-8, Ns = 128), pruned: bins k = lo + j, lo + 64 + j ---------------------
     float q[2] = {0.f, 0.f};
+    {
+      v2f a[2][8];
 #pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int k = lo + T1 * r + j;
-      if (k < lo + bw4) {
-        const int b = k & 127;
-        v2f a[8];
+      for (int r = 0; r < 2; r++) {
+        const int b = (lo + T1 * r + j) & 127;
 #pragma unroll
-        for (int t = 0; t < 8; t++) a[t] = lds_ld(lds, b + 128 * t);
-        const v2f w1 = buf_ld64(rs_tw, (k & (kN1 - 1)) * 8, 0);
-        const v2f w2 = buf_ld64(rs_tw, ((2 * k) & (kN1 - 1)) * 8, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        v2f e = pk_cfma(a[6], w2, a[4]), o = pk_cfma(a[7], w2, a[5]);
-        e = pk_cfma(e, w2, a[2]); o = pk_cfma(o, w2, a[3]);
-        e = pk_cfma(e, w2, a[0]); o = pk_cfma(o, w2, a[1]);
+        for (int t = 0; t < 8; t++) a[r][t] = lds_ld(lds, b + 128 * t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const v2f w1 = t3w1[r], w2 = t3w2[r];
+        v2f e = pk_cfma(a[r][6], w2, a[r][4]), o = pk_cfma(a[r][7], w2, a[r][5]);
+        e = pk_cfma(e, w2, a[r][2]); o = pk_cfma(o, w2, a[r][3]);
+        e = pk_cfma(e, w2, a[r][0]); o = pk_cfma(o, w2, a[r][1]);
         const v2f z = pk_cfma(o, w1, e);
         q[r] = z.x * z.x + z.y * z.y;
       }
@@ -386,36 +485,31 @@ __global__ __launch_bounds__(T1, 3) void iq1024_kernel(const IqParams p) {
     __syncthreads();  // tile free for the next frame
 
     // ---- windows (one wave: no merge step) -----------------------------------------------------
-    const int k0 = lo + j, k1 = lo + T1 + j;
-    const float q1v = (k1 < lo + bw4) ? q[1] : -INFINITY;
-    float ql, qr;
-    int il, ir;
-    window_first_max(q[0], k0, q1v, k1, lo, lo + bw2, ql, il);
-    window_first_max(q[0], k0, q1v, k1, center, center + bw2, qr, ir);
-    const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
-    const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
-    if (j == 0 && p.stats) {
-      if (nl) { ql = __int_as_float(0x7fc00000); il = lo; }
-      if (nr) { qr = __int_as_float(0x7fc00000); ir = center; }
-      const float ml = sqrtf(ql), mr = sqrtf(qr);
-      float mx = ml;
-      int ix = il;
-      if (!(ml != ml) && mr > ml) { mx = mr; ix = ir; }
-      const float mm = p.mag_mean ? p.mag_mean[2 * f] : p.mag_mean_scalar;
-      const float fsn = p.fs;
-      float4 sa, sb;
-      sa.x = mx; sa.y = ml; sa.z = mr;
-      sa.w = __int_as_float((int)(unsigned)(fsn * (float)ix / (float)kN1));
-      sb.x = __int_as_float((int)(unsigned)(fsn * (float)il / (float)kN1));
-      sb.y = __int_as_float((int)(unsigned)(fsn * (float)ir / (float)kN1));
-      sb.z = mm;
-      sb.w = (mx - mm) / mm;
-      float4* d = reinterpret_cast<float4*>(p.stats + f);
-      d[0] = sa;
-      d[1] = sb;
+    {
+      const int k0 = lo + j, k1 = lo + T1 + j;
+      const float q1v = (k1 < lo + bw4) ? q[1] : -INFINITY;
+      float ql, qr;
+      int il, ir;
+      window_first_max(q[0], k0, q1v, k1, lo, lo + bw2, ql, il);
+      window_first_max(q[0], k0, q1v, k1, center, center + bw2, qr, ir);
+      // first elements (a NaN there sticks): bin lo is lane 0 / round 0; bin `center` wherever it sits
+      const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
+      const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
+      if (j == 0) {
+        float* e = ring + ring_n * kRingStride1;
+        e[0] = ql;
+        e[1] = __int_as_float(il);
+        e[2] = qr;
+        e[3] = __int_as_float(ir);
+        e[4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
+      }
+      ring_n++;
     }
-    if (j == 0 && p.symbols) p.symbols[f] = (uint8_t)UC_SYM_NONE;
+    if (!has_next) break;
+    f = fnext;
   }
+  __syncthreads();
+  if (ring_n > 0) finalise(ring_f0, ring_n);
 }
 
 }  // namespace

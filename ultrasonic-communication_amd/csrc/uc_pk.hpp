@@ -99,6 +99,46 @@ __device__ __forceinline__ v2f pk_scale_hi(v2f w, v2f x) {
   return r;
 }
 
+// acc + w * b (or w * b) with the REAL factor b broadcast from the low / high half of an SGPR pair:
+// two filter taps per pair, no (b, b) copies
+__device__ __forceinline__ v2f pk_fma_slo(v2f w, v2f bb, v2f acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(bb));
+  return acc;
+}
+__device__ __forceinline__ v2f pk_fma_shi(v2f w, v2f bb, v2f acc) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(bb));
+  return acc;
+}
+__device__ __forceinline__ v2f pk_mul_slo(v2f w, v2f bb) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(w), "s"(bb));
+  return r;
+}
+
+// Two consecutive filter taps (k odd, k + 1) on eight independent accumulators as ONE asm block
+// (hipcc puts an s_nop between dependent asm statements, so the blocks are made long):
+//   acc[u] += w[u + 1] * hi(b0) + w[u] * lo(b1)      -- sample index falls as the tap index rises
+__device__ __forceinline__ void pk_tap8x2(v2f (&acc)[8], const v2f* w, v2f b0, v2f b1) {
+  asm("v_pk_fma_f32 %0, %9, %17, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %1, %10, %17, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %2, %11, %17, %2 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %3, %12, %17, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %4, %13, %17, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %5, %14, %17, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %6, %15, %17, %6 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %7, %16, %17, %7 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"
+      "v_pk_fma_f32 %0, %8, %18, %0 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %1, %9, %18, %1 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %2, %10, %18, %2 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %3, %11, %18, %3 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %4, %12, %18, %4 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %5, %13, %18, %5 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %6, %14, %18, %6 op_sel_hi:[1,0,1]\n\t"
+      "v_pk_fma_f32 %7, %15, %18, %7 op_sel_hi:[1,0,1]"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7])
+      : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(w[4]), "v"(w[5]), "v"(w[6]), "v"(w[7]), "v"(w[8]), "s"(b0), "s"(b1));
+}
+
 // ---- multiplications by the fixed radix-16 twiddles -------------------------
 // K = (cos(pi/8), sin(pi/8)), H = (sqrt(1/2), sqrt(1/2)) live in two SGPR pairs ("s" operands:
 // wave-uniform constants cost no VGPRs).
