@@ -425,11 +425,11 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
     size_t grid = (size_t)c->num_cu * (size_t)c->iq_blocks_per_cu;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     if (grid > n_frames) grid = n_frames;
-    // n = 1024: groups of up to 64 consecutive frames (one finaliser drain each), dealt round robin;
+    // groups of up to 64 consecutive frames (one finaliser drain each), dealt round robin;
     // smaller groups when the batch would not give every workgroup one
     ip.group = 64;
     while (ip.group > 1 && n_frames < (size_t)ip.group * grid) ip.group >>= 1;
-    if (n == 1024) {
+    {
       const size_t ngroups = (n_frames + ip.group - 1) / ip.group;
       if (grid > ngroups) grid = ngroups;
     }

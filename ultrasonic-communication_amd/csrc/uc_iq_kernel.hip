@@ -27,10 +27,6 @@ namespace {
 constexpr int T = kBandThreads;          // 128
 constexpr int kHalo = 26;                // FIR taps - 1
 constexpr int kMixLen = kN + kHalo;      // 2074 mixed samples
-constexpr int kMixPad = kMixLen + (kMixLen >> 4) + 2;  // padded image (complex units)
-constexpr int kRedOff = 2 * kMixPad;     // floats
-constexpr int kLdsFloats = kRedOff + 32;
-static_assert(kMixPad >= kN, "the FFT tile aliases the mixed image");
 
 template <int DTYPE>
 __device__ __forceinline__ float cvt1(float raw) {
@@ -52,20 +48,38 @@ __device__ __forceinline__ void window_first_max(float q0, int k0, float q1, int
   k = wave_min_u32(cand);
 }
 
+// LDS: the padded mixed image (also exchange 1), a second tile (FIR outputs, exchange 2) and the
+// ring of per-frame window partials.  Ping-ponging between image and tile leaves ONE barrier per
+// exchange: a buffer is rewritten only after a barrier that follows its last read.
+constexpr int kImg = T * 17 + ((T * 17) >> 4) + 4;  // 2316: every m = j + 128 u, u < 17, has a slot
+constexpr int kRingFr = 64;
+constexpr int kRingSt = 11;                         // 2 waves x (vl, kl, vr, kr, flags) + 1 pad
+constexpr int kTileOff = 2 * kImg;
+constexpr int kRingO = kTileOff + 2 * kN;
+constexpr int kTw2O = kRingO + kRingFr * kRingSt;  // even: 8-byte aligned
+constexpr int kLdsAll = kTw2O + 2 * 256;
+static_assert((kTw2O & 1) == 0, "complex alignment");
+static_assert(kImg >= kN, "exchange 1 lives in the image area");
+
 template <int DTYPE>
-__global__ __launch_bounds__(T, 3) void iq_kernel(const IqParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
-  float* red = lds + kRedOff;
+__global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[kLdsAll];
+  float* img = lds;
+  float* tile = lds + kTileOff;
+  float* ring = lds + kRingO;
+  float* tw2l = lds + kTw2O;
 
   const int j = threadIdx.x;
   const int lane = j & 63;
   const int wave = j >> 6;
 
+  // frames are dealt in groups of G consecutive frames, round robin over the workgroups
   const size_t nfr = p.n_frames;
-  const size_t chunk = (nfr + gridDim.x - 1) / gridDim.x;
-  size_t f = (size_t)blockIdx.x * chunk;
-  if (f >= nfr) return;
-  const size_t fend = (f + chunk < nfr) ? f + chunk : nfr;
+  const size_t G = p.group;
+  const size_t ngroups = (nfr + G - 1) / G;
+  size_t grp = blockIdx.x;
+  if (grp >= ngroups) return;
+  size_t f = grp * G;
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN * 8);
@@ -73,9 +87,38 @@ __global__ __launch_bounds__(T, 3) void iq_kernel(const IqParams p) {
   const int voff8 = j * 8;
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
 
-  v2f tw2[16];  // pass 2: W_256^(t k), k = j & 15
+  const int lo = (int)p.idx_left_zero, center = (int)p.center;
+  const int bw2 = (int)p.bw2, bw4 = (int)p.bw4;
+
+  // ---- resident tables (the loop loads nothing but the frames: vector loads return in order) ----
+  // carrier of mixed sample m = j + 128 u (frame index i = m - 26).  History was mixed with the
+  // TAIL of the table, as the previous back-to-back block's samples were (iq_modem.c:60-61 with
+  // the state carried in i_state / q_state).  m >= 2074 reads past the table: (0, 0).
+  v2f cs[17];
 #pragma unroll
-  for (int t = 1; t < 16; t++) tw2[t] = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN - 1)) * 8, 0);
+  for (int u = 0; u < 17; u++) {
+    const int i = j + T * u - kHalo;
+    const int ci = i < 0 ? kN + i : i;
+    cs[u] = buf_ld64(rs_car, ci * 8, 0);
+  }
+  v2f ch[16];  // chirp*hann of sample n = j + 128 t
+#pragma unroll
+  for (int t = 0; t < 16; t++) ch[t] = buf_ld64(rs_ch, voff8, T * 8 * t);
+  // pass 2: W_256^(t k), k = j & 15 -- 16 x 16 entries shared through LDS (read with the pass-2 tile reads)
+  for (int e = j; e < 256; e += T) lds_st(tw2l, e, buf_ld64(rs_tw, ((8 * (e >> 4) * (e & 15)) & (kN - 1)) * 8, 0));
+  const int tw2o = j & 15;  // + 16 t
+  // pass-3 twiddles of bins k = lo + j and lo + 128 + j: W^k and W^2k (Horner form)
+  v2f t3w1[2], t3w2[2];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int k = lo + T * r + j;
+    t3w1[r] = buf_ld64(rs_tw, (k & (kN - 1)) * 8, 0);
+    t3w2[r] = buf_ld64(rs_tw, ((2 * k) & (kN - 1)) * 8, 0);
+  }
+  // the 27 real taps, two per SGPR pair
+  v2f taps[14];
+#pragma unroll
+  for (int i = 0; i < 14; i++) taps[i] = mkv(p.fir[2 * i], 2 * i + 1 < kFirTapsDev ? p.fir[2 * i + 1] : 0.f);
 
   const int s1 = j & 15;
   const int wr1 = 16 * j;                                   // exchange-1 layout: + (t ^ s1)
@@ -83,131 +126,26 @@ __global__ __launch_bounds__(T, 3) void iq_kernel(const IqParams p) {
   const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);   // + 128 t, t odd
   const int wr2 = (j >> 4) * 256 + (j & 15);                // exchange-2 layout: + 16 t
 
-  const int lo = (int)p.idx_left_zero, center = (int)p.center;
-  const int bw2 = (int)p.bw2, bw4 = (int)p.bw4;
+  // the frame's 2074 samples (26 of history first) as raw words, one frame ahead
+  float xn[17];
+  auto load_frame = [&](size_t fr) {
+    const __amdgpu_buffer_rsrc_t rx =
+        make_rsrc(reinterpret_cast<const char*>(p.frames) + (fr * p.stride) * 4 - kHalo * 4, kMixLen * 4);
+#pragma unroll
+    for (int u = 0; u < 17; u++) xn[u] = buf_ld32(rx, j * 4, T * 4 * u);  // past the end: 0
+  };
+  load_frame(f);
 
-  for (; f < fend; f++) {
-    int s1v = s1;
-    asm volatile("" : "+v"(s1v));
-    // ---- stage 0: carrier mix while copying frame + history into the padded image ----
-    {
-      // sample i = -26 + j + 128 u of the frame; the resource starts at the first history sample
-      const __amdgpu_buffer_rsrc_t rx =
-          make_rsrc(reinterpret_cast<const char*>(p.frames) + (f * p.stride) * 4 - kHalo * 4, kMixLen * 4);
-#pragma unroll
-      for (int u = 0; u < 17; u++) {
-        const int m = j + T * u;  // 0 .. 2175, valid below kMixLen (out-of-range loads return 0)
-        if (m < kMixLen) {
-          const float x = cvt1<DTYPE>(buf_ld32(rx, j * 4, T * 4 * u));
-          const int i = m - kHalo;
-          // history was mixed with the TAIL of the table, as the previous back-to-back block's
-          // samples were (iq_modem.c:60-61 with the state carried in i_state / q_state)
-          const int ci = i < 0 ? kN + i : i;
-          const v2f cs = buf_ld64(rs_car, ci * 8, 0);
-          lds_st(lds, mix_idx(m), mkv(x * cs.x, x * cs.y));
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- stage 1: 27-tap FIR, 16 consecutive outputs per thread -----------------------
-    // output o = 16 j + u needs mixed[o + 26 - k], k = 0..26: window w[d] = mixed[16 j + d], d < 42
-    v2f acc[16];
-    {
-      v2f w[42];
-#pragma unroll
-      for (int d = 0; d < 42; d++) w[d] = lds_ld(lds, 17 * j + d + (d >> 4));
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int u = 0; u < 16; u++) {
-        v2f a = mkv(0.f, 0.f);
-#pragma unroll
-        for (int k = 0; k < kFirTapsDev; k++) {
-          const float b = p.fir[k];
-          a = __builtin_elementwise_fma(w[u + kHalo - k], mkv(b, b), a);
-        }
-        acc[u] = a;
-      }
-    }
-    __syncthreads();  // every window is in registers: the image may be overwritten
-#pragma unroll
-    for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), acc[u]);
-    __syncthreads();
-
-    // ---- stage 2: (I + jQ) * down_chirp * hann, FFT pass 1 -------------------------------
-    v2f v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], buf_ld64(rs_ch, voff8, T * 8 * t));
-    pk_dft16(v, K, H);
-    __syncthreads();  // all natural-order reads done before exchange 1 overwrites the tile
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(lds, wr1 + (t ^ s1v), v[pk_slot16(t)]);
-    __syncthreads();
-
-    // ---- FFT pass 2 -----------------------------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, ((t & 1) ? rd1o : rd1e) + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], tw2[t]);
-    pk_dft16(v, K, H);
-    __syncthreads();
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[pk_slot16(t)]);
-    __syncthreads();
-
-    // ---- FFT pass 3, pruned: bins k = lo + j and k = lo + 128 + j (< lo + bw4) ------------
-    float q[2] = {0.f, 0.f};
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int k = lo + T * r + j;
-      if (k < lo + bw4) {
-        const int b = k & 255;
-        v2f a[8];
-#pragma unroll
-        for (int t = 0; t < 8; t++) a[t] = lds_ld(lds, b + 256 * t);
-        v2f w[8];
-        w[1] = buf_ld64(rs_tw, (k & (kN - 1)) * 8, 0);
-        w[2] = buf_ld64(rs_tw, ((2 * k) & (kN - 1)) * 8, 0);
-        w[4] = buf_ld64(rs_tw, ((4 * k) & (kN - 1)) * 8, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        w[3] = pk_cmul(w[1], w[2]);
-        w[5] = pk_cmul(w[1], w[4]);
-        w[6] = pk_cmul(w[2], w[4]);
-        w[7] = pk_cmul(w[3], w[4]);
-        v2f z = a[0];
-#pragma unroll
-        for (int t = 1; t < 8; t++) z = pk_cfma(a[t], w[t], z);
-        q[r] = z.x * z.x + z.y * z.y;  // |Z[k]|^2, the square root is taken for the winners only
-      }
-    }
-
-    // ---- the three arm_max_f32 (first maximum wins) ---------------------------------------
-    const int k0 = lo + j, k1 = lo + T + j;
-    const float q1v = (k1 < lo + bw4) ? q[1] : -INFINITY;
-    float vl, vr;
-    int kl, kr;
-    window_first_max(q[0], k0, q1v, k1, lo, lo + bw2, vl, kl);           // left  [lo, lo + bw2)
-    window_first_max(q[0], k0, q1v, k1, center, center + bw2, vr, kr);   // right [center, center + bw2)
-    // first elements (a NaN there sticks): bin lo is thread 0 / round 0; bin `center` wherever it sits
-    const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
-    const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
-    if (lane == 0) {
-      red[8 * wave + 0] = vl;
-      red[8 * wave + 1] = __int_as_float(kl);
-      red[8 * wave + 2] = vr;
-      red[8 * wave + 3] = __int_as_float(kr);
-      red[8 * wave + 4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
-    }
-    __syncthreads();  // also frees the tile for the next frame
-    if (j == 0 && p.stats) {
-      float a0 = red[0], a1 = red[8], b0 = red[2], b1 = red[10];
-      int ka0 = __float_as_int(red[1]), ka1 = __float_as_int(red[9]);
-      int kb0 = __float_as_int(red[3]), kb1 = __float_as_int(red[11]);
-      const int flags = __float_as_int(red[4]) | __float_as_int(red[12]);
+  // finaliser: lane L of wave 0 merges the two waves' partials of ring slot L into the history
+  // record of frame f0 + L (experiments/iq_modulation/Src/main.c:283-303)
+  auto finalise = [&](size_t f0, int count) {
+    if (lane < count) {
+      const float* e = ring + lane * kRingSt;
+      const size_t ff = f0 + (size_t)lane;
+      const float a0 = e[0], a1 = e[5], b0 = e[2], b1 = e[7];
+      const int ka0 = __float_as_int(e[1]), ka1 = __float_as_int(e[6]);
+      const int kb0 = __float_as_int(e[3]), kb1 = __float_as_int(e[8]);
+      const int flags = __float_as_int(e[4]) | __float_as_int(e[9]);
       // merge waves: larger value, ties -> smaller bin
       float ql = a0, qr = b0;
       int il = ka0, ir = kb0;
@@ -220,22 +158,150 @@ __global__ __launch_bounds__(T, 3) void iq_kernel(const IqParams p) {
       float mx = ml;
       int ix = il;
       if (!(ml != ml) && mr > ml) { mx = mr; ix = ir; }
-      const float mm = p.mag_mean ? p.mag_mean[2 * f] : p.mag_mean_scalar;
-      // idx2freq of this experiment: (uint32)(sampling_rate * idx / n), Src/main.c:112-114
-      const float fsn = p.fs;
-      float4 sa, sb;
-      sa.x = mx; sa.y = ml; sa.z = mr;
-      sa.w = __int_as_float((int)(unsigned)(fsn * (float)ix / (float)kN));
-      sb.x = __int_as_float((int)(unsigned)(fsn * (float)il / (float)kN));
-      sb.y = __int_as_float((int)(unsigned)(fsn * (float)ir / (float)kN));
-      sb.z = mm;
-      sb.w = (mx - mm) / mm;
-      float4* d = reinterpret_cast<float4*>(p.stats + f);
-      d[0] = sa;
-      d[1] = sb;
+      if (p.stats) {
+        const float mm = p.mag_mean ? p.mag_mean[2 * ff] : p.mag_mean_scalar;
+        // idx2freq of this experiment: (uint32)(sampling_rate * idx / n), Src/main.c:112-114
+        const float fsn = p.fs;
+        float4 sa, sb;
+        sa.x = mx; sa.y = ml; sa.z = mr;
+        sa.w = __int_as_float((int)(unsigned)(fsn * (float)ix / (float)kN));
+        sb.x = __int_as_float((int)(unsigned)(fsn * (float)il / (float)kN));
+        sb.y = __int_as_float((int)(unsigned)(fsn * (float)ir / (float)kN));
+        sb.z = mm;
+        sb.w = (mx - mm) / mm;
+        float4* d = reinterpret_cast<float4*>(p.stats + ff);
+        d[0] = sa;
+        d[1] = sb;
+      }
+      if (p.symbols) p.symbols[ff] = (uint8_t)UC_SYM_NONE;
     }
-    if (j == 0 && p.symbols) p.symbols[f] = (uint8_t)UC_SYM_NONE;
+  };
+
+  size_t ring_f0 = f;
+  int ring_n = 0;
+
+  for (;;) {
+    size_t fnext = f + 1;
+    if ((fnext % G) == 0 || fnext >= nfr) {
+      grp += gridDim.x;
+      fnext = grp * G;
+    }
+    const bool has_next = grp < ngroups;
+    int s1v = s1;
+    asm volatile("" : "+v"(s1v));
+
+    // ---- stage 0: carrier mix into the padded image (iq_modem.c:60-61) ------------------------
+#pragma unroll
+    for (int u = 0; u < 17; u++) {
+      const float x = cvt1<DTYPE>(xn[u]);
+      lds_st(img, mix_idx(j + T * u), mkv(x * cs[u].x, x * cs[u].y));
+    }
+    if (has_next) load_frame(fnext);
+    __syncthreads();  // B1: image complete; the previous frame's pruned-pass reads of the tile are done
+    if (ring_n > 0 && (f % G) == 0) {  // a new group starts: drain the last one
+      if (wave == 0) finalise(ring_f0, ring_n);
+      ring_f0 = f;
+      ring_n = 0;
+    }
+
+    // ---- stage 1: FIR (iq_modem.c:64-65), 16 consecutive outputs per thread --------------------
+    // output o = 16 j + u needs mixed[o + 26 - k], k = 0..26: window w[d] = mixed[16 j + d], d < 42.
+    // Two halves of eight outputs; within a half the eight accumulators advance tap by tap.
+    {
+      v2f accA[8], accB[8];
+      v2f w[42];
+#pragma unroll
+      for (int d = 0; d < 34; d++) w[d] = lds_ld(img, 17 * j + d + (d >> 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; u++) accA[u] = pk_mul_slo(w[u + kHalo], taps[0]);
+#pragma unroll
+      for (int k = 1; k < kFirTapsDev; k += 2)  // taps k (high half of pair k/2) and k + 1 (low half of the next)
+        pk_tap8x2(accA, &w[kHalo - k - 1], taps[k >> 1], taps[(k >> 1) + 1]);
+#pragma unroll
+      for (int d = 34; d < 42; d++) w[d] = lds_ld(img, 17 * j + d + (d >> 4));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int u = 0; u < 8; u++) accB[u] = pk_mul_slo(w[8 + u + kHalo], taps[0]);
+#pragma unroll
+      for (int k = 1; k < kFirTapsDev; k += 2)
+        pk_tap8x2(accB, &w[8 + kHalo - k - 1], taps[k >> 1], taps[(k >> 1) + 1]);
+#pragma unroll
+      for (int u = 0; u < 16; u++) lds_st(tile, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
+    }
+    __syncthreads();  // B2: filtered frame in the tile; every window read of the image is done
+
+    // ---- stage 2: (I + jQ) * down_chirp * hann, FFT pass 1 -------------------------------
+    v2f v[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
+    pk_dft16(v, K, H);
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(img, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    __syncthreads();  // B3
+
+    // ---- FFT pass 2 -----------------------------------------------------------------------
+#pragma unroll
+    for (int t = 0; t < 16; t++) v[t] = lds_ld(img, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2l, tw2o + 16 * t));
+    pk_dft16(v, K, H);
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(tile, wr2 + 16 * t, v[pk_slot16(t)]);
+    __syncthreads();  // B4
+
+    // ---- FFT pass 3, pruned: bins k = lo + j and k = lo + 128 + j (< lo + bw4) ------------
+    float q[2] = {0.f, 0.f};
+    {
+      v2f a[2][8];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int b = (lo + T * r + j) & 255;
+#pragma unroll
+        for (int t = 0; t < 8; t++) a[r][t] = lds_ld(tile, b + 256 * t);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const v2f w1 = t3w1[r], w2 = t3w2[r];
+        v2f e = pk_cfma(a[r][6], w2, a[r][4]), o = pk_cfma(a[r][7], w2, a[r][5]);
+        e = pk_cfma(e, w2, a[r][2]); o = pk_cfma(o, w2, a[r][3]);
+        e = pk_cfma(e, w2, a[r][0]); o = pk_cfma(o, w2, a[r][1]);
+        const v2f z = pk_cfma(o, w1, e);
+        q[r] = z.x * z.x + z.y * z.y;  // |Z[k]|^2, the square root is taken for the winners only
+      }
+    }
+
+    // ---- the three arm_max_f32 (first maximum wins): this wave's partials ----------------------
+    {
+      const int k0 = lo + j, k1 = lo + T + j;
+      const float q1v = (k1 < lo + bw4) ? q[1] : -INFINITY;
+      float vl, vr;
+      int kl, kr;
+      window_first_max(q[0], k0, q1v, k1, lo, lo + bw2, vl, kl);           // left  [lo, lo + bw2)
+      window_first_max(q[0], k0, q1v, k1, center, center + bw2, vr, kr);   // right [center, center + bw2)
+      // first elements (a NaN there sticks): bin lo is thread 0 / round 0; bin `center` wherever it sits
+      const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
+      const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
+      if (lane == 0) {
+        float* e = ring + ring_n * kRingSt + 5 * wave;
+        e[0] = vl;
+        e[1] = __int_as_float(kl);
+        e[2] = vr;
+        e[3] = __int_as_float(kr);
+        e[4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
+      }
+      ring_n++;
+    }
+    if (!has_next) break;
+    f = fnext;
   }
+  __syncthreads();
+  if (ring_n > 0 && wave == 0) finalise(ring_f0, ring_n);
 }
 
 

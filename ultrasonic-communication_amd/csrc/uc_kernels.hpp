@@ -72,7 +72,7 @@ struct IqParams {
   float mag_mean_scalar;
   float fs;
   uint32_t idx_left_zero, center, bw2, bw4;
-  uint32_t group;             // n = 1024: frames per round-robin group (power of two, <= 64)
+  uint32_t group;             // frames per round-robin group (power of two, <= 64)
 };
 // n = 2048 (the committed firmware) or 1024 (one wave per frame)
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
