@@ -7,8 +7,9 @@ over one batch of synthetic frames already resident in HBM.  Workload =
 BASELINE.json configs[1]: 1 Mi x 2048-sample fp32 frames per GPU, orthogonal
 up/down chirp at -10 dB SNR.  Multi-GPU: one process per GPU, the frame index
 space is block-partitioned (weak scaling: 1 Mi frames per GPU), no data-path
-collective; the decoded symbol stream (1 B/frame) is all-gathered over RCCL at
-the end of every step, inside the timed region.
+collective; the decoded symbol stream (1 B/frame) is all-gathered over RCCL
+every step, inside the timed region, on RCCL's stream: the gather of step k
+overlaps the kernel of step k + 1 (two symbol buffers).
 
 Prints ONE JSON line on rank 0 (see the contract in the task statement).
 """
@@ -141,13 +142,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    # UC_BENCH_REHEARSE=1: plumbing rehearsal of the N > 1 path on a ONE-GPU box (every rank on
+    # device 0, gloo, symbol gather staged through host memory).  Never a measurement.
+    rehearse = os.environ.get("UC_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if rehearse:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     import uchirp
     mag_mean = 1000.0
@@ -159,17 +168,44 @@ def main():
     frames, bits = make_device_frames(nf, device, seed=1234 + rank, snr_db=args.snr)
     if args.variant != "rx_real":
         return side_measurement(args, eng, frames, world, rank)
-    symbols = torch.empty(nf, dtype=torch.uint8, device=device)
-    gathered = torch.empty(world * nf, dtype=torch.uint8, device=device) if world > 1 else None
+    # Two symbol buffers: the gather of step k (RCCL's own stream) overlaps the kernel of step k + 1;
+    # a buffer is rewritten only after the gather that read it has finished (work.wait() orders the
+    # launch stream behind it without blocking the host).
+    sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
+    gathered2 = [torch.empty(world * nf, dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+    works = [None, None]
     stream = torch.cuda.current_stream(device)
 
-    def step():
-        eng.process(frames, want_stats=False, symbols_out=symbols, stream=stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, symbols)
+    def gather(b):
+        if rehearse:  # gloo has no device all-gather: stage through the host (rehearsal only)
+            host = [torch.empty(nf, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(host, sym2[b].cpu())
+            gathered2[b].copy_(torch.cat(host))
+            return None
+        return dist.all_gather_into_tensor(gathered2[b], sym2[b], async_op=True)
 
-    for _ in range(args.warmup):
-        step()
+    def step(k, e0=None, e1=None):
+        b = k & 1
+        if works[b] is not None:
+            works[b].wait()
+            works[b] = None
+        if e0 is not None:
+            e0.record(stream)
+        eng.process(frames, want_stats=False, symbols_out=sym2[b], stream=stream.cuda_stream)
+        if e1 is not None:
+            e1.record(stream)
+        if world > 1:
+            works[b] = gather(b)
+
+    def drain():
+        for b in range(2):
+            if works[b] is not None:
+                works[b].wait()
+                works[b] = None
+
+    for k in range(args.warmup):
+        step(k)
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -179,20 +215,22 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record(stream)
-        eng.process(frames, want_stats=False, symbols_out=symbols, stream=stream.cuda_stream)
-        ev[k][1].record(stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, symbols)
+        step(k, ev[k][0], ev[k][1])
+    drain()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    symbols = sym2[(args.steps - 1) & 1]
+    if world > 1:
+        # the gathered stream is the concatenation of every rank's symbols, rank order
+        g = gathered2[(args.steps - 1) & 1]
+        assert torch.equal(g[rank * nf:(rank + 1) * nf], symbols), "gathered symbol stream differs from this rank's symbols"
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
 
     # correctness gate on the measured run: decoded symbols == transmitted bits
