@@ -108,30 +108,65 @@ struct Common {
   int ks, kl;
 };
 
+// Both histories' common maxima with ONE reduction: v_permlane32_swap folds the upper half of the
+// up candidates and the lower half of the down candidates across, so that after one v_max lanes 0-31
+// carry the up search and lanes 32-63 the down search; four row rotations and one row broadcast then
+// leave the up maximum in lane 31 and the down maximum in lane 63 (7 cross-lane steps instead of 12).
 template <bool HAS1>
-__device__ __forceinline__ Common common_partial(float q0, int k0, float q1, int k1, int bw2) {
+__device__ __forceinline__ void common_partial2(float a0, float b0, int k0, float a1, float b1, int k1, int bw2,
+                                                Common& up, Common& dn) {
   const float ninf = -INFINITY;
-  const float c0 = (k0 >= 1 && k0 < bw2) ? q0 : ninf;
-  float c1 = ninf;
-  if (HAS1) c1 = (k1 < bw2) ? q1 : ninf;
-  Common o;
-  o.m = wave_max_f32(HAS1 ? max_f32(c0, c1) : c0);
-  // the attaining bins from two ballots and scalar bit scans (slot 0 holds the smaller bins)
+  const bool in0 = (k0 >= 1 && k0 < bw2);
+  const float ca0 = in0 ? a0 : ninf, cb0 = in0 ? b0 : ninf;
+  float ca1 = ninf, cb1 = ninf;
+  float ma = ca0, mb = cb0;
+  if (HAS1) {
+    const bool in1 = k1 < bw2;
+    ca1 = in1 ? a1 : ninf;
+    cb1 = in1 ? b1 : ninf;
+    ma = max_f32(ca0, ca1);
+    mb = max_f32(cb0, cb1);
+  }
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ma), __float_as_uint(mb), false, false);
+  float m = max_f32(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  asm("s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+      "s_nop 1\n\t"
+      "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+      : "+v"(m));
+  up.m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31));
+  dn.m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+  // the attaining bins from ballots and scalar bit scans (slot 0 holds the smaller bins)
   const int base = __builtin_amdgcn_readfirstlane(k0);
-  const unsigned long long b0 = __ballot(c0 == o.m);
-  unsigned long long b1 = 0;
-  if (HAS1) b1 = __ballot(c1 == o.m);
-  o.ks = 0;
-  o.kl = 0;
-  if (b0) {
-    o.ks = base + (__ffsll((long long)b0) - 1);
-    o.kl = base + (63 - __clzll((long long)b0));
+  const unsigned long long ua0 = __ballot(ca0 == up.m), ub0 = __ballot(cb0 == dn.m);
+  unsigned long long ua1 = 0, ub1 = 0;
+  if (HAS1) {
+    ua1 = __ballot(ca1 == up.m);
+    ub1 = __ballot(cb1 == dn.m);
   }
-  if (HAS1 && b1) {
-    if (!b0) o.ks = 128 + (__ffsll((long long)b1) - 1);
-    o.kl = 128 + (63 - __clzll((long long)b1));
+  up.ks = up.kl = dn.ks = dn.kl = 0;
+  if (ua0) {
+    up.ks = base + (__ffsll((long long)ua0) - 1);
+    up.kl = base + (63 - __clzll((long long)ua0));
   }
-  return o;
+  if (ub0) {
+    dn.ks = base + (__ffsll((long long)ub0) - 1);
+    dn.kl = base + (63 - __clzll((long long)ub0));
+  }
+  if (HAS1 && ua1) {
+    if (!ua0) up.ks = 128 + (__ffsll((long long)ua1) - 1);
+    up.kl = 128 + (63 - __clzll((long long)ua1));
+  }
+  if (HAS1 && ub1) {
+    if (!ub0) dn.ks = 128 + (__ffsll((long long)ub1) - 1);
+    dn.kl = 128 + (63 - __clzll((long long)ub1));
+  }
 }
 
 // finaliser side of common_partial: merge the two waves' common maxima, then fold in the
@@ -550,13 +585,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       if (kReal) {
         // up history looks at m_a, down history at m_b; wave 1 also holds slot 1
         Common up, dn;
-        if (wave == 0) {
-          up = common_partial<false>(m_a[0], j, 0.f, k1, bw2);
-          dn = common_partial<false>(m_b[0], j, 0.f, k1, bw2);
-        } else {
-          up = common_partial<true>(m_a[0], j, m_a[1], k1, bw2);
-          dn = common_partial<true>(m_b[0], j, m_b[1], k1, bw2);
-        }
+        if (wave == 0) common_partial2<false>(m_a[0], m_b[0], j, 0.f, 0.f, k1, bw2, up, dn);
+        else common_partial2<true>(m_a[0], m_b[0], j, m_a[1], m_b[1], k1, bw2, up, dn);
         if (lane == 0) {
           e[0] = up.m;
           e[1] = dn.m;
