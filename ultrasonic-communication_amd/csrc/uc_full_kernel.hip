@@ -36,32 +36,59 @@ constexpr int kTw2Off = kRedOff + 16;
 constexpr int kTwBOff = kTw2Off + 2 * 256;
 constexpr int kLdsFloats = kTwBOff + 2 * 128;
 
-// arm_max_f32 over the 2048 signed values of one frame held as v[slot].{x|y}, index j + 128 t
-template <int COMP>
-__device__ __forceinline__ void frame_max(const v2f (&y)[16], int j, int lane, float& out_v, int& out_i) {
-  // per thread: ascending t = ascending index, strict '>' keeps the first maximum
-  float m = COMP == 0 ? y[0].x : y[0].y;
-  int mi = j;
-  bool first_nan = false;
-  if (j == 0) first_nan = (m != m);  // element 0 of the frame: a NaN there sticks (arm_max_f32)
+// five cross-lane steps that finish a reduction whose two 32-lane halves hold two independent searches:
+// afterwards lane 31 has the result of lanes 0-31 and lane 63 that of lanes 32-63
+#define UC_DPP_HALVES(OP, v)                                                  \
+  asm("s_nop 1\n\t" OP " %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"  \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"  \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"  \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"  \
+      "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"     \
+      : "+v"(v))
+
+__device__ __forceinline__ float max3_f32(float a, float b, float c) {
+  float r;
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+  return r;
+}
+
+// arm_max_f32 over the 2048 signed values of BOTH frames of a pair (y[t].x = frame a, y[t].y = frame b,
+// index j + 128 t): this wave's maxima and first indices.  NaNs are skipped as arm_max_f32's '<' update
+// skips them (v_max_f32 returns the number), except a NaN in element 0, which sticks.
+__device__ __forceinline__ void pair_max(const v2f (&y)[16], int j, float& va, int& ia, float& vb, int& ib) {
+  // per thread: the maximum of its 16 values, then the FIRST t that attains it
+  float ma = max3_f32(y[0].x, y[1].x, y[2].x), mb = max3_f32(y[0].y, y[1].y, y[2].y);
 #pragma unroll
-  for (int t = 1; t < 16; t++) {
-    const float c = COMP == 0 ? y[t].x : y[t].y;
-    // '!(m >= c)' also replaces a NaN running maximum by a number, like skipping NaNs
-    const bool take = (c > m) || (m != m && c == c);
-    m = take ? c : m;
-    mi = take ? j + T * t : mi;
+  for (int t = 3; t < 15; t += 2) {
+    ma = max3_f32(ma, y[t].x, y[t + 1].x);
+    mb = max3_f32(mb, y[t].y, y[t + 1].y);
   }
-  const float ms = (m != m) ? -INFINITY : m;
-  const float wm = wave_max_f32(ms);
-  const int cand = (ms == wm) ? mi : 0x7fffffff;
-  const int wi = wave_min_u32(cand);
-  out_v = wm;
-  out_i = wi;
-  if (__ballot(first_nan)) {
-    out_v = __int_as_float(0x7fc00000);
-    out_i = 0;
+  ma = max_f32(ma, y[15].x);
+  mb = max_f32(mb, y[15].y);
+  int ta = 0, tb = 0;
+#pragma unroll
+  for (int t = 15; t >= 1; t--) {
+    ta = (y[t].x == ma) ? t : ta;
+    tb = (y[t].y == mb) ? t : tb;
   }
+  ta = (y[0].x == ma) ? 0 : ta;
+  tb = (y[0].y == mb) ? 0 : tb;
+  const unsigned long long fna = __ballot(j == 0 && y[0].x != y[0].x), fnb = __ballot(j == 0 && y[0].y != y[0].y);
+  // across the wave: frame a's search in lanes 0-31, frame b's in lanes 32-63 after one swap
+  const float sa = (ma != ma) ? -INFINITY : ma, sb = (mb != mb) ? -INFINITY : mb;
+  const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(sa), __float_as_uint(sb), false, false);
+  float m = max_f32(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  UC_DPP_HALVES("v_max_f32_dpp", m);
+  va = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31));
+  vb = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+  const int ca = (sa == va) ? j + T * ta : 0x7fffffff, cb = (sb == vb) ? j + T * tb : 0x7fffffff;
+  const auto si = __builtin_amdgcn_permlane32_swap((unsigned)ca, (unsigned)cb, false, false);
+  int c = (int)(si[0] < si[1] ? si[0] : si[1]);
+  UC_DPP_HALVES("v_min_u32_dpp", c);
+  ia = __builtin_amdgcn_readlane(c, 31);
+  ib = __builtin_amdgcn_readlane(c, 63);
+  if (fna) { va = __int_as_float(0x7fc00000); ia = 0; }
+  if (fnb) { vb = __int_as_float(0x7fc00000); ib = 0; }
 }
 
 template <int DTYPE>
@@ -277,8 +304,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
     // ---- arm_max_f32 over the 2048 signed values of each frame -------------------
     float va, vb;
     int ia, ib;
-    frame_max<0>(y, j, lane, va, ia);
-    frame_max<1>(y, j, lane, vb, ib);
+    pair_max(y, j, va, ia, vb, ib);
     if (lane == 0) {
       red[4 * wave + 0] = va;
       red[4 * wave + 1] = __int_as_float(ia);
