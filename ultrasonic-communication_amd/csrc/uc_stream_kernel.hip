@@ -327,17 +327,22 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     const size_t q0 = b * (size_t)HOP;                       // first output of this block
     const size_t room = p.n_out - q0;                        // > 0
     const int valid = room < (size_t)HOP ? (int)room : HOP;  // outputs of this block that exist
+    // Branch-free: the stores go through a buffer resource that covers exactly this block's `valid`
+    // outputs, so the wrapped-around head (o < 0: a huge unsigned offset) and the tail beyond the
+    // stream are dropped by the range check; v_sqrt_f32 (1 ulp) is far inside the stated tolerance.
     float best = -1.0f;
     int best_i = 0x7fffffff;
+    // no output buffer: a resource of zero records drops every store
+    const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.compressed ? p.compressed + q0 : nullptr, p.compressed ? valid * 4 : 0);
 #pragma unroll
     for (int t = 0; t < 16; t++) {
       const v2f y = v[pk_slot16((16 - t) & 15)];
       const float m2 = y.x * y.x + y.y * y.y;
       const int o = j + T * t - (L - 1);  // offset inside the block's hop
-      if (o >= 0 && o < valid) {
-        if (p.compressed) p.compressed[q0 + (size_t)o] = __builtin_sqrtf(m2);
-        if (m2 > best) { best = m2; best_i = o; }  // ascending t = ascending offset: first maximum
-      }
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_sqrtf(m2)), ro, o * 4, 0, 0);
+      const bool take = (unsigned)o < (unsigned)valid && m2 > best;  // ascending offset: first maximum
+      best = take ? m2 : best;
+      best_i = take ? o : best_i;
     }
     if (p.peaks) {
       const float wm = wave_max_f32(best);
