@@ -657,6 +657,40 @@ def test_iq_variant_at_1024_points_one_wave_per_frame(uchirp):
         uchirp.Engine(uchirp.RX_REAL, n=1024)   # only UC_IQ has a 1024-point plan
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_iq_frame_groups_ring_and_round_robin(uchirp, n, monkeypatch):
+    """The IQ kernels deal frames to workgroups in groups of up to 64 (one finaliser drain per group: a
+    ring of window partials in LDS, one lane per frame).  A tiny grid (UC_GRID, a tuning knob read at
+    uc_create) forces full groups, a ragged last group, several groups per workgroup and the
+    next-group prefetch on a batch small enough for the oracle: the records must be bit-identical to
+    the default launch (one frame per group) and agree with the oracle."""
+    frames_2048 = 150
+    x = _iq_stream(frames_2048, seed=11)
+    n_frames = (x.size - 26) // n            # 150 or 300: 2 or 4 full groups + a ragged one
+    ref_eng = uchirp.Engine(uchirp.IQ, n=n, mag_mean=1.0)
+    mm = (np.arange(2 * n_frames, dtype=np.float32) % 7.0) + 1.0     # per-frame noise floors (first of each pair used)
+    gs0, gst0 = ref_eng.process(x, n_frames=n_frames, mag_mean=mm)
+    for grid in ("1", "2", "3"):
+        monkeypatch.setenv("UC_GRID", grid)
+        e = uchirp.Engine(uchirp.IQ, n=n, mag_mean=1.0)
+        monkeypatch.delenv("UC_GRID")
+        gs, gst = e.process(x, n_frames=n_frames, mag_mean=mm)
+        assert (gs == uchirp.SYM_NONE).all() and len(gs) == n_frames
+        assert np.array_equal(gst.view(np.uint32), gst0.view(np.uint32)), "grid %s changes the records" % grid
+        # fewer frames than one group, and exactly one group
+        for cnt in (1, 63, 64, 65):
+            a, ast = e.process(x, n_frames=cnt, mag_mean=mm[:2 * cnt])
+            assert np.array_equal(ast.view(np.uint32), gst0[:cnt].view(np.uint32)), (grid, cnt)
+    o = uco.Oracle(uco.IQ, n=n, mag_mean=1.0)
+    rs, rst = o.process(x, halo=26, n_frames=n_frames, mag_mean=mm)
+    specs = [o.spectrum(x[f * n: f * n + n + 26], halo=26)[0] for f in range(0, n_frames, 7)]
+    scale = max(sp[: n // 2].max() for sp in specs)
+    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+        assert (np.abs(gst0[:, 0][fld].astype(np.float64) - rst[:, 0][fld]) / scale).max() <= MAG_TOL, fld
+    assert np.array_equal(gst0[:, 0]["mag_mean"], rst[:, 0]["mag_mean"].astype(np.float32))
+
+
 def test_unsupported_configurations_fail_loudly(uchirp):
     with pytest.raises(uchirp.UchirpError, match="bandwidth2"):
         uchirp.Engine(uchirp.RX_REAL, f1=25000.0)          # 2*bandwidth = 470 bins > the 191 the kernel evaluates

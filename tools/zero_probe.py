@@ -21,9 +21,11 @@ noise, _ = make_device_frames(nf, dev, seed=1)
 zeros = torch.zeros_like(noise)
 sym = torch.empty(nf, dtype=torch.uint8, device=dev)
 stream = torch.cuda.current_stream(dev)
-for name, vid, kw in (("rx_real", uchirp.RX_REAL, {}), ("dechirp_down", uchirp.DECHIRP_DOWN, {}), ("compress", uchirp.COMPRESS, {})):
+for name, vid, kw in (("rx_real", uchirp.RX_REAL, {}), ("dechirp_down", uchirp.DECHIRP_DOWN, {}), ("compress", uchirp.COMPRESS, {}),
+                      ("iq1024", uchirp.IQ, {"n": 1024}), ("iq", uchirp.IQ, {})):
     e = uchirp.Engine(vid, mag_mean=1000.0, **kw)
-    st = torch.empty((nf, e.spf, 8), dtype=torch.float32, device=dev)
+    nfr = (noise.numel() - e.halo - e.n) // e.n + 1
+    st = torch.empty((nfr, e.spf, 8), dtype=torch.float32, device=dev)
     for label, x in (("noise", noise), ("zeros", zeros), ("noise", noise), ("zeros", zeros)):
         ts = []
         for r in range(40):
@@ -32,9 +34,9 @@ for name, vid, kw in (("rx_real", uchirp.RX_REAL, {}), ("dechirp_down", uchirp.D
             if vid == uchirp.RX_REAL:
                 e.process(x, want_stats=False, symbols_out=sym, stream=stream.cuda_stream)
             else:
-                e.process(x, want_symbols=False, want_stats=True, stats_out=st, stream=stream.cuda_stream)
+                e.process(x, n_frames=nfr, want_symbols=False, want_stats=True, stats_out=st, stream=stream.cuda_stream)
             b.record(stream)
             torch.cuda.synchronize()
             ts.append(a.elapsed_time(b))
         t = np.median(ts[10:])
-        print("%-13s %-6s median %.3f ms -> %.1f Mframes/s" % (name, label, t, nf / t / 1e3), flush=True)
+        print("%-13s %-6s median %.3f ms -> %.1f Mframes/s" % (name, label, t, nfr / t / 1e3), flush=True)
