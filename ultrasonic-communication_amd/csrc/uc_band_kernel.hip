@@ -437,12 +437,15 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       v2f v[16];
       // ---- pass 1: window*chirp multiply, radix-16, Ns = 1 ------------------
       if (MODE == kModeRxReal) {
+        // sample t of this thread = half (t & 1) of pair t >> 1; the table products ride in the first
+        // butterfly additions (pk_dft4_scaled), so the pass starts at the second half of the DFT
+        v2f xc[8];
 #pragma unroll
-        for (int m = 0; m < 8; m++) {
-          const v2f x2 = cvt_pair<DTYPE>(xp[m]);
-          v[2 * m] = pk_scale_lo(wt[2 * m], x2);
-          v[2 * m + 1] = pk_scale_hi(wt[2 * m + 1], x2);
-        }
+        for (int m = 0; m < 8; m++) xc[m] = cvt_pair<DTYPE>(xp[m]);
+        pk_dft4_scaled<0>(v[0], v[4], v[8], v[12], xc[0], xc[2], xc[4], xc[6], wt[0], wt[4], wt[8], wt[12]);
+        pk_dft4_scaled<1>(v[1], v[5], v[9], v[13], xc[0], xc[2], xc[4], xc[6], wt[1], wt[5], wt[9], wt[13]);
+        pk_dft4_scaled<0>(v[2], v[6], v[10], v[14], xc[1], xc[3], xc[5], xc[7], wt[2], wt[6], wt[10], wt[14]);
+        pk_dft4_scaled<1>(v[3], v[7], v[11], v[15], xc[1], xc[3], xc[5], xc[7], wt[3], wt[7], wt[11], wt[15]);
       } else if (kPair) {
         // re = frame a * ref * hann, im = frame b * ref * hann: two real spectra in one transform
 #pragma unroll
@@ -462,7 +465,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // prefetch the next frame a whole frame time ahead (HBM latency under load is
       // microseconds; at 3 waves/SIMD the 16 registers are free)
       if (run == kRuns - 1 && has_next) load_unit(fnext);
-      pk_dft16(v, K, H);
+      if (MODE == kModeRxReal) pk_dft16_finish(v, K, H);
+      else pk_dft16(v, K, H);
       UC_STAMP(0);
       // B4, placed AFTER the register-only part of pass 1: the wave that finished the previous
       // frame first computes ahead instead of idling (wave 1 carries the extra pruned round).
@@ -538,6 +542,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             eh = pk_cfmac(eh, w2, bv[2]); oh = pk_cfmac(oh, w2, bv[3]);
             el = pk_cfma(el, w2, av[0]); ol = pk_cfma(ol, w2, av[1]);
             eh = pk_cfmac(eh, w2, bv[0]); oh = pk_cfmac(oh, w2, bv[1]);
+            // bin 0 (w = 1): el / ol are the sums of the even / odd terms, so Z[n/2] = sum (-1)^t a_t = el - ol
+            const v2f zn = el - ol;
             const v2f zl = pk_cfma(ol, w1, el);   // Z[k]
             const v2f zh = pk_cfmac(oh, w1, eh);  // Z[n-k] (conjugated twiddles)
             const v2f sa = pk_add_conj(zl, zh);
@@ -551,9 +557,6 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
               // Q2: the packed RFFT stores Re X[n/2] in the imaginary slot of bin 0, so the
               // reference's mag[0] is hypot(X0, X[n/2]) (receiver/Src/main.c:178).
               // sa.x = 2 Re Z[0] = 2 X_up[0], sb.y = 2 Im Z[0] = 2 X_down[0], zn = Z[n/2].
-              v2f zn = av[0];
-#pragma unroll
-              for (int t = 1; t < 8; t++) zn = (t & 1) ? (zn - av[t]) : (zn + av[t]);
               ma = sa.x * sa.x;
               mb = sb.y * sb.y;
               if (!p.true_dc) {

@@ -200,10 +200,53 @@ __device__ __forceinline__ void pk_dft4(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {
       : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(a1), "=&v"(d));
 }
 
+// forward 4-point DFT of w_i * s_i, i = 0..3, where the REAL samples s_i are the low (HI = 0) or high
+// (HI = 1) halves of the register pairs x_i: the table products are folded into the first butterfly
+// additions as fused multiply-adds (2 multiplies + 4 FMAs + 4 additions instead of 4 + 8).
+template <int HI>
+__device__ __forceinline__ void pk_dft4_scaled(v2f& X0, v2f& X1, v2f& X2, v2f& X3, v2f x0, v2f x1, v2f x2, v2f x3, v2f w0,
+                                               v2f w1, v2f w2, v2f w3) {
+  v2f p0, p1, a1, d;
+  if (HI) {
+    asm("v_pk_mul_f32 %4, %12, %8 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                              // p0 = w0 s0
+        "v_pk_mul_f32 %5, %13, %9 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                              // p1 = w1 s1
+        "v_pk_fma_f32 %6, %14, %10, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"  // a1 = p0 - w2 s2
+        "v_pk_fma_f32 %0, %14, %10, %4 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                     // a0 = p0 + w2 s2
+        "v_pk_fma_f32 %7, %15, %11, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"  // d  = p1 - w3 s3
+        "v_pk_fma_f32 %1, %15, %11, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                     // a2 = p1 + w3 s3
+        "v_pk_add_f32 %2, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"                                   // X2 = a0 - a2
+        "v_pk_add_f32 %0, %0, %1\n\t"                                                            // X0 = a0 + a2
+        "v_pk_add_f32 %1, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"                   // X1 = a1 + (-j) d
+        "v_pk_add_f32 %3, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"                        // X3 = a1 - (-j) d
+        : "=&v"(X0), "=&v"(X1), "=&v"(X2), "=&v"(X3), "=&v"(p0), "=&v"(p1), "=&v"(a1), "=&v"(d)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  } else {
+    asm("v_pk_mul_f32 %4, %12, %8 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %5, %13, %9 op_sel_hi:[1,0]\n\t"
+        "v_pk_fma_f32 %6, %14, %10, %4 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %0, %14, %10, %4 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %7, %15, %11, %5 op_sel_hi:[1,0,1] neg_lo:[0,1,0] neg_hi:[0,1,0]\n\t"
+        "v_pk_fma_f32 %1, %15, %11, %5 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_add_f32 %2, %0, %1 neg_lo:[0,1] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %0, %0, %1\n\t"
+        "v_pk_add_f32 %1, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]\n\t"
+        "v_pk_add_f32 %3, %6, %7 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"
+        : "=&v"(X0), "=&v"(X1), "=&v"(X2), "=&v"(X3), "=&v"(p0), "=&v"(p1), "=&v"(a1), "=&v"(d)
+        : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+  }
+}
+
+// second half of the 16-point DFT: the fixed twiddles and the four output butterflies
+__device__ __forceinline__ void pk_dft16_finish(v2f (&v)[16], v2f K, v2f H);
+
 // forward 16-point DFT as 4 x 4; X[t] ends up in v[4*(t&3) + (t>>2)]
 __device__ __forceinline__ void pk_dft16(v2f (&v)[16], v2f K, v2f H) {
 #pragma unroll
   for (int n2 = 0; n2 < 4; n2++) pk_dft4(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+  pk_dft16_finish(v, K, H);
+}
+
+__device__ __forceinline__ void pk_dft16_finish(v2f (&v)[16], v2f K, v2f H) {
   v[5] = pk_mul_w1(v[5], K);
   v[6] = pk_mul_w2(v[6], H);
   v[7] = pk_mul_w3(v[7], K);
