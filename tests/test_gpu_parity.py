@@ -408,6 +408,40 @@ def test_device_tensors_async_and_properties_at_scale(uchirp):
     assert np.array_equal(sym[:256].cpu().numpy()[clear], rs[clear])
 
 
+def test_one_million_frames_of_the_bench_workload_match_the_oracle(uchirp):
+    """SURVEY section 7 gate 4 at BASELINE configs[1]'s full size: the bench's own device-generated batch
+    (1 Mi x 2048 fp32 frames, -10 dB) decoded in ONE launch, every symbol compared with the float64
+    oracle (all host threads, 64 Ki frames at a time); declared near-ties (decision margin < 1e-3, or
+    an snr within 1e-3 of the threshold) are counted and excluded."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from bench import make_device_frames
+    dev = torch.device("cuda:0")
+    n_frames = 1 << 20
+    frames, bits = make_device_frames(n_frames, dev, seed=1234, snr_db=-10.0)
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+    sym, _ = e.process(frames, want_stats=False)
+    torch.cuda.synchronize()
+    sym = sym.cpu().numpy()
+    o = uco.Oracle(uco.RX_REAL, mag_mean=1000.0)
+    chunk = 1 << 16
+    ties = mismatches = 0
+    for s0 in range(0, n_frames, chunk):
+        host = frames[s0:s0 + chunk].cpu().numpy()
+        rs, rst = o.process(host, precision=uco.F64, threads=os.cpu_count() or 1)
+        su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+        margin = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30)
+        thr_close = (np.abs(su - 2.0) < 1e-3 * np.abs(su)) | (np.abs(sd - 2.0) < 1e-3 * np.abs(sd))
+        clear = (margin >= MARGIN) & ~thr_close
+        ties += int((~clear).sum())
+        mismatches += int((sym[s0:s0 + chunk][clear] != rs[clear]).sum())
+    assert mismatches == 0, "%d of %d symbols differ from the float64 oracle" % (mismatches, n_frames)
+    assert ties <= 0.02 * n_frames, "too many declared near-ties: %d" % ties
+    print("1 Mi frames: 0 mismatches, %d declared near-ties" % ties)
+
+
 def test_compress_variant_fft_h_ifft(uchirp):
     """UC_COMPRESS (experiments/chirp_compression_time_domain): signed peak of
     IFFT(FFT(hann*x) * H_down) and its index, frame pairs sharing one complex transform."""
