@@ -22,6 +22,7 @@
 // HBM traffic: 2 x 8 KiB in, 2 x 32 B stats out per pair.
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
+#include "uc_xform.hpp"
 
 namespace uc {
 
@@ -134,25 +135,8 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   const v2f tw3_1 = buf_ld64(rs_tw, (j & (kN - 1)) * 8, 0);        // W_2048^j
   const v2f tw3_2 = buf_ld64(rs_tw, ((2 * j) & (kN - 1)) * 8, 0);  // W_2048^2j
   const v2f tw3_4 = buf_ld64(rs_tw, ((4 * j) & (kN - 1)) * 8, 0);  // W_2048^4j
-#pragma unroll
-  for (int r = 0; r < 2; r++) {
-    const int e = j + T * r;  // t = e >> 4, k = e & 15
-    lds_st(tw2t, e, buf_ld64(rs_tw, ((8 * (e >> 4) * (e & 15)) & (kN - 1)) * 8, 0));
-  }
-  lds_st(twBt, j, buf_ld64(rs_tw, ((16 * (j >> 3) * (j & 7)) & (kN - 1)) * 8, 0));  // t = j >> 3, k = j & 7
-
-  // LDS addresses (complex units)
-  const int s1 = j & 15;
-  const int wr1 = 16 * j;                                   // forward exchange 1: + (t ^ s1)
-  const int rd1e = (j & ~15) + ((j & 15) ^ (j >> 4));       // + 128 t, t even
-  const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);   // + 128 t, t odd
-  const int wr2 = (j >> 4) * 256 + (j & 15);                // forward exchange 2: + 16 t
-  const int rdA = j ^ ((j >> 4) & 7);                       // inverse exchange A read: + 128 t
-  // inverse exchange B write: element (j>>3)*128 + (j&7) + 8 t, swizzled by flipping bit 3
-  // for odd j>>3, i.e. t -> t ^ ((j>>3)&1): two bases, one for even and one for odd t
-  const int wrBe = (j >> 3) * 128 + (j & 7) + 8 * ((j >> 3) & 1);
-  const int wrBo = (j >> 3) * 128 + (j & 7) - 8 * ((j >> 3) & 1);
-  const int rdBe = j, rdBo = j ^ 8;                         // inverse exchange B read: + 128 t
+  xf_fill_twiddle_tables(tw2t, twBt, rs_tw, j);
+  const XfAddr xa = xf_addresses(j);
 
   const bool has_mm = p.mag_mean != nullptr;
 
@@ -195,111 +179,35 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
 
   bool pending = false;
   for (; q < qend; q++) {
-    int s1v = s1;
+    int s1v = xa.s1;
     v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
     asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
 
     // ---- window, forward pass 1 (registers -> tile A) -------------------------------
-    v2f v[16];
+    {
+      v2f v[16];
 #pragma unroll
-    for (int m = 0; m < 8; m++) {
-      // hann * x, one float32 rounding, as windowing() does (chirp.c:47-50)
-      v[2 * m] = pk_scale_lo(cvt_pair<DTYPE>(xp[2 * m]), hw[m]);
-      v[2 * m + 1] = pk_scale_hi(cvt_pair<DTYPE>(xp[2 * m + 1]), hw[m]);
+      for (int m = 0; m < 8; m++) {
+        // hann * x, one float32 rounding, as windowing() does (chirp.c:47-50)
+        v[2 * m] = pk_scale_lo(cvt_pair<DTYPE>(xp[2 * m]), hw[m]);
+        v[2 * m + 1] = pk_scale_hi(cvt_pair<DTYPE>(xp[2 * m + 1]), hw[m]);
+      }
+      if (q + 1 < qend) load_pair(q + 1);  // a whole pair time ahead
+      pk_dft16(v, K, H);
+      xf_store1(ta, xa, s1v, v);
     }
-    if (q + 1 < qend) load_pair(q + 1);  // a whole pair time ahead
-    pk_dft16(v, K, H);
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(ta, wr1 + (t ^ s1v), v[pk_slot16(t)]);
     __syncthreads();
     if (pending) publish(q - 1);
 
-    // ---- forward pass 2 (A -> B) ----------------------------------------------------
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(ta, ((t & 1) ? rd1o : rd1e) + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2t, 16 * t + (j & 15)));
-    pk_dft16(v, K, H);
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(tb, wr2 + 16 * t, v[pk_slot16(t)]);
+    xf_fwd2(ta, tb, tw2t, xa, j, K, H);                        // forward pass 2 (A -> B)
     __syncthreads();
-
-    // ---- forward pass 3 (full radix-8), x H/N, inverse pass A (radix-8) (B -> A) ----
-    // butterfly b = j (h = 0) and b = j + 128 (h = 1): X[b + 256 t], t = 0..7
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int b = j + T * h;
-      v2f u[8];
-#pragma unroll
-      for (int t = 0; t < 8; t++) u[t] = lds_ld(tb, b + 256 * t);
-      __builtin_amdgcn_sched_barrier(0);
-      v2f w[8];
-      if (h == 0) {
-        w[1] = t3a; w[2] = t3b; w[4] = t3c;
-      } else {  // W_2048^(t (j+128)) = W_2048^(t j) W_16^t
-        w[1] = pk_mul_w1(t3a, K); w[2] = pk_mul_w2(t3b, H); w[4] = pk_mul_mj(t3c);
-      }
-      w[3] = pk_cmul(w[1], w[2]);
-      w[5] = pk_cmul(w[1], w[4]);
-      w[6] = pk_cmul(w[2], w[4]);
-      w[7] = pk_cmul(w[3], w[4]);
-#pragma unroll
-      for (int t = 1; t < 8; t++) u[t] = pk_cmul(u[t], w[t]);
-      pk_dft8(u, H);
-      // spectrum bin k = b + 256 t sits in u[slot8(t)]: multiply by H_down[k] / N
-#pragma unroll
-      for (int t = 0; t < 8; t++) u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hres[h][t]);
-      // inverse radix-8, Ns = 1 (no twiddles): inputs in natural t order
-      v2f g[8];
-#pragma unroll
-      for (int t = 0; t < 8; t++) g[t] = u[pk_slot8(t)];
-      pk_dft8(g, H);
-      // IDFT8[t] = DFT8[(8 - t) & 7]; inverse exchange A: element 8 b + t, swizzled phys = o ^ ((o >> 4) & 7)
-#pragma unroll
-      for (int t = 0; t < 8; t++) lds_st(ta, 8 * b + (t ^ ((b >> 1) & 7)), g[pk_slot8((8 - t) & 7)]);
-    }
+    xf_fwd3_h_invA(tb, ta, hres, t3a, t3b, t3c, j, K, H);     // forward pass 3, x H/N, inverse pass A (B -> A)
     __syncthreads();
-
-    // ---- inverse pass B: radix-16, Ns = 8, conj twiddles W_128^(t k), k = j & 7 (A -> B)
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(ta, rdA + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], lds_ld(twBt, 8 * t + (j & 7)));
-    pk_dft16(v, K, H);
-    // output t of the inverse = forward output (16 - t) & 15; element (j>>3)*128 + (j&7) + 8 t
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(tb, ((t & 1) ? wrBo : wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
+    xf_invB(ta, tb, twBt, xa, j, K, H);                        // inverse pass B (A -> B)
     __syncthreads();
-
-    // ---- inverse pass C: radix-16, Ns = 128, conj twiddles W_2048^(t j) (B -> registers)
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tb, ((t & 1) ? rdBo : rdBe) + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
-    {
-      // W_2048^(t j), t = 1..15, as products of the three resident powers (at most three factors deep)
-      v2f w[16];
-      w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = pk_cmul(t3c, t3c);
-      w[3] = pk_cmul(w[1], w[2]);
-      w[5] = pk_cmul(w[1], w[4]);
-      w[6] = pk_cmul(w[2], w[4]);
-      w[9] = pk_cmul(w[1], w[8]);
-      w[10] = pk_cmul(w[2], w[8]);
-      w[12] = pk_cmul(w[4], w[8]);
-      w[7] = pk_cmul(w[3], w[4]);
-      w[11] = pk_cmul(w[3], w[8]);
-      w[13] = pk_cmul(w[5], w[8]);
-      w[14] = pk_cmul(w[6], w[8]);
-      w[15] = pk_cmul(w[7], w[8]);
-#pragma unroll
-      for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], w[t]);
-    }
-    pk_dft16(v, K, H);
-    // y[j + 128 t] = inverse output t = v[slot16((16 - t) & 15)]; re = frame a, im = frame b
+    // inverse pass C (B -> registers): y[t] = sample j + 128 t; re = frame a, im = frame b
     v2f y[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) y[t] = v[pk_slot16((16 - t) & 15)];
+    xf_invC(tb, y, xa, t3a, t3b, t3c, K, H);
 
     // ---- arm_max_f32 over the 2048 signed values of each frame -------------------
     float va, vb;

@@ -27,10 +27,7 @@
 // HBM traffic per input sample: 4 B in + 4/D B out (+ 8 B of peak record per block).
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
-
-#ifndef UC_STREAM_EXP
-#define UC_STREAM_EXP 0  // diagnostic builds: 1 = no transforms, 2 = no input loads
-#endif
+#include "uc_xform.hpp"
 
 namespace uc {
 
@@ -114,29 +111,10 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   v2f rotu[OPT];   // e^{-jw D (OPT j + u)}: rotation of this thread's outputs inside a sub-tile
 #pragma unroll
   for (int u = 0; u < OPT; u++) rotu[u] = buf_ld64(rs_rot, (OPT * j + u) * 8, 0);
-  {
-    float* tw2t = lds + kTw2Off;
-    float* twBt = lds + kTwBOff;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-      const int e = j + T * r;  // t = e >> 4, k = e & 15
-      lds_st(tw2t, e, buf_ld64(rs_tw, ((8 * (e >> 4) * (e & 15)) & (kN - 1)) * 8, 0));
-    }
-    lds_st(twBt, j, buf_ld64(rs_tw, ((16 * (j >> 3) * (j & 7)) & (kN - 1)) * 8, 0));  // t = j >> 3, k = j & 7
-  }
+  xf_fill_twiddle_tables(lds + kTw2Off, lds + kTwBOff, rs_tw, j);
   const float* tw2t = lds + kTw2Off;
   const float* twBt = lds + kTwBOff;
-
-  // LDS addresses of the transform (complex units), as uc_full_kernel.hip
-  const int s1 = j & 15;
-  const int wr1 = 16 * j;
-  const int rd1e = (j & ~15) + ((j & 15) ^ (j >> 4));
-  const int rd1o = (j & ~15) + ((j & 15) ^ (j >> 4) ^ 8);
-  const int wr2 = (j >> 4) * 256 + (j & 15);
-  const int rdA = j ^ ((j >> 4) & 7);
-  const int wrBe = (j >> 3) * 128 + (j & 7) + 8 * ((j >> 3) & 1);
-  const int wrBo = (j >> 3) * 128 + (j & 7) - 8 * ((j >> 3) & 1);
-  const int rdBe = j, rdBo = j ^ 8;
+  const XfAddr xa = xf_addresses(j);  // LDS addresses of the transform, as uc_full_kernel.hip
 
   // one sub-tile of input: 4096 + 28 samples starting at sample (blk HOP D + sub 4096) of the buffer
   // (that sample is 26 taps behind the first output of the sub-tile); loads past the end of the
@@ -148,14 +126,9 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     const size_t left = p.n_samples > first ? p.n_samples - first : 0;
     const int recs = left < (size_t)(kSubIn + 28) ? (int)left : kSubIn + 28;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.samples) + first * 4, recs * 4);
-#if UC_STREAM_EXP == 2
-    if (blk > 1u << 30)
-#endif
-    {
 #pragma unroll
-      for (int r = 0; r < 8; r++) dst[r] = buf_ld128(rx, voff16, T * 16 * r);
-      dst[8] = buf_ld128(rx, voff16, kSubIn * 4);
-    }
+    for (int r = 0; r < 8; r++) dst[r] = buf_ld128(rx, voff16, T * 16 * r);
+    dst[8] = buf_ld128(rx, voff16, kSubIn * 4);
   };
 
   issue_loads(b, 0, stg[0]);
@@ -164,7 +137,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   float* tb = lds;  // second transform tile: the image area is free once the last window is read
 
   while (true) {
-    int s1v = s1;
+    int s1v = xa.s1;
     v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
     asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
     const size_t bn = b + 1;
@@ -226,103 +199,26 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     }
     __syncthreads();
 
-    // The transforms ping-pong between the two tiles (tile -> tb -> tile -> tb -> tile): every
-    // exchange is write, ONE barrier, read.
-    // ---- forward pass 1 -------------------------------------------------------------------------
-    v2f v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, j + T * t);
-    __builtin_amdgcn_sched_barrier(0);
-#if UC_STREAM_EXP == 1
-    if (p.n_out != 12345) goto outputs;
-#endif
-    pk_dft16(v, K, H);
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(tb, wr1 + (t ^ s1v), v[pk_slot16(t)]);
-    __syncthreads();
-
-    // ---- forward pass 2: twiddles W_256^(t k), k = j & 15 ------------------------------------------
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tb, ((t & 1) ? rd1o : rd1e) + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2t, 16 * t + (j & 15)));
-    pk_dft16(v, K, H);
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(tile, wr2 + 16 * t, v[pk_slot16(t)]);
-    __syncthreads();
-
-    // ---- forward pass 3 (radix-8), x H/N, inverse pass A (radix-8) ----------------------------------
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-      const int bf = j + T * h;
-      v2f u[8];
-#pragma unroll
-      for (int t = 0; t < 8; t++) u[t] = lds_ld(tile, bf + 256 * t);
-      __builtin_amdgcn_sched_barrier(0);
-      v2f w[8];
-      if (h == 0) {
-        w[1] = t3a; w[2] = t3b; w[4] = t3c;
-      } else {  // W_2048^(t (j+128)) = W_2048^(t j) W_16^t
-        w[1] = pk_mul_w1(t3a, K); w[2] = pk_mul_w2(t3b, H); w[4] = pk_mul_mj(t3c);
-      }
-      w[3] = pk_cmul(w[1], w[2]);
-      w[5] = pk_cmul(w[1], w[4]);
-      w[6] = pk_cmul(w[2], w[4]);
-      w[7] = pk_cmul(w[3], w[4]);
-#pragma unroll
-      for (int t = 1; t < 8; t++) u[t] = pk_cmul(u[t], w[t]);
-      pk_dft8(u, H);
-#pragma unroll
-      for (int t = 0; t < 8; t++) u[pk_slot8(t)] = pk_cmul(u[pk_slot8(t)], hres[h][t]);
-      v2f g[8];
-#pragma unroll
-      for (int t = 0; t < 8; t++) g[t] = u[pk_slot8(t)];
-      pk_dft8(g, H);
-      // IDFT8[t] = DFT8[(8 - t) & 7]; element 8 bf + t, swizzled phys = o ^ ((o >> 4) & 7)
-#pragma unroll
-      for (int t = 0; t < 8; t++) lds_st(tb, 8 * bf + (t ^ ((bf >> 1) & 7)), g[pk_slot8((8 - t) & 7)]);
-    }
-    __syncthreads();
-
-    // ---- inverse pass B: radix-16, conj twiddles W_128^(t k), k = j & 7 -------------------------------
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tb, rdA + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], lds_ld(twBt, 8 * t + (j & 7)));
-    pk_dft16(v, K, H);
-#pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(tile, ((t & 1) ? wrBo : wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
-    __syncthreads();
-
-    // ---- inverse pass C: radix-16, conj twiddles W_2048^(t j) ------------------------------------------
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rdBo : rdBe) + 128 * t);
-    __builtin_amdgcn_sched_barrier(0);
+    // The transforms (uc_xform.hpp) ping-pong between the two tiles (tile -> tb -> tile -> tb -> tile):
+    // every exchange is write, ONE barrier, read.
     {
-      // W_2048^(t j), t = 1..15, as products of the three resident powers (at most three factors deep)
-      v2f w[16];
-      w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = pk_cmul(t3c, t3c);
-      w[3] = pk_cmul(w[1], w[2]);
-      w[5] = pk_cmul(w[1], w[4]);
-      w[6] = pk_cmul(w[2], w[4]);
-      w[9] = pk_cmul(w[1], w[8]);
-      w[10] = pk_cmul(w[2], w[8]);
-      w[12] = pk_cmul(w[4], w[8]);
-      w[7] = pk_cmul(w[3], w[4]);
-      w[11] = pk_cmul(w[3], w[8]);
-      w[13] = pk_cmul(w[5], w[8]);
-      w[14] = pk_cmul(w[6], w[8]);
-      w[15] = pk_cmul(w[7], w[8]);
+      v2f v[16];  // forward pass 1
 #pragma unroll
-      for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], w[t]);
+      for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, j + T * t);
+      __builtin_amdgcn_sched_barrier(0);
+      pk_dft16(v, K, H);
+      xf_store1(tb, xa, s1v, v);
     }
-    pk_dft16(v, K, H);
+    __syncthreads();
+    xf_fwd2(tb, tile, tw2t, xa, j, K, H);                       // forward pass 2
+    __syncthreads();
+    xf_fwd3_h_invA(tile, tb, hres, t3a, t3b, t3c, j, K, H);    // forward pass 3, x H/N, inverse pass A
+    __syncthreads();
+    xf_invB(tb, tile, twBt, xa, j, K, H);                       // inverse pass B
+    __syncthreads();
+    v2f y16[16];                                                // inverse pass C: y16[t] = output j + 128 t
+    xf_invC(tile, y16, xa, t3a, t3b, t3c, K, H);
 
-#if UC_STREAM_EXP == 1
-  outputs:
-#endif
     // ---- |y[i]|, i = j + 128 t; outputs i >= L-1 are free of circular wrap-around ---------------------
     const size_t q0 = b * (size_t)HOP;                       // first output of this block
     const size_t room = p.n_out - q0;                        // > 0
@@ -336,7 +232,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     const __amdgpu_buffer_rsrc_t ro = make_rsrc(p.compressed ? p.compressed + q0 : nullptr, p.compressed ? valid * 4 : 0);
 #pragma unroll
     for (int t = 0; t < 16; t++) {
-      const v2f y = v[pk_slot16((16 - t) & 15)];
+      const v2f y = y16[t];
       const float m2 = y.x * y.x + y.y * y.y;
       const int o = j + T * t - (L - 1);  // offset inside the block's hop
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_sqrtf(m2)), ro, o * 4, 0, 0);
