@@ -50,12 +50,32 @@ def make_device_frames(n_frames, device, seed, snr_db=-10.0, amp=1000.0):
     return frames, bits.to(torch.uint8)
 
 
+def host_cpu_share():
+    """CPUs this process may actually use: the smaller of the affinity mask and the cgroup CPU
+    quota (a one-GPU box exposes all 256 hardware threads but schedules 16 CPUs' worth of time:
+    256 OpenMP threads there run 4x slower than 16)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]          # cgroup v2
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())          # cgroup v1
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(frames_host, mag_mean):
     """The CPU restatement (oracle, float32 butterflies like CMSIS-DSP) timed on the
     host cores of this box on a bounded sample of the same frames."""
     from oracle import uco
     o = uco.Oracle(uco.RX_REAL, mag_mean=mag_mean)
-    cores = os.cpu_count() or 1
+    cores = host_cpu_share()
     n = frames_host.shape[0]
     o.process(frames_host[:8192], precision=uco.F32, threads=cores)  # warm the thread pool
     passes, dt = 0, 0.0
@@ -68,7 +88,8 @@ def cpu_baseline(frames_host, mag_mean):
     rs, _ = o.process(frames_host[:4096], precision=uco.F64, threads=cores)
     return {"symbols_f64_oracle_head": rs, "value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "%d passes over the first %d frames of the same batch, oracle/uc_oracle.c "
-                      "(float32 butterflies), OpenMP %d threads, %.1f s" % (passes, n // passes, cores, dt)}
+                      "(float32 butterflies), OpenMP %d threads = this box's CPU share (%d hardware threads visible), "
+                      "%.1f s" % (passes, n // passes, cores, os.cpu_count() or 1, dt)}
 
 
 def stream_measurement(args, eng, frames, rank):

@@ -411,13 +411,13 @@ def test_device_tensors_async_and_properties_at_scale(uchirp):
 def test_one_million_frames_of_the_bench_workload_match_the_oracle(uchirp):
     """SURVEY section 7 gate 4 at BASELINE configs[1]'s full size: the bench's own device-generated batch
     (1 Mi x 2048 fp32 frames, -10 dB) decoded in ONE launch, every symbol compared with the float64
-    oracle (all host threads, 64 Ki frames at a time); declared near-ties (decision margin < 1e-3, or
+    oracle (this box's CPU share, 64 Ki frames at a time); declared near-ties (decision margin < 1e-3, or
     an snr within 1e-3 of the threshold) are counted and excluded."""
     import os
     import sys
     import torch
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-    from bench import make_device_frames
+    from bench import host_cpu_share, make_device_frames
     dev = torch.device("cuda:0")
     n_frames = 1 << 20
     frames, bits = make_device_frames(n_frames, dev, seed=1234, snr_db=-10.0)
@@ -430,7 +430,7 @@ def test_one_million_frames_of_the_bench_workload_match_the_oracle(uchirp):
     ties = mismatches = 0
     for s0 in range(0, n_frames, chunk):
         host = frames[s0:s0 + chunk].cpu().numpy()
-        rs, rst = o.process(host, precision=uco.F64, threads=os.cpu_count() or 1)
+        rs, rst = o.process(host, precision=uco.F64, threads=host_cpu_share())
         su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
         margin = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30)
         thr_close = (np.abs(su - 2.0) < 1e-3 * np.abs(su)) | (np.abs(sd - 2.0) < 1e-3 * np.abs(sd))
