@@ -32,6 +32,10 @@ constexpr int T = kBandThreads;  // 128
 #ifndef UC_COMPRESS_WAVES
 #define UC_COMPRESS_WAVES 2
 #endif
+#ifndef UC_COMPRESS_RESIDENT_TW
+#define UC_COMPRESS_RESIDENT_TW 1
+#endif
+constexpr bool kResTw = UC_COMPRESS_RESIDENT_TW != 0;
 constexpr int kRedOff = 4 * kN;  // floats: per-wave reduction results after the two tiles
 constexpr int kTw2Off = kRedOff + 16;
 constexpr int kTwBOff = kTw2Off + 2 * 256;
@@ -137,6 +141,13 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   const v2f tw3_4 = buf_ld64(rs_tw, ((4 * j) & (kN - 1)) * 8, 0);  // W_2048^4j
   xf_fill_twiddle_tables(tw2t, twBt, rs_tw, j);
   const XfAddr xa = xf_addresses(j);
+  // pass-3 and pass-C twiddles resident (the registers are there at 2 waves/SIMD): 44 fewer products per pair
+  v2f w3r[2][8], wCr[16];
+  if (kResTw) {
+    xf_twiddles3(w3r[0], 0, tw3_1, tw3_2, tw3_4, K, H);
+    xf_twiddles3(w3r[1], 1, tw3_1, tw3_2, tw3_4, K, H);
+    xf_twiddlesC(wCr, tw3_1, tw3_2, tw3_4);
+  }
 
   const bool has_mm = p.mag_mean != nullptr;
 
@@ -201,13 +212,13 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
 
     xf_fwd2(ta, tb, tw2t, xa, j, K, H);                        // forward pass 2 (A -> B)
     __syncthreads();
-    xf_fwd3_h_invA(tb, ta, hres, t3a, t3b, t3c, j, K, H);     // forward pass 3, x H/N, inverse pass A (B -> A)
+    xf_fwd3_h_invA<kResTw>(tb, ta, hres, w3r, t3a, t3b, t3c, j, K, H);  // forward pass 3, x H/N, inverse pass A (B -> A)
     __syncthreads();
     xf_invB(ta, tb, twBt, xa, j, K, H);                        // inverse pass B (A -> B)
     __syncthreads();
     // inverse pass C (B -> registers): y[t] = sample j + 128 t; re = frame a, im = frame b
     v2f y[16];
-    xf_invC(tb, y, xa, t3a, t3b, t3c, K, H);
+    xf_invC<kResTw>(tb, y, xa, wCr, t3a, t3b, t3c, K, H);
 
     // ---- arm_max_f32 over the 2048 signed values of each frame -------------------
     float va, vb;

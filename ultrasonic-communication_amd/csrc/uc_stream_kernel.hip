@@ -212,12 +212,12 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     __syncthreads();
     xf_fwd2(tb, tile, tw2t, xa, j, K, H);                       // forward pass 2
     __syncthreads();
-    xf_fwd3_h_invA(tile, tb, hres, t3a, t3b, t3c, j, K, H);    // forward pass 3, x H/N, inverse pass A
+    xf_fwd3_h_invA<false>(tile, tb, hres, hres, t3a, t3b, t3c, j, K, H);  // forward pass 3, x H/N, inverse pass A
     __syncthreads();
     xf_invB(tb, tile, twBt, xa, j, K, H);                       // inverse pass B
     __syncthreads();
     v2f y16[16];                                                // inverse pass C: y16[t] = output j + 128 t
-    xf_invC(tile, y16, xa, t3a, t3b, t3c, K, H);
+    xf_invC<false>(tile, y16, xa, y16, t3a, t3b, t3c, K, H);
 
     // ---- |y[i]|, i = j + 128 t; outputs i >= L-1 are free of circular wrap-around ---------------------
     const size_t q0 = b * (size_t)HOP;                       // first output of this block

@@ -80,11 +80,41 @@ __device__ __forceinline__ void xf_fwd2(const float* src, float* dst, const floa
   for (int t = 0; t < 16; t++) lds_st(dst, a.wr2 + 16 * t, v[pk_slot16(t)]);
 }
 
+// pass-3 twiddles W_2048^(t (j + 128 h)), t = 1..7, from the three resident powers t3a/b/c = W_2048^j, ^2j, ^4j
+__device__ __forceinline__ void xf_twiddles3(v2f (&w)[8], int h, v2f t3a, v2f t3b, v2f t3c, v2f K, v2f H) {
+  if (h == 0) {
+    w[1] = t3a; w[2] = t3b; w[4] = t3c;
+  } else {  // W_2048^(t (j+128)) = W_2048^(t j) W_16^t
+    w[1] = pk_mul_w1(t3a, K); w[2] = pk_mul_w2(t3b, H); w[4] = pk_mul_mj(t3c);
+  }
+  w[3] = pk_cmul(w[1], w[2]);
+  w[5] = pk_cmul(w[1], w[4]);
+  w[6] = pk_cmul(w[2], w[4]);
+  w[7] = pk_cmul(w[3], w[4]);
+}
+
+// pass-C twiddles W_2048^(t j), t = 1..15, as products of the three resident powers (at most three factors deep)
+__device__ __forceinline__ void xf_twiddlesC(v2f (&w)[16], v2f t3a, v2f t3b, v2f t3c) {
+  w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = pk_cmul(t3c, t3c);
+  w[3] = pk_cmul(w[1], w[2]);
+  w[5] = pk_cmul(w[1], w[4]);
+  w[6] = pk_cmul(w[2], w[4]);
+  w[9] = pk_cmul(w[1], w[8]);
+  w[10] = pk_cmul(w[2], w[8]);
+  w[12] = pk_cmul(w[4], w[8]);
+  w[7] = pk_cmul(w[3], w[4]);
+  w[11] = pk_cmul(w[3], w[8]);
+  w[13] = pk_cmul(w[5], w[8]);
+  w[14] = pk_cmul(w[6], w[8]);
+  w[15] = pk_cmul(w[7], w[8]);
+}
+
 // forward pass 3 (full radix-8) x H/N, inverse pass A (radix-8, no twiddles).
-// butterfly b = j (h = 0) and b = j + 128 (h = 1): X[b + 256 t], t = 0..7; hres[h][t] = H[b + 256 t] / N;
-// t3a/b/c = W_2048^j, ^2j, ^4j
-__device__ __forceinline__ void xf_fwd3_h_invA(const float* src, float* dst, const v2f (&hres)[2][8], v2f t3a, v2f t3b,
-                                               v2f t3c, int j, v2f K, v2f H) {
+// butterfly b = j (h = 0) and b = j + 128 (h = 1): X[b + 256 t], t = 0..7; hres[h][t] = H[b + 256 t] / N.
+// RESIDENT: the twiddles come from w3 (kept in registers by the caller), else they are derived per call.
+template <bool RESIDENT>
+__device__ __forceinline__ void xf_fwd3_h_invA(const float* src, float* dst, const v2f (&hres)[2][8], const v2f (&w3)[2][8],
+                                               v2f t3a, v2f t3b, v2f t3c, int j, v2f K, v2f H) {
 #pragma unroll
   for (int h = 0; h < 2; h++) {
     const int b = j + kXfThreads * h;
@@ -93,15 +123,12 @@ __device__ __forceinline__ void xf_fwd3_h_invA(const float* src, float* dst, con
     for (int t = 0; t < 8; t++) u[t] = lds_ld(src, b + 256 * t);
     __builtin_amdgcn_sched_barrier(0);
     v2f w[8];
-    if (h == 0) {
-      w[1] = t3a; w[2] = t3b; w[4] = t3c;
-    } else {  // W_2048^(t (j+128)) = W_2048^(t j) W_16^t
-      w[1] = pk_mul_w1(t3a, K); w[2] = pk_mul_w2(t3b, H); w[4] = pk_mul_mj(t3c);
+    if (RESIDENT) {
+#pragma unroll
+      for (int t = 1; t < 8; t++) w[t] = w3[h][t];
+    } else {
+      xf_twiddles3(w, h, t3a, t3b, t3c, K, H);
     }
-    w[3] = pk_cmul(w[1], w[2]);
-    w[5] = pk_cmul(w[1], w[4]);
-    w[6] = pk_cmul(w[2], w[4]);
-    w[7] = pk_cmul(w[3], w[4]);
 #pragma unroll
     for (int t = 1; t < 8; t++) u[t] = pk_cmul(u[t], w[t]);
     pk_dft8(u, H);
@@ -135,27 +162,21 @@ __device__ __forceinline__ void xf_invB(const float* src, float* dst, const floa
 }
 
 // inverse pass C: radix-16, Ns = 128, conj twiddles W_2048^(t j); y[t] = output sample j + 128 t
-__device__ __forceinline__ void xf_invC(const float* src, v2f (&y)[16], const XfAddr& a, v2f t3a, v2f t3b, v2f t3c, v2f K,
-                                        v2f H) {
+template <bool RESIDENT>
+__device__ __forceinline__ void xf_invC(const float* src, v2f (&y)[16], const XfAddr& a, const v2f (&wC)[16], v2f t3a,
+                                        v2f t3b, v2f t3c, v2f K, v2f H) {
   v2f v[16];
 #pragma unroll
   for (int t = 0; t < 16; t++) v[t] = lds_ld(src, ((t & 1) ? a.rdBo : a.rdBe) + 128 * t);
   __builtin_amdgcn_sched_barrier(0);
   {
-    // W_2048^(t j), t = 1..15, as products of the three resident powers (at most three factors deep)
     v2f w[16];
-    w[1] = t3a; w[2] = t3b; w[4] = t3c; w[8] = pk_cmul(t3c, t3c);
-    w[3] = pk_cmul(w[1], w[2]);
-    w[5] = pk_cmul(w[1], w[4]);
-    w[6] = pk_cmul(w[2], w[4]);
-    w[9] = pk_cmul(w[1], w[8]);
-    w[10] = pk_cmul(w[2], w[8]);
-    w[12] = pk_cmul(w[4], w[8]);
-    w[7] = pk_cmul(w[3], w[4]);
-    w[11] = pk_cmul(w[3], w[8]);
-    w[13] = pk_cmul(w[5], w[8]);
-    w[14] = pk_cmul(w[6], w[8]);
-    w[15] = pk_cmul(w[7], w[8]);
+    if (RESIDENT) {
+#pragma unroll
+      for (int t = 1; t < 16; t++) w[t] = wC[t];
+    } else {
+      xf_twiddlesC(w, t3a, t3b, t3c);
+    }
 #pragma unroll
     for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], w[t]);
   }
