@@ -20,9 +20,26 @@ namespace uc {
 
 namespace {
 
-constexpr int TC = 256;          // 4 waves
-constexpr int kTileWords = 256;  // words one wave loads
-constexpr int kTileOut = 252;    // outputs one wave stores
+#ifndef UC_CIC_THREADS
+#define UC_CIC_THREADS 1024
+#endif
+#ifndef UC_CIC_R4
+#define UC_CIC_R4 4
+#endif
+#ifndef UC_CIC_R1
+#define UC_CIC_R1 8
+#endif
+constexpr int TC = UC_CIC_THREADS;  // one workgroup per CU shares one set of tables
+constexpr int kTileWords = 256;     // words one wave loads
+constexpr int kTileOut = 252;       // outputs one wave stores
+// The lookups are indexed by DATA bytes: lanes of one LDS access group that need different entries on
+// the same banks are serialised (16 random bytes on 16 bank quads: ~3 per quad).  Replicating the
+// tables -- entry e of replica r at e * R + r, a lane reads replica lane % R -- spreads a group over
+// R times as many bank positions per entry: 4 lanes share a replica of the 16-byte table (R4 = 4),
+// 4 lanes a replica of the 4-byte table (R1 = 8; 32-lane groups on 32 banks).
+constexpr int R4 = UC_CIC_R4;
+constexpr int R1 = UC_CIC_R1;
+constexpr size_t kCicLdsBytes = 1024 * (size_t)R4 * 16 + 1024 * (size_t)R1 * 4;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -32,12 +49,11 @@ __device__ __forceinline__ int from_prev_lane(int v) {
 }
 
 __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
-  __shared__ v4i t4[1024];  // [byte position b][value v] -> contributions to outputs m, m+1, m+2, m+3 of word m
-  __shared__ int t1[1024];  //                           -> contribution to output m+4
-  for (int i = threadIdx.x; i < 1024; i += TC) {
-    t4[i] = reinterpret_cast<const v4i*>(p.t4)[i];
-    t1[i] = p.t1[i];
-  }
+  extern __shared__ __attribute__((aligned(16))) unsigned char cic_lds[];
+  v4i* t4 = reinterpret_cast<v4i*>(cic_lds);              // [byte position b][value v][replica] -> outputs m .. m+3 of word m
+  int* t1 = reinterpret_cast<int*>(cic_lds + 1024 * R4 * 16);  //                                 -> output m+4
+  for (int i = threadIdx.x; i < 1024 * R4; i += TC) t4[i] = reinterpret_cast<const v4i*>(p.t4)[i / R4];
+  for (int i = threadIdx.x; i < 1024 * R1; i += TC) t1[i] = p.t1[i / R1];
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
@@ -46,13 +62,23 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
   const size_t wave0 = (size_t)blockIdx.x * (TC / 64) + (threadIdx.x >> 6);
   const size_t nwaves = (size_t)gridDim.x * (TC / 64);
 
-  for (size_t tile = wave0; tile < tiles; tile += nwaves) {
+  // words base + 4 lane .. + 3 of a tile; past the end of the buffer the resource returns 0 (those outputs
+  // are not stored), and so does a tile beyond the last one
+  auto load_tile = [&](size_t tile) {
     const size_t base = tile * kTileOut;  // first word of the tile = first output of the tile + 4 - 4
-    // words base + 4 lane .. + 3; past the end of the buffer the resource returns 0 (those outputs are not stored)
-    const size_t left = p.n_words - base;
+    const size_t left = tile < tiles ? p.n_words - base : 0;
     const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.pdm + base, recs * 4);
-    const v4u w = __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, 0);
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.pdm + (tile < tiles ? base : 0), recs * 4);
+    return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, 0);
+  };
+  // A wave has 1 KiB of input in flight per outstanding load; 16 waves per CU with one load each cannot
+  // cover the HBM latency at this rate, so the loads run TWO tiles ahead of the arithmetic.
+  v4u w1 = load_tile(wave0), w2 = load_tile(wave0 + nwaves);
+  for (size_t tile = wave0; tile < tiles; tile += nwaves) {
+    const size_t base = tile * kTileOut;
+    const v4u w = w1;
+    w1 = w2;
+    w2 = load_tile(tile + 2 * nwaves);
     const unsigned wd[4] = {w.x, w.y, w.z, w.w};
     int g[4][5];
 #pragma unroll
@@ -61,9 +87,9 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
 #pragma unroll
       for (int b = 0; b < 4; b++) {
         const int idx = b * 256 + (int)((wd[c] >> (8 * b)) & 255u);
-        const v4i q = t4[idx];
+        const v4i q = t4[idx * R4 + (lane & (R4 - 1))];
         a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
-        a4 += t1[idx];
+        a4 += t1[idx * R1 + (lane & (R1 - 1))];
       }
       g[c][0] = a0; g[c][1] = a1; g[c][2] = a2; g[c][3] = a3; g[c][4] = a4;
     }
@@ -107,13 +133,20 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
 
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream) {
   if (grid <= 0 || p.n_words <= 4) return (int)hipSuccess;
-  hipLaunchKernelGGL(sinc5_kernel, dim3((unsigned)grid), dim3((unsigned)TC), 0, stream, p);
+  static bool attr_set = false;  // more than the default 64 KiB of dynamic LDS needs the opt-in, once per process
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCicLdsBytes);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(sinc5_kernel, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
   return (int)hipGetLastError();
 }
 
 int sinc5_max_blocks_per_cu() {
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel, TC, 0) != hipSuccess || nb <= 0) nb = 4;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel, TC, kCicLdsBytes) != hipSuccess || nb <= 0) nb = 1;
   return nb;
 }
 
