@@ -545,7 +545,13 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   cp.out = d_out;
   cp.t4 = c->d_cic4;
   cp.t1 = c->d_cic1;
-  if (c->cic_blocks_per_cu == 0) c->cic_blocks_per_cu = uc::sinc5_max_blocks_per_cu();
+  if (c->cic_blocks_per_cu == 0) {
+    c->cic_blocks_per_cu = uc::sinc5_max_blocks_per_cu();
+    if (c->cic_blocks_per_cu <= 0) {
+      c->cic_blocks_per_cu = 0;
+      return fail(-ENOMEM, "uc_dfsdm_sinc5: the kernel's LDS tables do not fit this device");
+    }
+  }
   size_t grid = (size_t)c->num_cu * (size_t)c->cic_blocks_per_cu;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   const size_t need = (n_out + uc::sinc5_tile_outputs() - 1) / uc::sinc5_tile_outputs();

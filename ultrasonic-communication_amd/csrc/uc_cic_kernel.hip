@@ -133,18 +133,16 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
 
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream) {
   if (grid <= 0 || p.n_words <= 4) return (int)hipSuccess;
-  static bool attr_set = false;  // more than the default 64 KiB of dynamic LDS needs the opt-in, once per process
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)kCicLdsBytes);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
   hipLaunchKernelGGL(sinc5_kernel, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
   return (int)hipGetLastError();
 }
 
+// Called once per context on its device, before the first launch: more than the default 64 KiB of
+// dynamic LDS needs the opt-in; returns the resident workgroups per CU (0 if the opt-in fails).
 int sinc5_max_blocks_per_cu() {
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kCicLdsBytes) != hipSuccess)
+    return 0;
   int nb = 0;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel, TC, kCicLdsBytes) != hipSuccess || nb <= 0) nb = 1;
   return nb;
