@@ -99,16 +99,7 @@ __device__ __forceinline__ v2f pk_scale_hi(v2f w, v2f x) {
   return r;
 }
 
-// acc + w * b (or w * b) with the REAL factor b broadcast from the low / high half of an SGPR pair:
-// two filter taps per pair, no (b, b) copies
-__device__ __forceinline__ v2f pk_fma_slo(v2f w, v2f bb, v2f acc) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[1,0,1]" : "+v"(acc) : "v"(w), "s"(bb));
-  return acc;
-}
-__device__ __forceinline__ v2f pk_fma_shi(v2f w, v2f bb, v2f acc) {
-  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "+v"(acc) : "v"(w), "s"(bb));
-  return acc;
-}
+// w * b with the REAL factor b broadcast from the low half of an SGPR pair (two filter taps per pair, no (b, b) copies)
 __device__ __forceinline__ v2f pk_mul_slo(v2f w, v2f bb) {
   v2f r;
   asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[1,0]" : "=v"(r) : "v"(w), "s"(bb));
