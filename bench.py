@@ -85,8 +85,22 @@ def cpu_baseline(frames_host, mag_mean):
         passes += 1
         dt = time.perf_counter() - t0
     n = n * passes
+    # one-thread figure on a smaller sample, and what the host is
+    n1 = min(frames_host.shape[0], 1 << 15)
+    t1 = time.perf_counter()
+    o.process(frames_host[:n1], precision=uco.F32, threads=1)
+    one_thread = n1 / (time.perf_counter() - t1)
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
     rs, _ = o.process(frames_host[:4096], precision=uco.F64, threads=cores)
     return {"symbols_f64_oracle_head": rs, "value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "one_thread_value": one_thread, "cpu_model": model,
             "sample": "%d passes over the first %d frames of the same batch, oracle/uc_oracle.c "
                       "(float32 butterflies), OpenMP %d threads = this box's CPU share (%d hardware threads visible), "
                       "%.1f s" % (passes, n // passes, cores, os.cpu_count() or 1, dt)}
