@@ -24,6 +24,10 @@
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 
+#ifndef UC_CPLX_RES3
+#define UC_CPLX_RES3 1  // SYNC_CPLX at 3 waves/SIMD: tables kept resident (0, 1)
+#endif
+
 namespace uc {
 
 namespace {
@@ -292,6 +296,19 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #pragma unroll
     for (int t = 0; t < 16; t++) wt[t] = buf_ld64(rs_tab0, voff8, T * 8 * t);
   }
+  // CPLX: the two complex tables (up, down).  Table loads inside the loop are 32 KiB of cache traffic per
+  // frame and sit behind the prefetch in the in-order vector-memory queue, so as many as the register budget
+  // allows stay resident: both at 2 waves/SIMD, the first one at 3.
+  constexpr int kCplxRes = (MODE == kModeCplx) ? (WAVES <= 2 ? 2 : (WAVES == 3 ? UC_CPLX_RES3 : 0)) : 0;
+  v2f wc[2][16];
+  if (kCplxRes >= 1) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) wc[0][t] = buf_ld64(rs_tab0, voff8, T * 8 * t);
+  }
+  if (kCplxRes >= 2) {
+#pragma unroll
+    for (int t = 0; t < 16; t++) wc[1][t] = buf_ld64(rs_tab1, voff8, T * 8 * t);
+  }
   v2f wr[8];   // PAIR only: the REAL window*chirp table, two samples per register pair
   if (kPair) {
 #pragma unroll
@@ -458,8 +475,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const v2f x2 = cvt_pair<DTYPE>(xp[m]);
-          v[2 * m] = pk_scale_lo(buf_ld64(rt, voff8, T * 8 * (2 * m)), x2);
-          v[2 * m + 1] = pk_scale_hi(buf_ld64(rt, voff8, T * 8 * (2 * m + 1)), x2);
+          const bool res = run < kCplxRes;
+          v[2 * m] = pk_scale_lo(res ? wc[run][2 * m] : buf_ld64(rt, voff8, T * 8 * (2 * m)), x2);
+          v[2 * m + 1] = pk_scale_hi(res ? wc[run][2 * m + 1] : buf_ld64(rt, voff8, T * 8 * (2 * m + 1)), x2);
         }
       }
       // prefetch the next frame a whole frame time ahead (HBM latency under load is
