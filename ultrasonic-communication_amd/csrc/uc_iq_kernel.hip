@@ -7,16 +7,22 @@
 //   Hann, arm_cfft_f32(len 2048), arm_cmplx_mag_f32(n/2)           Src/main.c:126-132
 //   arm_max_f32 x 3 over [idx_left_zero, +bw4), [.., +bw2), [center, +bw2)   Src/main.c:283-285
 //
-// Design (MI355X): one 2-wave workgroup per frame, persistent.  The frame plus its
-// 26-sample FIR history is mixed with the carrier while it is copied into a padded
-// LDS image (stride 17 per 16 samples: conflict-free for the per-thread sliding
-// window); every thread then filters 16 CONSECUTIVE outputs from a 42-sample register
-// window (27 packed FMAs per output, I and Q together), writes them back in the
-// XOR-swizzled layout of the band kernel's first exchange, and the 16 x 16 x 8 FFT
-// of uc_band_kernel.hip follows with the chirp*Hann table multiplied in pass 1.
-// Only the 4*bandwidth bins the three windows look at are evaluated in the last pass.
-// This variant is compute-bound (the FIR alone is ~110 kflop per frame, as much as
-// the FFT); HBM traffic is 8 KiB + 104 B of history in, 32 B of stats out per frame.
+// Design (MI355X): one 2-wave workgroup per frame (n = 2048; ONE wave per frame at n = 1024, below),
+// persistent over round-robin groups of up to 64 frames.  The frame plus its 26-sample FIR
+// history is mixed with the carrier while it is written into a padded LDS image (stride 17
+// per 16 samples: conflict-free for the per-thread sliding window); every thread then filters
+// 16 CONSECUTIVE outputs from a 42-sample register window (27 packed FMAs per output, I and Q
+// together, eight accumulators in flight, two taps per SGPR pair), writes them in the
+// XOR-swizzled layout of the band kernel's first exchange, and the 16 x 16 x 8 FFT of
+// uc_band_kernel.hip follows with the chirp*Hann table multiplied in pass 1.  Only the
+// 4*bandwidth bins the three windows look at are evaluated in the last pass.
+// The loop loads nothing but frames: the next frame sits in 17 registers a frame time ahead,
+// the carrier, chirp*Hann and twiddle entries of a thread are resident (vector loads return
+// in order: a table load behind the prefetch would stall the arithmetic on HBM latency).
+// Image and tile ping-pong: one barrier per exchange.  Window partials go to a ring in LDS
+// that is finalised for 64 frames at once (one lane per frame, coalesced 32-byte records).
+// Compute-bound by definition (the FIR alone is as many flops as the FFT); HBM traffic is
+// 4 n + 104 B in, 32 B out per frame.
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 
