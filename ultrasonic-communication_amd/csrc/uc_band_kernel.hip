@@ -27,6 +27,9 @@
 #ifndef UC_CPLX_RES3
 #define UC_CPLX_RES3 1  // SYNC_CPLX at 3 waves/SIMD: tables kept resident (0, 1)
 #endif
+#ifndef UC_CPLX_NRES
+#define UC_CPLX_NRES 14  // ... and how many of the 16 entries of that table
+#endif
 
 namespace uc {
 
@@ -299,7 +302,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // CPLX: the two complex tables (up, down).  Table loads inside the loop are 32 KiB of cache traffic per
   // frame and sit behind the prefetch in the in-order vector-memory queue, so as many as the register budget
   // allows stay resident: both at 2 waves/SIMD, the first one at 3.
-  constexpr int kCplxRes = (MODE == kModeCplx) ? (WAVES <= 2 ? 2 : (WAVES == 3 ? UC_CPLX_RES3 : 0)) : 0;
+  constexpr int kCplxRes =
+      (MODE == kModeCplx) ? (WAVES <= 2 ? 2 : (WAVES == 3 && DTYPE == UC_DTYPE_F32 ? UC_CPLX_RES3 : 0)) : 0;  // (int32: no room)
   v2f wc[2][16];
   if (kCplxRes >= 1) {
 #pragma unroll
@@ -475,9 +479,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #pragma unroll
         for (int m = 0; m < 8; m++) {
           const v2f x2 = cvt_pair<DTYPE>(xp[m]);
-          const bool res = run < kCplxRes;
-          v[2 * m] = pk_scale_lo(res ? wc[run][2 * m] : buf_ld64(rt, voff8, T * 8 * (2 * m)), x2);
-          v[2 * m + 1] = pk_scale_hi(res ? wc[run][2 * m + 1] : buf_ld64(rt, voff8, T * 8 * (2 * m + 1)), x2);
+          // (at 3 waves/SIMD the last entries of the resident table would spill: they are loaded instead)
+          const bool res0 = run < kCplxRes && (WAVES <= 2 || 2 * m < UC_CPLX_NRES);
+          const bool res1 = run < kCplxRes && (WAVES <= 2 || 2 * m + 1 < UC_CPLX_NRES);
+          v[2 * m] = pk_scale_lo(res0 ? wc[run][2 * m] : buf_ld64(rt, voff8, T * 8 * (2 * m)), x2);
+          v[2 * m + 1] = pk_scale_hi(res1 ? wc[run][2 * m + 1] : buf_ld64(rt, voff8, T * 8 * (2 * m + 1)), x2);
         }
       }
       // prefetch the next frame a whole frame time ahead (HBM latency under load is
