@@ -349,12 +349,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       const __amdgpu_buffer_rsrc_t rb = make_rsrc(
           reinterpret_cast<const char*>(p.frames) + (2 * u + (has_b ? 1 : 0)) * p.stride * 4, has_b ? kN * 4 : 0);
 #pragma unroll
-      for (int t = 0; t < NX; t++) xp[t] = mkv(buf_ld32(ra, voff4, T * 4 * t), buf_ld32(rb, voff4, T * 4 * t));
+      for (int t = 0; t < NX; t++) xp[t] = mkv(buf_ld32_stream(ra, voff4, T * 4 * t), buf_ld32_stream(rb, voff4, T * 4 * t));
     } else {
       const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + u * p.stride * 4, kN * 4);
 #pragma unroll
       for (int m = 0; m < 8; m++)
-        xp[m] = mkv(buf_ld32(rx, voff4, T * 4 * (2 * m)), buf_ld32(rx, voff4, T * 4 * (2 * m + 1)));
+        xp[m] = mkv(buf_ld32_stream(rx, voff4, T * 4 * (2 * m)), buf_ld32_stream(rx, voff4, T * 4 * (2 * m + 1)));
     }
   };
   load_unit(f);

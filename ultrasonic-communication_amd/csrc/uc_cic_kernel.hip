@@ -70,7 +70,7 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     const size_t left = tile < tiles ? p.n_words - base : 0;
     const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.pdm + (tile < tiles ? base : 0), recs * 4);
-    return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, 0);
+    return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, UC_STREAM_CPOL);
   };
   // A wave has 1 KiB of input in flight per outstanding load; 16 waves per CU with one load each cannot
   // cover the HBM latency at this rate, so the loads run TWO tiles ahead of the arithmetic.
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
       if (o + 3 < n_out) {
         v4i r;
         r.x = word(y0); r.y = word(y1); r.z = word(y2); r.w = word(y3);
-        *reinterpret_cast<v4i*>(p.out + o) = r;
+        __builtin_nontemporal_store(r, reinterpret_cast<v4i*>(p.out + o));  // written once, never read here
       } else {
         if (o < n_out) p.out[o] = word(y0);
         if (o + 1 < n_out) p.out[o + 1] = word(y1);

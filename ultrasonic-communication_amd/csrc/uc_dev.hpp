@@ -23,9 +23,17 @@ constexpr int kRsrcFlags = 0x00020000;  // gfx9 raw buffer, 32-bit data format
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, int bytes) {
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, kRsrcFlags);
 }
+// *_stream: the same loads for data that is read exactly once (the frames): cache-policy hint UC_STREAM_CPOL
+// (gfx940+: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef UC_STREAM_CPOL
+#define UC_STREAM_CPOL 2
+#endif
 // raw 32-bit word; int32 words are converted when consumed (the ISR's (float) cast, receiver/Src/main.c:664)
 __device__ __forceinline__ float buf_ld32(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ float buf_ld32_stream(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, UC_STREAM_CPOL));
 }
 __device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   const v2u w = __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0);
@@ -33,6 +41,9 @@ __device__ __forceinline__ v2f buf_ld64(__amdgpu_buffer_rsrc_t r, int voff, int 
 }
 __device__ __forceinline__ v4u buf_ld128(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
   return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+}
+__device__ __forceinline__ v4u buf_ld128_stream(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, UC_STREAM_CPOL);
 }
 template <int DTYPE>
 __device__ __forceinline__ v2f cvt_pair(v2f raw) {

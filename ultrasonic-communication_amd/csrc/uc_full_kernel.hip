@@ -159,7 +159,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
     const __amdgpu_buffer_rsrc_t rb =
         make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u + (hb ? 1 : 0)) * p.stride * 4, hb ? kN * 4 : 0);
 #pragma unroll
-    for (int t = 0; t < 16; t++) xp[t] = mkv(buf_ld32(ra, voff4, T * 4 * t), buf_ld32(rb, voff4, T * 4 * t));
+    for (int t = 0; t < 16; t++) xp[t] = mkv(buf_ld32_stream(ra, voff4, T * 4 * t), buf_ld32_stream(rb, voff4, T * 4 * t));
   };
   load_pair(q);
 

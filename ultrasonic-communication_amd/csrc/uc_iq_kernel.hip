@@ -138,7 +138,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     const __amdgpu_buffer_rsrc_t rx =
         make_rsrc(reinterpret_cast<const char*>(p.frames) + (fr * p.stride) * 4 - kHalo * 4, kMixLen * 4);
 #pragma unroll
-    for (int u = 0; u < 17; u++) xn[u] = buf_ld32(rx, j * 4, T * 4 * u);  // past the end: 0
+    for (int u = 0; u < 17; u++) xn[u] = buf_ld32_stream(rx, j * 4, T * 4 * u);  // past the end: 0
   };
   load_frame(f);
 
@@ -401,7 +401,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
     const __amdgpu_buffer_rsrc_t rx =
         make_rsrc(reinterpret_cast<const char*>(p.frames) + (fr * p.stride) * 4 - kHalo * 4, kMixLen1 * 4);
 #pragma unroll
-    for (int u = 0; u < 17; u++) xn[u] = buf_ld32(rx, j * 4, T1 * 4 * u);  // past the end: 0
+    for (int u = 0; u < 17; u++) xn[u] = buf_ld32_stream(rx, j * 4, T1 * 4 * u);  // past the end: 0
   };
   load_frame(f);
 

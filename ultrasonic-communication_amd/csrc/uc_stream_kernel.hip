@@ -127,8 +127,8 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     const int recs = left < (size_t)(kSubIn + 28) ? (int)left : kSubIn + 28;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.samples) + first * 4, recs * 4);
 #pragma unroll
-    for (int r = 0; r < 8; r++) dst[r] = buf_ld128(rx, voff16, T * 16 * r);
-    dst[8] = buf_ld128(rx, voff16, kSubIn * 4);
+    for (int r = 0; r < 8; r++) dst[r] = buf_ld128_stream(rx, voff16, T * 16 * r);
+    dst[8] = buf_ld128_stream(rx, voff16, kSubIn * 4);
   };
 
   issue_loads(b, 0, stg[0]);
@@ -235,7 +235,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
       const v2f y = y16[t];
       const float m2 = y.x * y.x + y.y * y.y;
       const int o = j + T * t - (L - 1);  // offset inside the block's hop
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_sqrtf(m2)), ro, o * 4, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_sqrtf(m2)), ro, o * 4, 0, UC_STREAM_CPOL);
       const bool take = (unsigned)o < (unsigned)valid && m2 > best;  // ascending offset: first maximum
       best = take ? m2 : best;
       best_i = take ? o : best_i;
