@@ -3,51 +3,44 @@
 
 One "step" = one pass of the hot path (uc_process_batch, variant RX_REAL:
 ingest -> window*chirp -> 2048-pt FFT -> windowed peak pick -> up/down symbol)
-over one batch of synthetic frames already resident in HBM.  Workload =
-BASELINE.json configs[1]: 1 Mi x 2048-sample fp32 frames per GPU, orthogonal
-up/down chirp at -10 dB SNR.  Multi-GPU: one process per GPU, the frame index
-space is block-partitioned (weak scaling: 1 Mi frames per GPU), no data-path
-collective; the decoded symbol stream (1 B/frame) is all-gathered over RCCL
-every step, inside the timed region, on RCCL's stream: the gather of step k
-overlaps the kernel of step k + 1 (two symbol buffers).
+over one batch of synthetic frames already resident in HBM.
 
-Prints ONE JSON line on rank 0 (see the contract in the task statement).
+  N = 1   BASELINE.json configs[1]: 1 Mi x 2048-sample fp32 frames, random orthogonal up/down
+          chirps at -10 dB SNR, literal TIME_FRAME (the firmware's reference tables).
+  N > 1   BASELINE.json configs[4]: the frame index space is block-partitioned (weak scaling:
+          1 Mi frames per GPU, no data-path collective); the frames are the K7 wire format
+          (G, 7 x H, L, 96 data bits of "Hello World!", 12 x G) repeated over the GLOBAL frame
+          index at -10 dB, reference sweep matched to the frame; the decoded symbol stream
+          (1 B/frame) is all-gathered over RCCL every step inside the timed region (the gather of
+          step k overlaps the kernel of step k + 1) and decoded to text after it.
+
+`python bench.py --gpus N` starts its N ranks itself (one process per GPU, before anything touches
+the GPU); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is
+one of the ranks.  --gpus must equal the world size.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
-sys.path.insert(0, os.path.join(ROOT, "tests"))
-
-import numpy as np
-import torch
 
 N = 2048
 BYTES_PER_FRAME = 8192 + 1          # SURVEY.md section 8d: fp32 frame in + 1 symbol byte out
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
+MATCHED_TIME_FRAME = N / 78125.0    # one symbol = one frame (generator: T = 0.0262 s)
+MSG = "Hello World!"
 
 
 def make_device_frames(n_frames, device, seed, snr_db=-10.0, amp=1000.0):
-    """Synthetic orthogonal-chirp frames generated on the device (tests/synth.py model)."""
-    import synth
-    up, down = synth.chirp_pair(n=N, amp=amp)
-    tab = torch.tensor(np.stack([down, up]), dtype=torch.float32, device=device)
-    g = torch.Generator(device=device)
-    g.manual_seed(seed)
-    bits = torch.randint(0, 2, (n_frames,), generator=g, device=device, dtype=torch.int64)
-    frames = torch.empty((n_frames, N), dtype=torch.float32, device=device)
-    sigma = amp * 10.0 ** (-snr_db / 20.0)
-    chunk = 1 << 15
-    for s in range(0, n_frames, chunk):
-        e = min(n_frames, s + chunk)
-        frames[s:e] = tab[bits[s:e]]
-        frames[s:e] += sigma * torch.randn((e - s, N), generator=g, device=device)
-    return frames, bits.to(torch.uint8)
+    """configs[1] frames (kept under this name for the tools)."""
+    from uchirp import synth
+    return synth.device_frames(n_frames, device, seed, snr_db=snr_db, amp=amp)
 
 
 def host_cpu_share():
@@ -106,7 +99,46 @@ def cpu_baseline(frames_host, mag_mean):
                       "%.1f s" % (passes, n // passes, cores, os.cpu_count() or 1, dt)}
 
 
-def stream_measurement(args, eng, frames, rank):
+def achievable_hbm(frames, stream, torch):
+    """What the simplest kernels get out of this chip's HBM right now (tools/hbm_probe.hip): a read-only
+    non-temporal stream over the bench's own 8 GiB batch (the band kernel's traffic shape: 8192 B in, 1 B out)
+    and a 1:1 copy of 4 GiB.  HIP events on the launch stream, median of 10."""
+    import ctypes as C
+    path = os.path.join(ROOT, "tools", "libhbm_probe.so")
+    if not os.path.exists(path):
+        return None
+    L = C.CDLL(path)
+    L.hbm_probe_read.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int, C.c_void_p]
+    L.hbm_probe_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    nbytes = frames.numel() * 4
+    blocks = torch.cuda.get_device_properties(frames.device).multi_processor_count * 8
+    sink = torch.zeros(blocks, dtype=torch.int32, device=frames.device)
+    half = (nbytes // 2) & ~((1 << 15) - 1)
+    dst = torch.empty(half // 4, dtype=torch.float32, device=frames.device)
+
+    def timed(fn):
+        ts = []
+        for _ in range(13):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(stream)
+            rc = fn()
+            b.record(stream)
+            torch.cuda.synchronize()
+            if rc != 0:
+                return None
+            ts.append(a.elapsed_time(b))
+        return float(sorted(ts[3:])[len(ts[3:]) // 2])
+
+    t_read = timed(lambda: L.hbm_probe_read(frames.data_ptr(), nbytes, sink.data_ptr(), blocks, stream.cuda_stream))
+    t_copy = timed(lambda: L.hbm_probe_copy(frames.data_ptr(), dst.data_ptr(), half, blocks, stream.cuda_stream))
+    if not t_read or not t_copy:
+        return None
+    return {"read_stream_GBs": nbytes / t_read / 1e6, "copy_GBs": 2 * half / t_copy / 1e6,
+            "method": "tools/hbm_probe.hip: read-only nt stream over the %d MiB batch; 1:1 copy of %d MiB "
+                      "(read + write bytes); HIP events, median of 10" % (nbytes >> 20, half >> 20)}
+
+
+def stream_measurement(args, eng, frames, rank, torch):
     """BASELINE config 4 (side measurement): the batch read as ONE continuous stream through UC_STREAM."""
     x = frames.reshape(-1)
     halo, n_out, n_blocks, hop = eng.stream_geometry(x.numel())
@@ -131,10 +163,10 @@ def stream_measurement(args, eng, frames, rank):
                                        "bytes_per_sample": byts / x.numel()}}), flush=True)
 
 
-def side_measurement(args, eng, frames, world, rank):
+def side_measurement(args, eng, frames, world, rank, torch):
     """Not the contract line: frames/s of one of the sibling variants on the same synthetic batch."""
     if args.variant == "stream":
-        return stream_measurement(args, eng, frames, rank)
+        return stream_measurement(args, eng, frames, rank, torch)
     n = eng.n
     per_frame = {"sync_cplx": 8193, "compress": 8192 + 32, "dechirp_down": 8192 + 32, "iq": 8192 + 104 + 32,
                  "iq1024": 4096 + 104 + 32}[args.variant]
@@ -159,7 +191,7 @@ def side_measurement(args, eng, frames, world, rank):
                                        "frac": v * per_frame / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": per_frame}}), flush=True)
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -170,20 +202,76 @@ def main():
     ap.add_argument("--variant", default="rx_real",
                     choices=["rx_real", "sync_cplx", "compress", "dechirp_down", "iq", "iq1024", "stream"],
                     help="default rx_real = BASELINE configs[1]; the others are side measurements")
-    args = ap.parse_args()
+    return ap.parse_args(argv)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes.
+    This parent never imports torch and never touches the GPU (a process that has initialised the GPU
+    must not be replaced or forked on this pool); it relays rank 0's JSON line and the worst exit code."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    import tempfile
+    out0 = tempfile.TemporaryFile()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=out0 if r == 0 else sys.stderr))
+    deadline = time.time() + float(os.environ.get("UC_BENCH_TIMEOUT", "900"))
+    rc = 0
+    while rc == 0 and any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        rc = next((p.returncode for p in procs if p.poll() not in (None, 0)), 0)
+        if time.time() > deadline:
+            rc = -1
+    if rc:
+        for p in procs:                      # a rank died or hung: the others wait in a collective; end exactly those
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait()
+    out0.seek(0)
+    text = out0.read().decode()
+    if rc:
+        sys.stderr.write(text)
+        raise SystemExit("bench.py: a rank failed (exit %s)" % rc)
+    sys.stdout.write(text)
+    sys.stdout.flush()
+
+
+def main():
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return launch_ranks(args)
+    world = int(env_world or "1")
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d. Run `python bench.py --gpus N` (it starts its own ranks) "
+                         "or `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`."
+                         % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-    # UC_BENCH_REHEARSE=1: plumbing rehearsal of the N > 1 path on a ONE-GPU box (every rank on
-    # device 0, gloo, symbol gather staged through host memory).  Never a measurement.
+
+    import numpy as np
+    import torch
+    # UC_BENCH_REHEARSE=1: plumbing rehearsal of the N > 1 path (spawn, rendezvous, symbol gather, concatenation
+    # check, text decode, JSON line) with gloo.  On a ONE-GPU box every rank runs the real kernel on device 0; on a
+    # box without a GPU NO kernel runs (the "decoded" symbols are the transmitted ones) and `value` is null.
+    # Never a measurement.
     rehearse = os.environ.get("UC_BENCH_REHEARSE") == "1"
+    have_gpu = torch.cuda.is_available()
+    if not have_gpu and not rehearse:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     if rehearse:
         local_rank = 0
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    device = torch.device("cuda", local_rank) if have_gpu else torch.device("cpu")
+    if have_gpu:
+        torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -192,24 +280,36 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        world = dist.get_world_size()          # n_gpus printed below is what the process group reports
 
-    import uchirp
+    from uchirp import synth
     mag_mean = 1000.0
-    vmap = {"rx_real": (uchirp.RX_REAL, {}), "sync_cplx": (uchirp.SYNC_CPLX, {}), "compress": (uchirp.COMPRESS, {}),
-            "dechirp_down": (uchirp.DECHIRP_DOWN, {}), "iq": (uchirp.IQ, {}), "iq1024": (uchirp.IQ, {"n": 1024}), "stream": (uchirp.STREAM, {})}
-    vid, vkw = vmap[args.variant]
-    eng = uchirp.Engine(vid, device=local_rank, mag_mean=mag_mean, **vkw)
     nf = args.frames
-    frames, bits = make_device_frames(nf, device, seed=1234 + rank, snr_db=args.snr)
+    hello = world > 1 and args.variant == "rx_real"
+    eng = None
+    if have_gpu:
+        import uchirp
+        vmap = {"rx_real": (uchirp.RX_REAL, {}), "sync_cplx": (uchirp.SYNC_CPLX, {}), "compress": (uchirp.COMPRESS, {}),
+                "dechirp_down": (uchirp.DECHIRP_DOWN, {}), "iq": (uchirp.IQ, {}), "iq1024": (uchirp.IQ, {"n": 1024}),
+                "stream": (uchirp.STREAM, {})}
+        vid, vkw = vmap[args.variant]
+        if hello:
+            vkw = dict(vkw, time_frame=MATCHED_TIME_FRAME)
+        eng = uchirp.Engine(vid, device=local_rank, mag_mean=mag_mean, **vkw)
+    if hello:
+        # rank r owns frames [r nf, (r + 1) nf) of the global stream (uchirp/shard.py::partition, equal shares)
+        frames, sent = synth.device_hello_frames(rank * nf, nf, device, seed=1234 + rank, snr_db=args.snr, msg=MSG)
+    else:
+        frames, sent = synth.device_frames(nf, device, seed=1234 + rank, snr_db=args.snr)
     if args.variant != "rx_real":
-        return side_measurement(args, eng, frames, world, rank)
+        return side_measurement(args, eng, frames, world, rank, torch)
     # Two symbol buffers: the gather of step k (RCCL's own stream) overlaps the kernel of step k + 1;
     # a buffer is rewritten only after the gather that read it has finished (work.wait() orders the
     # launch stream behind it without blocking the host).
     sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
     gathered2 = [torch.empty(world * nf, dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
     works = [None, None]
-    stream = torch.cuda.current_stream(device)
+    stream = torch.cuda.current_stream(device) if have_gpu else None
 
     def gather(b):
         if rehearse:  # gloo has no device all-gather: stage through the host (rehearsal only)
@@ -224,11 +324,14 @@ def main():
         if works[b] is not None:
             works[b].wait()
             works[b] = None
-        if e0 is not None:
-            e0.record(stream)
-        eng.process(frames, want_stats=False, symbols_out=sym2[b], stream=stream.cuda_stream)
-        if e1 is not None:
-            e1.record(stream)
+        if eng is None:                       # rehearsal without a GPU: no kernel, the transmitted symbols
+            sym2[b].copy_(torch.where(sent == 2, torch.full_like(sent, 0xFF), sent))
+        else:
+            if e0 is not None:
+                e0.record(stream)
+            eng.process(frames, want_stats=False, symbols_out=sym2[b], stream=stream.cuda_stream)
+            if e1 is not None:
+                e1.record(stream)
         if world > 1:
             works[b] = gather(b)
 
@@ -238,72 +341,118 @@ def main():
                 works[b].wait()
                 works[b] = None
 
+    def sync():
+        if have_gpu:
+            torch.cuda.synchronize()
+
     for k in range(args.warmup):
         step(k)
     drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
 
     # per-launch kernel time: HIP events on the stream the kernel is launched on
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if have_gpu else (None, None)
+          for _ in range(args.steps)]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, ev[k][0], ev[k][1])
     drain()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     symbols = sym2[(args.steps - 1) & 1]
+    gathered_host = None
     if world > 1:
-        # the gathered stream is the concatenation of every rank's symbols, rank order
+        # Every rank holds the concatenation of all ranks' symbols, rank order: its own slice equals what it
+        # decoded, and every rank's gathered buffer has the same digest (so the other slices are the owners').
+        import hashlib
         g = gathered2[(args.steps - 1) & 1]
         assert torch.equal(g[rank * nf:(rank + 1) * nf], symbols), "gathered symbol stream differs from this rank's symbols"
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-
-    # correctness gate on the measured run: decoded symbols == transmitted bits
-    ber = float((symbols != bits).float().mean().item())
+        gathered_host = g.cpu().numpy()
+        dig = torch.frombuffer(bytearray(hashlib.sha256(gathered_host.tobytes()).digest()), dtype=torch.uint8).clone()
+        digs = [torch.empty(32, dtype=torch.uint8) for _ in range(world)]
+        if rehearse:
+            dist.all_gather(digs, dig)
+        else:
+            dd = [torch.empty(32, dtype=torch.uint8, device=device) for _ in range(world)]
+            dist.all_gather(dd, dig.to(device))
+            digs = [d.cpu() for d in dd]
+        assert all(torch.equal(d, digs[0]) for d in digs), "ranks hold different gathered symbol streams"
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if have_gpu else None
 
     if rank == 0:
         total_frames = world * nf * args.steps
         value = total_frames / elapsed
-        achieved = nf * BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
-        # collected with rocprofv3 --pmc in their own runs: profiles/*_hbm_traffic.json), scaled to
-        # this launch's frame count; null if no profile is committed.
-        traffic = None
-        try:
-            import glob
-            # the band kernel's own passes are named rNN_vM_hbm_traffic.json (other kernels carry their name)
-            import re
-            tf = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))
-                        if re.fullmatch(r"r\d+_v\d+_hbm_traffic\.json", os.path.basename(f)))[-1]
-            traffic = json.load(open(tf))["hbm_bytes_per_frame"] * nf
-        except Exception:
-            traffic = None
         out = {
-            "metric": "chirp frames/s (2048-pt FFT demod)", "value": value, "unit": "frames/s",
+            "metric": "chirp frames/s (2048-pt FFT demod)", "value": value if have_gpu else None, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "configs[1]: %d x 2048-sample fp32 frames per GPU, orthogonal up/down-chirp "
-                                   "symbol decision (rx_real), SNR %.0f dB" % (nf, args.snr),
-                       "frames_per_gpu": nf, "frame_len": N, "variant": "rx_real",
-                       "parallelism": "frame-sharded x%d, RCCL all-gather of symbols" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "band_kernel<rx_real,f32>", "kernel_ms": kern_ms,
-                         "bytes_per_frame": BYTES_PER_FRAME},
-            "bit_error_rate_vs_transmitted": ber,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if hello:
+            out["config"] = {"workload": "configs[4]: %d x 2048-sample fp32 frames per GPU, frame-sharded 'Hello World!' "
+                                         "stream (K7 framing: G, 7 H, L, 96 data bits, 12 G, repeated over the global frame "
+                                         "index), SNR %.0f dB, rx_real with the reference sweep matched to the frame"
+                                         % (nf, args.snr),
+                             "frames_per_gpu": nf, "frame_len": N, "variant": "rx_real", "time_frame": MATCHED_TIME_FRAME,
+                             "parallelism": "frame-sharded x%d, RCCL all-gather of the symbol stream (1 B/frame) every step"
+                                            % world}
+        else:
+            out["config"] = {"workload": "configs[1]: %d x 2048-sample fp32 frames per GPU, orthogonal up/down-chirp "
+                                         "symbol decision (rx_real), SNR %.0f dB" % (nf, args.snr),
+                             "frames_per_gpu": nf, "frame_len": N, "variant": "rx_real",
+                             "parallelism": "frame-sharded x%d, RCCL all-gather of symbols" % world}
+        if have_gpu:
+            achieved = nf * BYTES_PER_FRAME / (kern_ms * 1e-3) / 1e9
+            # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
+            # collected with rocprofv3 --pmc in their own runs: profiles/*_hbm_traffic.json), scaled to
+            # this launch's frame count; null if no profile is committed.
+            traffic = None
+            try:
+                import glob
+                import re
+                # the band kernel's own passes are named rNN_vM_hbm_traffic.json (other kernels carry their name)
+                tf = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))
+                            if re.fullmatch(r"r\d+_v\d+_hbm_traffic\.json", os.path.basename(f)))[-1]
+                traffic = json.load(open(tf))["hbm_bytes_per_frame"] * nf
+            except Exception:
+                traffic = None
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                               "kernel": "band_kernel<rx_real,f32>", "kernel_ms": kern_ms,
+                               "bytes_per_frame": BYTES_PER_FRAME}
+            if world == 1:
+                ach = achievable_hbm(frames, stream, torch)
+                if ach:
+                    out["roofline"]["achievable"] = ach
+                    out["roofline"]["frac_of_achievable_read"] = achieved / ach["read_stream_GBs"]
+        if hello:
+            # config 5 gate: the gathered stream decodes to the transmitted text
+            texts = synth.decode_hello(gathered_host, len(MSG))
+            good = sum(1 for t in texts if t == MSG)
+            out["decoded_text_first"] = texts[0] if texts else ""
+            out["transmissions"] = len(texts)
+            out["transmissions_decoded_exactly"] = good
+            data = synth.hello_kind_stream(0, world * nf, MSG)
+            m = data != 2
+            out["bit_error_rate_vs_transmitted"] = float((gathered_host[m] != data[m]).mean())
+            if not have_gpu:
+                out["rehearsal"] = "plumbing only: no GPU, no kernel ran, value is null"
+            elif rehearse:
+                out["rehearsal"] = "every rank on device 0, gloo: not a measurement"
+        else:
+            # correctness gate on the measured run: decoded symbols vs transmitted bits
+            out["bit_error_rate_vs_transmitted"] = float((symbols != sent).float().mean().item())
+        if world == 1 and have_gpu and not args.no_cpu_baseline:
             cb = cpu_baseline(frames[: 1 << 19].cpu().numpy(), mag_mean)
             # the oracle as the checker: GPU symbols of the measured run vs float64 oracle
             head = cb.pop("symbols_f64_oracle_head")

@@ -477,7 +477,10 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   p.ifs = (uint32_t)(int32_t)c->cfg.fs;
   p.true_dc = (c->cfg.flags & UC_FLAG_TRUE_DC) ? 1u : 0u;
   p.debug = nullptr;
+#if defined(UC_STAMPS) || defined(UC_CLOCKSTAMP)
+  // diagnostic builds only (libuchirp_stamps.so / libuchirp_clock.so): where the in-kernel stamps go
   if (const char* d = getenv("UC_DEBUG_PTR")) p.debug = (unsigned long long*)strtoull(d, nullptr, 0);
+#endif
   const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
                    : (variant == UC_DECHIRP_DOWN) ? uc::kModePair : uc::kModeRxReal;
   int& bpc = c->band_blocks_per_cu[mode];

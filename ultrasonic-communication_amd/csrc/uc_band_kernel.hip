@@ -268,6 +268,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_readcyclecounter();
 #endif
+#ifdef UC_CLOCKSTAMP
+  // Diagnostic build only (-DUC_CLOCKSTAMP, libuchirp_clock.so): ONE stamp pair around the whole
+  // persistent loop; shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/clock_probe.py).
+  const unsigned long long clk0_ = __builtin_readcyclecounter();
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
   __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   float* ring = lds + kRingOff;
 
@@ -651,6 +657,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #ifdef UC_STAMPS
   if (lane == 0 && p.debug) {
     for (int k = 0; k < 10; k++) p.debug[((size_t)blockIdx.x * 2 + wave) * 10 + k] = acc_[k];
+  }
+#endif
+#ifdef UC_CLOCKSTAMP
+  if (lane == 0 && p.debug) {
+    p.debug[((size_t)blockIdx.x * 2 + wave) * 2 + 0] = __builtin_readcyclecounter() - clk0_;
+    p.debug[((size_t)blockIdx.x * 2 + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - rt0_;
   }
 #endif
 }
