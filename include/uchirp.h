@@ -89,6 +89,16 @@ enum {
 #define UC_FLAG_STREAM_UP   (1u << 3) /* UC_STREAM: convolve with the UP template (compresses
                                          down chirps) instead of the default DOWN template */
 
+#define UC_FLAG_IQ_BASEBAND (1u << 4) /* UC_IQ: the INTENDED maths of the experiment, simulation/IQ_modulation.ipynb
+                                         cells 16-31, instead of the unfinished firmware windows:
+                                         after mix + low-pass, R = I + jQ is multiplied by the CONJUGATE of the
+                                         base-band up chirp (history 0) and of the base-band down chirp (history 1),
+                                         band edges f0 - carrier .. f1 - carrier; Hann; complex FFT; the two windows
+                                         are the `bandwidth` bins either side of DC, [0, bandwidth) and
+                                         [n - bandwidth, n); signed idx2freq as the receiver's; two uc_stats per
+                                         frame {up, down} and an up/down symbol, as RX_REAL / SYNC_CPLX.  The
+                                         modulation is the notebook's (cell 4): x = A cos(2 pi (carrier - f_b(t)) t) */
+
 /* table ids for uc_get_table */
 enum {
   UC_TABLE_UP        = 0, /* n floats (RX_REAL, DECHIRP_DOWN uses DOWN only) or 2n (re,im) */
@@ -156,7 +166,7 @@ int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
  * receiver/Src/main.c:447-451; stride_elems == 0 means n).
  * mag_mean : NULL (cfg.mag_mean for all) or 2 floats per frame {up, down}.
  * symbols  : n_frames bytes, nullable.
- * stats    : 2 uc_stats per frame {up, down} for RX_REAL / SYNC_CPLX,
+ * stats    : 2 uc_stats per frame {up, down} for RX_REAL / SYNC_CPLX / IQ with UC_FLAG_IQ_BASEBAND,
  *            1 per frame otherwise; nullable.
  * UC_IQ reads 26 samples of FIR history in front of every frame: frames must
  * point 26 elements into the buffer (see uc_iq_halo()).

@@ -407,7 +407,15 @@ int uco_create(const uc_config* cfg, uco_ctx** out) {
     c->bandwidth2 = c->bandwidth * 8;
     c->idx_left_zero = n - c->bandwidth2;
   }
-  if (cfg->variant == UC_IQ) {
+  if (cfg->variant == UC_IQ && (cfg->flags & UC_FLAG_IQ_BASEBAND)) {
+    /* the notebook's maths (simulation/IQ_modulation.ipynb cells 28-31: the dechirped tone sits at DC):
+     * windows of `bandwidth` bins either side of DC, searched as receiver/Src/main.c:205-215 does */
+    c->bandwidth2 = c->bandwidth;            /* window length used by fill_history() */
+    c->idx_left_zero = n - c->bandwidth;
+    c->center = 0;
+    c->bandwidth4 = 2 * c->bandwidth;
+    if (c->bandwidth == 0 || c->bandwidth4 > n / 2) { free(c); return -EINVAL; }
+  } else if (cfg->variant == UC_IQ) {
     /* iq_modulation/Src/main.c:215-219 */
     c->center = (uint32_t)((cfg->f0 + cfg->f1) * (float)n / cfg->fs);
     c->bandwidth4 = c->bandwidth * 4;
@@ -481,15 +489,19 @@ int uco_create(const uc_config* cfg, uco_ctx** out) {
       free(tmp);
       break;
     }
-    case UC_IQ:
+    case UC_IQ: {
       uco_hann_periodic(c->hann, n, libm);
-      gen_ref_chirp_deg(c->up, n, 1, cfg->f0, cfg->f1, tf, cfg->fs, cfg->phase_deg, 1, libm);
-      gen_ref_chirp_deg(c->down, n, 0, cfg->f0, cfg->f1, tf, cfg->fs, cfg->phase_deg, 1, libm);
+      /* UC_FLAG_IQ_BASEBAND: the reference chirps are BASE-BAND (IQ_modulation.ipynb cell 3: F0 = -BW/2,
+       * F1 = +BW/2 around the carrier), generated by the firmware's own generator */
+      float off = (cfg->flags & UC_FLAG_IQ_BASEBAND) ? cfg->carrier : 0.0f;
+      gen_ref_chirp_deg(c->up, n, 1, cfg->f0 - off, cfg->f1 - off, tf, cfg->fs, cfg->phase_deg, 1, libm);
+      gen_ref_chirp_deg(c->down, n, 0, cfg->f0 - off, cfg->f1 - off, tf, cfg->fs, cfg->phase_deg, 1, libm);
       c->carrier_c = (float*)malloc(sizeof(float) * n);
       c->carrier_s = (float*)malloc(sizeof(float) * n);
       gen_carrier(c->carrier_c, c->carrier_s, n, cfg->carrier, cfg->fs, tf, libm);
       memcpy(c->fir, fir_taps, sizeof(fir_taps));
       break;
+    }
     case UC_STREAM: {
       /* base-band template of one n-sample symbol at the decimated rate (include/uchirp.h):
        * symmetric Hann and -pi/2 phase as chirp_compression_time_domain/Src/chirp.c:52-75,
@@ -529,9 +541,13 @@ void uco_destroy(uco_ctx* c) {
   free(c);
 }
 
+static int iq_baseband(const uco_ctx* c) {
+  return c->cfg.variant == UC_IQ && (c->cfg.flags & UC_FLAG_IQ_BASEBAND) != 0;
+}
+
 int uco_stats_per_frame(const uco_ctx* c) {
   if (!c) return -EINVAL;
-  return (c->cfg.variant == UC_RX_REAL || c->cfg.variant == UC_SYNC_CPLX) ? 2 : 1;
+  return (c->cfg.variant == UC_RX_REAL || c->cfg.variant == UC_SYNC_CPLX || iq_baseband(c)) ? 2 : 1;
 }
 
 int uco_get_windows(const uco_ctx* c, uint32_t* bw, uint32_t* bw2, uint32_t* ilz) {
@@ -576,7 +592,7 @@ static int32_t idx2freq_n(float fs, uint32_t n, uint32_t idx) {
 
 int32_t uco_idx2freq(const uco_ctx* c, uint32_t idx) {
   if (!c) return 0;
-  if (c->cfg.variant == UC_IQ) /* iq_modulation/Src/main.c:112-114: float fs * idx / n */
+  if (c->cfg.variant == UC_IQ && !iq_baseband(c)) /* iq_modulation/Src/main.c:112-114: float fs * idx / n */
     return (int32_t)(uint32_t)(c->cfg.fs * (float)idx / (float)c->n);
   return idx2freq_n(c->cfg.fs, c->n, idx);
 }
@@ -782,15 +798,13 @@ static void compress_one(const uco_ctx* c, scratch* s, const void* frame, int dt
  * 26 samples of history sit in front of it (the FIR state the firmware
  * carries across blocks, iq_modem.c:47-48); the history samples were mixed
  * with the tail of the carrier table, as a back-to-back previous block's were. */
-static void iq_one(const uco_ctx* c, scratch* s, const void* frame, int dtype, int precision) {
+static void iq_one(const uco_ctx* c, scratch* s, const void* frame, int dtype, int precision, int updown) {
   uint32_t n = c->n;
   const int halo = UCO_FIR_TAPS - 1;
-  float* ir = s->c32;            /* reuse as scratch: I_raw[n+halo] */
-  float* qr = s->pk;             /* n floats only -- need n+halo: use y tail */
+  const int bb = iq_baseband(c);
   /* mixed samples, index j = i + halo, i in [-halo, n) */
   float* imix = (float*)malloc(sizeof(float) * (n + halo) * 2);
   float* qmix = imix + (n + halo);
-  (void)ir; (void)qr;
   for (int i = -halo; i < (int)n; i++) {
     float x = (dtype == UC_DTYPE_I32) ? (float)((const int32_t*)frame)[i] : ((const float*)frame)[i];
     uint32_t ci = (i < 0) ? (uint32_t)((int)n + i) : (uint32_t)i;
@@ -814,14 +828,28 @@ static void iq_one(const uco_ctx* c, scratch* s, const void* frame, int dtype, i
       }
       fi = (float)ai; fq = (float)aq;
     }
-    /* (I + jQ) * down_chirp, iq_modulation/Src/chirp.c:46-48 */
-    float cr = c->down[2 * i], ci = c->down[2 * i + 1];
-    float re = fi * cr - fq * ci;
-    float im = fi * ci + fq * cr;
+    float re, im;
+    if (bb) {
+      /* R * chirp.conjugate(): IQ_modulation.ipynb cells 29 (up) and 30 (down: conj(up) there, the
+       * base-band down chirp of a symmetric band) */
+      const float* ref = (updown == UC_UP_CHIRP) ? c->up : c->down;
+      float cr = ref[2 * i], ci = ref[2 * i + 1];
+      re = fi * cr + fq * ci;
+      im = fq * cr - fi * ci;
+    } else {
+      /* (I + jQ) * down_chirp, iq_modulation/Src/chirp.c:46-48 */
+      float cr = c->down[2 * i], ci = c->down[2 * i + 1];
+      re = fi * cr - fq * ci;
+      im = fi * ci + fq * cr;
+    }
     s->c32[2 * i] = re * c->hann[i]; /* iq_modulation/Src/main.c:126,237 */
     s->c32[2 * i + 1] = im * c->hann[i];
   }
   free(imix);
+  if (bb) {
+    cplx_frame_mags(c, s, precision, n); /* both signs of frequency: the windows straddle DC */
+    return;
+  }
   cplx_frame_mags(c, s, precision, n / 2);
   for (uint32_t i = n / 2; i < n; i++) { s->mag[i] = 0.0f; s->mag64[i] = 0.0; }
 }
@@ -911,7 +939,16 @@ static void process_one(const uco_ctx* c, scratch* s, const void* frame, int dty
       if (st) st[0] = tmp[0];
       break;
     case UC_IQ:
-      iq_one(c, s, frame, dtype, precision);
+      if (iq_baseband(c)) {
+        for (int ud = 1; ud >= 0; ud--) {
+          iq_one(c, s, frame, dtype, precision, ud);
+          fill_history(c, s->mag, ud == UC_UP_CHIRP ? mm_up : mm_dn, &tmp[ud == UC_UP_CHIRP ? 0 : 1]);
+        }
+        if (sym) *sym = decide(tmp[0].snr, tmp[1].snr, c->cfg.snr_threshold);
+        if (st) { st[0] = tmp[0]; st[1] = tmp[1]; }
+        break;
+      }
+      iq_one(c, s, frame, dtype, precision, UC_DOWN_CHIRP);
       iq_history(c, s->mag, mm_up, &tmp[0]);
       if (sym) *sym = UC_SYM_NONE;
       if (st) st[0] = tmp[0];
@@ -982,7 +1019,14 @@ int uco_spectrum(uco_ctx* c, const void* frame, int dtype, int precision, double
       memcpy(out, s.mag64, sizeof(double) * n);
       break;
     case UC_IQ:
-      iq_one(c, &s, frame, dtype, precision);
+      if (iq_baseband(c)) {
+        for (int ud = 1; ud >= 0; ud--) {
+          iq_one(c, &s, frame, dtype, precision, ud);
+          memcpy(out + (ud == UC_UP_CHIRP ? 0 : n), s.mag64, sizeof(double) * n);
+        }
+        break;
+      }
+      iq_one(c, &s, frame, dtype, precision, UC_DOWN_CHIRP);
       memcpy(out, s.mag64, sizeof(double) * n);
       break;
   }

@@ -15,7 +15,7 @@ _LIB = os.path.join(_HERE, "libuc_oracle.so")
 RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ, STREAM = range(6)
 DTYPE_I32, DTYPE_F32 = 0, 1
 F32, F64 = 32, 64
-FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP = 1, 2, 8
+FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP, FLAG_IQ_BASEBAND = 1, 2, 8, 16
 TABLE_UP, TABLE_DOWN, TABLE_HANN, TABLE_H_UP, TABLE_H_DOWN, TABLE_CARRIER_C, TABLE_CARRIER_S, TABLE_FIR,\
     TABLE_TEMPLATE = range(9)
 

@@ -13,7 +13,10 @@ writes are committed, the reference never travels.  What it does:
    peak frequencies the notebooks RECORDED in their stdout (parsed from the
    .ipynb JSON -- reference-held data).
  * K4: the FIR taps printed by "FIR LPF design.ipynb" cell 13.
- * K6: copies three on-device capture triplets (agent/, data files).
+ * K3: IQ_modulation.ipynb cells 4, 13, 16, 22, 28-31 on the reference's chirp.py (`chirp`, `lpf`): the modulated
+   signals, the demodulated base-band signals and the Butterworth coefficients its `lpf` call designs.
+ * K5: ChirpSimulation.ipynb's deterministic cells on the reference's dsp.py `Chirp`.
+ * K6: copies three on-device capture triplets (agent/, data files) and parses ALL 24 into one .npz.
  * K7: sha256 + head of generator/ChirpTone.wav and the regeneration recipe's
    parameters.
 """
@@ -95,6 +98,52 @@ def main():
     arrays["k2_chirp_down"] = sr.chirp(updown="down")
     np.savez_compressed(os.path.join(OUT, "notebook_vectors.npz"), **arrays)
 
+    # ---- K3: IQ_modulation.ipynb (runs ./chirp.py: Fs = 44100, TIME_FRAME = 0.0262, AMPLITUDE = 20000) -----
+    ch = _load_reference_module("ref_chirp", os.path.join(REF, "simulation/chirp.py"))
+    from numpy import linspace, cos, sin, pi
+    BW, CARRIER = 2000, 17000                      # cell 2
+    F0, F1, T = -BW / 2, +BW / 2, ch.TIME_FRAME    # cell 3
+    Fs, AMPLITUDE = ch.Fs, ch.AMPLITUDE
+
+    def carrier_IQ(iq, f=CARRIER, phase=0.0):      # cell 4, verbatim maths on the reference's constants
+        t = linspace(0, T, int(T * Fs))
+        return cos(2 * pi * f * t + phase) if iq == 'I' else sin(2 * pi * f * t + phase)
+
+    def chirp_x_carrier(f0=F0, f1=F1, updown="up"):  # cell 4
+        t = linspace(0, T, int(T * Fs))
+        k = float(f1 - f0) / float(T)
+        f = f0 + k * t / 2.0 if updown == "up" else f1 - k * t / 2.0
+        return cos(2 * pi * (CARRIER - f) * t) * AMPLITUDE
+
+    WW, WWd = chirp_x_carrier(), chirp_x_carrier(updown="down")              # cell 13
+    Ri, Rq = WW * carrier_IQ('I'), WW * carrier_IQ('Q')                      # cell 16
+    Rid, Rqd = WWd * carrier_IQ('I'), WWd * carrier_IQ('Q')
+    CUTOFF = 3000                                                            # cell 22
+    R = ch.lpf(Ri, CUTOFF) + 1j * ch.lpf(Rq, CUTOFF)
+    Rd = ch.lpf(Rid, CUTOFF) + 1j * ch.lpf(Rqd, CUTOFF)
+    ref_chirp = ch.chirp(f0=F0, f1=F1)
+    # the coefficients ch.lpf designs (chirp.py:139-146: buttord + butter with these arguments)
+    from scipy.signal import buttord, butter
+    WP = float(CUTOFF) / float(Fs / 2)
+    Nb, Wn = buttord(wp=WP, ws=1.3 * WP, gpass=2, gstop=30, analog=0)
+    bb, ab = butter(Nb, Wn, btype='low', analog=0, output='ba')
+    k3 = {"k3_WW": WW, "k3_WWd": WWd, "k3_R": R, "k3_Rd": Rd, "k3_chirp": ref_chirp, "k3_butter_b": bb, "k3_butter_a": ab,
+          "k3_absfft_cell28": np.abs(np.fft.fft(R * ref_chirp)), "k3_absfft_cell29": np.abs(np.fft.fft(R * ref_chirp.conjugate())),
+          "k3_absfft_cell30": np.abs(np.fft.fft(Rd * ref_chirp)), "k3_absfft_cell31": np.abs(np.fft.fft(Rd * ref_chirp.conjugate()))}
+    known["IQ_modulation_params"] = {"Fs": Fs, "T": T, "AMPLITUDE": AMPLITUDE, "BW": BW, "CARRIER": CARRIER, "CUTOFF": CUTOFF,
+                                     "samples": int(T * Fs), "butter_order": int(Nb)}
+
+    # ---- K5: ChirpSimulation.ipynb (runs ./dsp.py) cells 2, 6, 7, 13, 14, 20, 22 ------------------------------
+    dsp = _load_reference_module("ref_dsp", os.path.join(REF, "simulation/dsp.py"))
+    c = dsp.Chirp(f0=440, f1=1760, fs=44100, T=0.02, A=20000)
+    cl = dsp.Chirp(f0=440, f1=1760, fs=44100, T=2.0, A=20000)
+    cl2 = dsp.Chirp(f0=440, f1=1760, fs=44100, T=2.0, A=np.sqrt(20000))
+    k5 = {"k5_c_chirp": c.chirp(), "k5_c_chirp_cos": c.chirp_cos(), "k5_c_chirp_down": c.chirp(updown="down"),
+          # 88200-point signals: every 97th sample only (spot checks of this repo's generator)
+          "k5_cl_chirp_s97": cl.chirp()[::97], "k5_cl_chirp_cos_s97": cl.chirp_cos()[::97],
+          "k5_cl2_updown_s97": (cl2.chirp() * cl2.chirp(updown="down"))[::97]}
+    np.savez_compressed(os.path.join(OUT, "notebook_vectors_k3k5.npz"), **k3, **k5)
+
     # ---- K4: FIR taps --------------------------------------------------------
     nb = json.load(open(os.path.join(REF, "simulation/FIR LPF design.ipynb")))
     taps = None
@@ -138,6 +187,45 @@ def main():
         for ext in ("raw", "flt", "fft"):
             shutil.copyfile(os.path.join(REF, src + "." + ext), os.path.join(k6, dst + "." + ext))
             os.chmod(os.path.join(k6, dst + "." + ext), 0o644)
+    # all 24 triplets parsed into arrays (23 are consistent, `chirp_experiment/48.1(kHz)_M2A` is a
+    # mismatched trio and `100.0(kHz)_M1/_M2A`, `48.1(kHz)_M1` lack files)
+    import glob
+
+    def col(path, ncol, which):
+        rows = []
+        with open(path) as f:
+            next(f)
+            for line in f:
+                parts = line.strip().split(",")
+                if len(parts) < ncol:
+                    continue
+                try:
+                    rows.append(float(parts[which]))
+                except ValueError:
+                    continue
+        return np.array(rows)
+
+    allk6 = {}
+    names = []
+    for d in ("agent/chirp_experiment", "agent/vaccum_cleaner"):
+        for raw in sorted(glob.glob(os.path.join(REF, d, "*.raw"))):
+            stem = raw[:-4]
+            if not (os.path.exists(stem + ".flt") and os.path.exists(stem + ".fft")):
+                continue
+            key = "%s/%s" % (os.path.basename(d), os.path.basename(stem))
+            r, fl = col(raw, 2, 1), col(stem + ".flt", 2, 1)
+            fq, fm = col(stem + ".fft", 3, 0), col(stem + ".fft", 3, 1)
+            if r.size != 2048 or fl.size != 2048 or fm.size != 1024:
+                continue
+            i = len(names)
+            names.append(key)
+            allk6["raw_%02d" % i] = r.astype(np.int64)
+            allk6["flt_%02d" % i] = fl
+            allk6["fftfreq_%02d" % i] = fq
+            allk6["fftmag_%02d" % i] = fm
+    allk6["names"] = np.array(names)
+    np.savez_compressed(os.path.join(OUT, "k6_all.npz"), **allk6)
+    print("K6 triplets:", len(names))
     print("wrote", sorted(os.listdir(OUT)))
 
 

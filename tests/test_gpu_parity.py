@@ -16,11 +16,9 @@ ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 import synth
 from oracle import uco
+from parity_util import MAG_TOL, MARGIN, check_history, check_magnitudes, clear_symbols, index_mismatches, prove_ties
 
 pytestmark = pytest.mark.gpu
-
-MAG_TOL = 2e-5       # relative to the frame's largest window magnitude (float64 oracle)
-MARGIN = 1e-3        # decision margin below which a symbol is a declared near-tie
 
 
 @pytest.fixture(scope="module")
@@ -28,37 +26,6 @@ def uchirp():
     import uchirp as m
     m.lib()
     return m
-
-
-def _inv_freq(o, freqs):
-    """idx2freq is injective on the window bins: map frequencies back to indices."""
-    n = o.n
-    cand = list(range(0, o.bandwidth2 + 1)) + list(range(n - o.bandwidth2 - 1, n))
-    lut = {o.idx2freq(i): i for i in cand}
-    return np.array([lut[int(f)] for f in freqs])
-
-
-def _check_hist(o, frames, g, r, label):
-    """g, r: STATS arrays (n_frames,) of one history from GPU / oracle(f64)."""
-    scale = np.maximum(np.maximum(r["mag_max_left"], r["mag_max_right"]).astype(np.float64), 1e-30)
-    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
-        err = np.abs(g[fld].astype(np.float64) - r[fld].astype(np.float64)) / scale
-        assert np.nanmax(err) <= MAG_TOL, "%s %s: rel err %.3g" % (label, fld, np.nanmax(err))
-    bad = np.nonzero((g["max_freq"] != r["max_freq"]) | (g["max_freq_left"] != r["max_freq_left"])
-                     | (g["max_freq_right"] != r["max_freq_right"]))[0]
-    return bad
-
-
-def _assert_peaks_are_ties(o, frames, bad, g, hist, label):
-    """An index mismatch is legal only if the oracle's float64 spectrum has the
-    GPU's bin within MAG_TOL of the oracle's own maximum (a genuine near-tie)."""
-    for f in bad:
-        spec = o.spectrum(frames[f])[0 if hist == 0 else 1]
-        for fld, lo, hi in (("max_freq_right", 0, o.bandwidth2), ("max_freq_left", o.idx_left_zero, o.n)):
-            gi = _inv_freq(o, [g[fld][f]])[0]
-            win = spec[lo:hi]
-            assert win.max() - spec[gi] <= MAG_TOL * win.max(), \
-                "%s frame %d %s: GPU bin %d is not a near-tie" % (label, f, fld, gi)
 
 
 @pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX])
@@ -84,9 +51,7 @@ def test_symbol_decision_matches_oracle(uchirp, variant, snr_db):
         # sweep and errs -- there only GPU == oracle is required (see the matched test)
         assert (gs[clear] == bits[clear]).mean() > 0.97
     for h in (0, 1):
-        bad = _check_hist(o, frames, gst[:, h], rst[:, h], "hist%d" % h)
-        assert len(bad) <= 0.02 * n_frames
-        _assert_peaks_are_ties(o, frames, bad, gst[:, h], h, "hist%d" % h)
+        check_history(o, lambda f: frames[f], gst[:, h], rst[:, h], h, "hist%d" % h)   # every mismatch a proven tie
         np.testing.assert_array_equal(gst[:, h]["mag_mean"], rst[:, h]["mag_mean"])
         snr_err = np.abs(gst[:, h]["snr"].astype(np.float64) - rst[:, h]["snr"]) / np.maximum(np.abs(rst[:, h]["snr"]), 1.0)
         assert snr_err.max() < 1e-4
@@ -142,7 +107,8 @@ def test_int32_ingest_and_process_frame(uchirp):
     gs, gst = e.process(frames)
     assert np.array_equal(gs, rs)
     assert np.array_equal(gs, bits)
-    assert len(_check_hist(o, frames, gst[:, 0], rst[:, 0], "i32")) == 0
+    for h in (0, 1):
+        check_history(o, lambda f: frames[f], gst[:, h], rst[:, h], h, "i32 hist%d" % h)
     # the one-frame entry point preserves process_frame(pcm_in -> symbol_out)
     for f in (0, 5, 63):
         sym, st = e.process_frame(frames[f], mag_mean=1e5)
@@ -165,8 +131,9 @@ def test_overlapping_fifo_reads_stride_256(uchirp):
         su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
         clear = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30) >= MARGIN
         assert np.array_equal(gs[clear], rs[clear])
-        bad = _check_hist(o, None, gst[:, 0], rst[:, 0], "stride%d" % stride)
-        assert len(bad) <= 2
+        for h in (0, 1):
+            check_history(o, lambda f: stream[f * stride: f * stride + 2048], gst[:, h], rst[:, h], h,
+                          "stride%d hist%d" % (stride, h))
 
 
 def test_per_frame_mag_mean(uchirp):
@@ -223,7 +190,8 @@ def test_true_dc_flag_and_q2_default(uchirp):
         e = uchirp.Engine(uchirp.RX_REAL, flags=flags)
         rs, rst = o.process(x)
         gs, gst = e.process(x)
-        assert len(_check_hist(o, x, gst[:, 0], rst[:, 0], "dc")) == 0
+        check_magnitudes(gst[:, 0], rst[:, 0], "dc")
+        assert len(index_mismatches(gst[:, 0], rst[:, 0])) == 0
         assert gst[0, 0]["max_freq"] == 0
         got[flags] = float(gst[0, 0]["mag_max"])
     assert got[0] > 1.05 * got[uco.FLAG_TRUE_DC]  # the Nyquist term is really folded in by default
@@ -238,11 +206,7 @@ def test_dechirp_down_variant(uchirp):
     gs, gst = e.process(frames)
     assert (gs == uchirp.SYM_NONE).all()
     r, g = rst[:, 0], gst[:, 0]
-    scale = np.maximum(r["mag_max"].astype(np.float64), 1e-30)
-    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
-        assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL
-    same = (g["max_freq_right"] == r["max_freq_right"]) & (g["max_freq_left"] == r["max_freq_left"])
-    assert same.mean() >= 0.98
+    check_history(o, lambda f: frames[f], g, r, 0, "dechirp_down", raw_idx=True)
 
 
 @pytest.mark.parametrize("n_frames,stride,dtype", [(97, 0, np.float32), (1, 0, np.float32), (64, 512, np.int32),
@@ -266,12 +230,9 @@ def test_dechirp_down_frame_pairs_ragged_strided_per_frame_floor(uchirp, n_frame
     assert gst.shape == rst.shape == (n_frames, 1) and (gs == uchirp.SYM_NONE).all()
     r, g = rst[:, 0], gst[:, 0]
     scale = np.maximum(r["mag_max"].astype(np.float64), 1e-30)
-    for fld in ("mag_max", "mag_max_left", "mag_max_right"):
-        assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL
+    check_history(o, lambda f: buf[f * st: f * st + 2048], g, r, 0, "dechirp pairs", raw_idx=True)
     assert np.array_equal(g["mag_mean"], mm[:, 0])
     assert np.allclose(g["snr"], r["snr"], rtol=1e-4, atol=1e-4)
-    same = (g["max_freq_right"] == r["max_freq_right"]) & (g["max_freq_left"] == r["max_freq_left"])
-    assert same.mean() >= 0.97
     if n_frames >= 4 and stride == 0:
         # partner independence: swap the partners of every pair, each frame's record must not move
         perm = np.arange(n_frames)
@@ -326,12 +287,8 @@ def test_randomised_configurations(uchirp, case):
     rs, rst = o.process(frames)
     gs, gst = e.process(frames)
     for h in range(o.spf):
-        r, g = rst[:, h], gst[:, h]
-        scale = np.maximum(np.maximum(r["mag_max_left"], r["mag_max_right"]).astype(np.float64), 1e-30)
-        for fld in ("mag_max", "mag_max_left", "mag_max_right"):
-            assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL, (cfg, fld)
-        same = (g["max_freq_right"] == r["max_freq_right"]) & (g["max_freq_left"] == r["max_freq_left"])
-        assert same.mean() >= 0.95, cfg
+        check_history(o, lambda f: frames[f], gst[:, h], rst[:, h], h, "case %d %r hist%d" % (case, cfg, h),
+                      raw_idx=(variant == uco.DECHIRP_DOWN))
     if o.spf == 2:
         su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
         thr = cfg["snr_threshold"]
@@ -466,8 +423,7 @@ def test_compress_variant_fft_h_ifft(uchirp):
     scale = np.abs(r["mag_max"].astype(np.float64))
     assert (np.abs(g["mag_max"].astype(np.float64) - r["mag_max"]) / scale).max() <= MAG_TOL
     same = g["max_freq"] == r["max_freq"]
-    assert same.mean() >= 0.98
-    for f in np.nonzero(~same)[0]:  # an index mismatch must be a near-tie in the oracle's own output
+    for f in np.nonzero(~same)[0]:  # every index mismatch must be a near-tie in the oracle's own output
         y = o.spectrum(frames[f])[0]
         assert y.max() - y[g["max_freq"][f]] <= MAG_TOL * abs(y.max())
     # the compressed pulse follows the circular shift (aligned peak near 1060)
@@ -529,6 +485,21 @@ def _iq_stream(n_frames, seed=5, fs=100000.0, carrier=18000.0, bw=3000.0, amp=10
     return x.astype(np.float32)
 
 
+def _iq_prove_ties(o, specs, scale, g, r, windows):
+    """Firmware-window IQ records: every index mismatch must be a near-tie in the oracle's float64 spectrum
+    (`scale` = what the magnitude tolerance of that test is relative to).  idx2freq of this experiment,
+    (uint32)(fs idx / n), is inverted exactly through the oracle's own idx2freq."""
+    n_ties = 0
+    for fld, (lo_, hi_) in windows.items():
+        inv = {o.idx2freq(i): i for i in range(lo_, hi_)}
+        assert len(inv) == hi_ - lo_
+        for f in np.nonzero(g[fld] != r[fld])[0]:
+            gi = inv[int(g[fld][f])]
+            assert specs[f][lo_:hi_].max() - specs[f][gi] <= MAG_TOL * scale[f], (fld, f, gi)
+            n_ties += 1
+    return n_ties
+
+
 def test_iq_variant_mix_fir_chirp_cfft(uchirp):
     """UC_IQ (experiments/iq_modulation): carrier mix, 27-tap FIR with carried history, complex
     chirp multiply, Hann, CFFT, maxima over [594,838), [594,716), [716,838)."""
@@ -553,15 +524,7 @@ def test_iq_variant_mix_fir_chirp_cfft(uchirp):
     assert (scale > 50 * r["mag_max"]).all()
     for fld in ("mag_max", "mag_max_left", "mag_max_right"):
         assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL, fld
-    for fld in ("max_freq", "max_freq_left", "max_freq_right"):
-        bad = np.nonzero(g[fld] != r[fld])[0]
-        assert len(bad) <= 0.1 * n_frames, fld
-        for f in bad:  # the GPU's bin is within tolerance of the oracle's maximum
-            sp = specs[f]
-            gi = int(round(g[fld][f] * 2048 / 100000.0))
-            lo_, hi_ = {"max_freq": (594, 838), "max_freq_left": (594, 716), "max_freq_right": (716, 838)}[fld]
-            cand = [i for i in (gi - 1, gi, gi + 1) if lo_ <= i < hi_]
-            assert min(sp[lo_:hi_].max() - sp[i] for i in cand) <= MAG_TOL * scale[f]
+    _iq_prove_ties(o, specs, scale, g, r, {"max_freq": (594, 838), "max_freq_left": (594, 716), "max_freq_right": (716, 838)})
     # strided / overlapping frames and int32 words
     rs2, rst2 = o.process(x, halo=26, stride=512, n_frames=64)
     gs2, gst2 = e.process(x, stride=512, n_frames=64)
@@ -680,13 +643,7 @@ def test_iq_variant_at_1024_points_one_wave_per_frame(uchirp):
     scale = np.array([sp[:512].max() for sp in specs])
     for fld in ("mag_max", "mag_max_left", "mag_max_right"):
         assert (np.abs(g[fld].astype(np.float64) - r[fld]) / scale).max() <= MAG_TOL, fld
-    for fld, (lo_, hi_) in (("max_freq", (298, 418)), ("max_freq_left", (298, 358)), ("max_freq_right", (358, 418))):
-        bad = np.nonzero(g[fld] != r[fld])[0]
-        assert len(bad) <= 0.1 * n_frames, fld
-        for f in bad:
-            gi = int(round(g[fld][f] * 1024 / 100000.0))
-            cand = [i for i in (gi - 1, gi, gi + 1) if lo_ <= i < hi_]
-            assert min(specs[f][lo_:hi_].max() - specs[f][i] for i in cand) <= MAG_TOL * scale[f]
+    _iq_prove_ties(o, specs, scale, g, r, {"max_freq": (298, 418), "max_freq_left": (298, 358), "max_freq_right": (358, 418)})
     with pytest.raises(uchirp.UchirpError):
         uchirp.Engine(uchirp.RX_REAL, n=1024)   # only UC_IQ has a 1024-point plan
 

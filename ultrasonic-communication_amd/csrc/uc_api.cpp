@@ -78,6 +78,7 @@ struct uc_ctx {
   // device-resident tables
   float2* d_tab0 = nullptr;
   float2* d_tab1 = nullptr;
+  float2* d_tab2 = nullptr;  // IQ base band: conj(down chirp) * hann
   float2* d_tw = nullptr;
   float* d_aux = nullptr;  // variant-specific (COMPRESS: H_down packed; IQ: carrier/fir/...)
   int32_t* d_cic4 = nullptr;  // sinc^5 byte tables, built on first use of uc_dfsdm_sinc5
@@ -195,6 +196,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 191-bin window the kernel evaluates",
                 c->tab.bandwidth2);
   }
+  const bool iq_bb = cfg->variant == UC_IQ && (cfg->flags & UC_FLAG_IQ_BASEBAND) != 0;
   if (cfg->variant == UC_IQ && c->tab.bandwidth4 > (cfg->n == 1024 ? 128u : 256u)) {
     delete c;
     return fail(-ENOTSUP, "uc_create: IQ window of %u bins exceeds the 256 the kernel evaluates", c->tab.bandwidth4);
@@ -213,7 +215,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   uc::build_twiddles(n, tw);
   rc = upload((void**)&c->d_tw, tw.data(), tw.size() * sizeof(float));
 
-  std::vector<float> t0(2 * (size_t)n, 0.0f), t1(2 * (size_t)n, 0.0f);
+  std::vector<float> t0(2 * (size_t)n, 0.0f), t1(2 * (size_t)n, 0.0f), t2;
   const uc::Tables& T = c->tab;
   switch (cfg->variant) {
     case UC_RX_REAL:
@@ -260,6 +262,16 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
         t1[2 * i] = T.down[2 * i] * T.hann[i];
         t1[2 * i + 1] = T.down[2 * i + 1] * T.hann[i];
       }
+      if (iq_bb) {
+        // R * chirp.conjugate() (IQ_modulation.ipynb cells 29, 30): t1 <- conj(up) * hann, t2 <- conj(down) * hann
+        t2.resize(2 * (size_t)n);
+        for (uint32_t i = 0; i < n; i++) {
+          t1[2 * i] = T.up[2 * i] * T.hann[i];
+          t1[2 * i + 1] = -(T.up[2 * i + 1] * T.hann[i]);
+          t2[2 * i] = T.down[2 * i] * T.hann[i];
+          t2[2 * i + 1] = -(T.down[2 * i + 1] * T.hann[i]);
+        }
+      }
       break;
     case UC_STREAM:
       // t0 <- H/n (spectrum of the zero-padded template), t1 <- per-sample carrier rotation
@@ -271,6 +283,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   }
   if (!rc) rc = upload((void**)&c->d_tab0, t0.data(), t0.size() * sizeof(float));
   if (!rc) rc = upload((void**)&c->d_tab1, t1.data(), t1.size() * sizeof(float));
+  if (!rc && !t2.empty()) rc = upload((void**)&c->d_tab2, t2.data(), t2.size() * sizeof(float));
   if (rc) {
     uc_destroy(c);
     return rc;
@@ -284,6 +297,7 @@ void uc_destroy(uc_ctx* c) {
   (void)hipSetDevice(c->device);
   if (c->d_tab0) (void)hipFree(c->d_tab0);
   if (c->d_tab1) (void)hipFree(c->d_tab1);
+  if (c->d_tab2) (void)hipFree(c->d_tab2);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_aux) (void)hipFree(c->d_aux);
   if (c->d_cic4) (void)hipFree(c->d_cic4);
@@ -299,9 +313,13 @@ void uc_destroy(uc_ctx* c) {
   delete c;
 }
 
+static bool iq_baseband(const uc_ctx* c) {
+  return c->cfg.variant == UC_IQ && (c->cfg.flags & UC_FLAG_IQ_BASEBAND) != 0;
+}
+
 int uc_stats_per_frame(const uc_ctx* c) {
   if (!c) return fail(-EINVAL, "uc_stats_per_frame: NULL ctx");
-  return (c->cfg.variant == UC_RX_REAL || c->cfg.variant == UC_SYNC_CPLX) ? 2 : 1;
+  return (c->cfg.variant == UC_RX_REAL || c->cfg.variant == UC_SYNC_CPLX || iq_baseband(c)) ? 2 : 1;
 }
 
 int uc_iq_halo(const uc_ctx* c) {
@@ -341,7 +359,7 @@ int uc_get_table(const uc_ctx* c, int id, float* out, size_t cap) {
 int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
   if (!c) return 0;
   const uint32_t n = c->cfg.n;
-  if (c->cfg.variant == UC_IQ)  // experiments/iq_modulation/Src/main.c:112-114
+  if (c->cfg.variant == UC_IQ && !iq_baseband(c))  // experiments/iq_modulation/Src/main.c:112-114
     return (int32_t)(uint32_t)(c->cfg.fs * (float)idx / (float)n);
   const uint32_t ifs = (uint32_t)(int32_t)c->cfg.fs;
   if (idx < n / 2) return (int32_t)(ifs * idx / n);
@@ -421,13 +439,22 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
     ip.center = c->tab.center;
     ip.bw2 = c->tab.bandwidth2;
     ip.bw4 = c->tab.bandwidth4;
-    if (c->iq_blocks_per_cu == 0) c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype, (int)n);
+    const bool bb = iq_baseband(c);
+    if (bb) {
+      // the windows straddle DC: the kernel walks UNWRAPPED bins n - bandwidth ... n + bandwidth (taken mod n)
+      ip.chirp_hann2 = c->d_tab2;
+      ip.baseband = 1u;
+      ip.center = n;
+      ip.ifs = (uint32_t)(int32_t)c->cfg.fs;
+      ip.snr_threshold = c->cfg.snr_threshold;
+    }
+    if (c->iq_blocks_per_cu == 0) c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype, (int)n, bb ? 1 : 0);
     size_t grid = (size_t)c->num_cu * (size_t)c->iq_blocks_per_cu;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     if (grid > n_frames) grid = n_frames;
     // groups of up to 64 consecutive frames (one finaliser drain each), dealt round robin;
     // smaller groups when the batch would not give every workgroup one
-    ip.group = 64;
+    ip.group = (bb && n == 2048) ? 32 : 64;  // (the base-band ring of the n = 2048 kernel holds 32 frames)
     while (ip.group > 1 && n_frames < (size_t)ip.group * grid) ip.group >>= 1;
     {
       const size_t ngroups = (n_frames + ip.group - 1) / ip.group;

@@ -54,20 +54,74 @@ __device__ __forceinline__ void window_first_max(float q0, int k0, float q1, int
   k = wave_min_u32(cand);
 }
 
+// UC_FLAG_IQ_BASEBAND (simulation/IQ_modulation.ipynb cells 28-31): one history of dsp() from the two window
+// partials of one dechirp run; the windows straddle DC, searched and merged as receiver/Src/main.c:205-229 does.
+// il is a bin of [n - bandwidth, n), ir an UNWRAPPED bin of [n, n + bandwidth).
+struct BbHist {
+  float mag_max, mag_left, mag_right, snr;
+  int32_t f, fl, fr;
+};
+__device__ __forceinline__ int32_t idx2freq_n(uint32_t ifs, uint32_t idx, uint32_t n) {  // receiver/Src/main.c:154-160
+  if (idx < n / 2) return (int32_t)(ifs * idx / n);
+  return (int32_t)((ifs * (n - idx) / n) * 0xFFFFFFFFu);
+}
+__device__ __forceinline__ BbHist bb_hist(float ql, int il, float qr, int ir, float mm, uint32_t ifs, uint32_t n) {
+  BbHist h;
+  h.mag_left = sqrtf(ql);
+  h.mag_right = sqrtf(qr);
+  const uint32_t idx_l = (uint32_t)il, idx_r = (uint32_t)ir - n;
+  uint32_t idx;
+  if (h.mag_left > h.mag_right) { h.mag_max = h.mag_left; idx = idx_l; } else { h.mag_max = h.mag_right; idx = idx_r; }
+  h.f = idx2freq_n(ifs, idx, n);
+  h.fl = idx2freq_n(ifs, idx_l, n);
+  h.fr = idx2freq_n(ifs, idx_r, n);
+  h.snr = (h.mag_max - mm) / mm;
+  return h;
+}
+__device__ __forceinline__ void bb_store(uc_stats* dst, const BbHist& h, float mm) {
+  float4 a, b;
+  a.x = h.mag_max; a.y = h.mag_left; a.z = h.mag_right; a.w = __int_as_float(h.f);
+  b.x = __int_as_float(h.fl); b.y = __int_as_float(h.fr); b.z = mm; b.w = h.snr;
+  float4* d = reinterpret_cast<float4*>(dst);
+  d[0] = a;
+  d[1] = b;
+}
+// both histories of one frame + the symbol decision (receiver/Src/main.c:518-531); e0 / e1 = (ql, il, qr, ir) of the runs
+__device__ __forceinline__ void bb_finish(const IqParams& p, size_t ff, float ql0, int il0, float qr0, int ir0, float ql1,
+                                          int il1, float qr1, int ir1, uint32_t n) {
+  const float mm_up = p.mag_mean ? p.mag_mean[2 * ff] : p.mag_mean_scalar;
+  const float mm_dn = p.mag_mean ? p.mag_mean[2 * ff + 1] : p.mag_mean_scalar;
+  const BbHist h0 = bb_hist(ql0, il0, qr0, ir0, mm_up, p.ifs, n);
+  const BbHist h1 = bb_hist(ql1, il1, qr1, ir1, mm_dn, p.ifs, n);
+  if (p.stats) {
+    bb_store(p.stats + 2 * ff, h0, mm_up);
+    bb_store(p.stats + 2 * ff + 1, h1, mm_dn);
+  }
+  if (p.symbols) {
+    uint8_t sym = (uint8_t)UC_SYM_NONE;
+    if ((h0.snr >= p.snr_threshold) || (h1.snr >= p.snr_threshold))
+      sym = (h1.snr > h0.snr) ? (uint8_t)UC_SYM_DOWN : (uint8_t)UC_SYM_UP;
+    p.symbols[ff] = sym;
+  }
+}
+
 // LDS: the padded mixed image (also exchange 1), a second tile (FIR outputs, exchange 2) and the
 // ring of per-frame window partials.  Ping-ponging between image and tile leaves ONE barrier per
 // exchange: a buffer is rewritten only after a barrier that follows its last read.
 constexpr int kImg = T * 17 + ((T * 17) >> 4) + 4;  // 2316: every m = j + 128 u, u < 17, has a slot
-constexpr int kRingFr = 64;
+constexpr int kRingFr = 64;                         // (base band: 32 frames of 2 runs each, same footprint)
 constexpr int kRingSt = 11;                         // 2 waves x (vl, kl, vr, kr, flags) + 1 pad
+constexpr int kRingStBb = 21;                       // 2 runs x 2 waves x 5 + 1 pad
+constexpr int kRingFrBb = 32;
 constexpr int kTileOff = 2 * kImg;
 constexpr int kRingO = kTileOff + 2 * kN;
 constexpr int kTw2O = kRingO + kRingFr * kRingSt;  // even: 8-byte aligned
 constexpr int kLdsAll = kTw2O + 2 * 256;
 static_assert((kTw2O & 1) == 0, "complex alignment");
 static_assert(kImg >= kN, "exchange 1 lives in the image area");
+static_assert(kRingFrBb * kRingStBb <= kRingFr * kRingSt, "the base-band ring fits the same LDS");
 
-template <int DTYPE>
+template <int DTYPE, bool BB>
 __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   __shared__ __attribute__((aligned(16))) float lds[kLdsAll];
   float* img = lds;
@@ -89,6 +143,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN * 8);
+  const __amdgpu_buffer_rsrc_t rs_ch2 = make_rsrc(BB ? p.chirp_hann2 : p.chirp_hann, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
   const int voff8 = j * 8;
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);
@@ -145,6 +200,28 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   // finaliser: lane L of wave 0 merges the two waves' partials of ring slot L into the history
   // record of frame f0 + L (experiments/iq_modulation/Src/main.c:283-303)
   auto finalise = [&](size_t f0, int count) {
+    if (BB) {
+      if (lane < count) {
+        const float* e = ring + lane * kRingStBb;
+        float ql[2], qr[2];
+        int il[2], ir[2];
+#pragma unroll
+        for (int run = 0; run < 2; run++) {
+          const float* er = e + 10 * run;
+          const float a0 = er[0], a1 = er[5], b0 = er[2], b1 = er[7];
+          const int ka0 = __float_as_int(er[1]), ka1 = __float_as_int(er[6]);
+          const int kb0 = __float_as_int(er[3]), kb1 = __float_as_int(er[8]);
+          const int flags = __float_as_int(er[4]) | __float_as_int(er[9]);
+          ql[run] = a0; qr[run] = b0; il[run] = ka0; ir[run] = kb0;
+          if (a1 > a0 || (a1 == a0 && ka1 < ka0)) { ql[run] = a1; il[run] = ka1; }
+          if (b1 > b0 || (b1 == b0 && kb1 < kb0)) { qr[run] = b1; ir[run] = kb1; }
+          if (flags & 1) { ql[run] = __int_as_float(0x7fc00000); il[run] = lo; }
+          if (flags & 2) { qr[run] = __int_as_float(0x7fc00000); ir[run] = center; }
+        }
+        bb_finish(p, f0 + (size_t)lane, ql[0], il[0], qr[0], ir[0], ql[1], il[1], qr[1], ir[1], (uint32_t)kN);
+      }
+      return;
+    }
     if (lane < count) {
       const float* e = ring + lane * kRingSt;
       const size_t ff = f0 + (size_t)lane;
@@ -238,26 +315,40 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     __syncthreads();  // B2: filtered frame in the tile; every window read of the image is done
 
     // ---- stage 2: (I + jQ) * down_chirp * hann, FFT pass 1 -------------------------------
+    // Base band: two dechirp runs (conj(up), conj(down)) over the SAME filtered frame.  Run 0 keeps the
+    // filtered frame in `tile` intact: its pass 2 goes back into the image area (one more barrier), and its
+    // pruned pass reads from there.
+    constexpr int kRuns = BB ? 2 : 1;
+#pragma unroll
+    for (int run = 0; run < kRuns; run++) {
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rd1o : rd1e) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
+    if (run == 0) {
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], buf_ld64(rs_ch2, voff8, T * 8 * t));
+    }
     pk_dft16(v, K, H);
+    if (run) __syncthreads();  // run 0's pruned pass has read the image area
 #pragma unroll
     for (int t = 0; t < 16; t++) lds_st(img, wr1 + (t ^ s1v), v[pk_slot16(t)]);
     __syncthreads();  // B3
 
     // ---- FFT pass 2 -----------------------------------------------------------------------
+    float* dst2 = (BB && run == 0) ? img : tile;
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = lds_ld(img, ((t & 1) ? rd1o : rd1e) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2l, tw2o + 16 * t));
     pk_dft16(v, K, H);
+    if (BB && run == 0) __syncthreads();  // every pass-2 read of the image area is done
 #pragma unroll
-    for (int t = 0; t < 16; t++) lds_st(tile, wr2 + 16 * t, v[pk_slot16(t)]);
+    for (int t = 0; t < 16; t++) lds_st(dst2, wr2 + 16 * t, v[pk_slot16(t)]);
     __syncthreads();  // B4
 
     // ---- FFT pass 3, pruned: bins k = lo + j and k = lo + 128 + j (< lo + bw4) ------------
@@ -268,7 +359,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
       for (int r = 0; r < 2; r++) {
         const int b = (lo + T * r + j) & 255;
 #pragma unroll
-        for (int t = 0; t < 8; t++) a[r][t] = lds_ld(tile, b + 256 * t);
+        for (int t = 0; t < 8; t++) a[r][t] = lds_ld(dst2, b + 256 * t);
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -294,15 +385,16 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
       const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
       const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
       if (lane == 0) {
-        float* e = ring + ring_n * kRingSt + 5 * wave;
+        float* e = ring + ring_n * (BB ? kRingStBb : kRingSt) + 5 * wave + 10 * run;
         e[0] = vl;
         e[1] = __int_as_float(kl);
         e[2] = vr;
         e[3] = __int_as_float(kr);
         e[4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
       }
-      ring_n++;
     }
+    }  // run
+    ring_n++;
     if (!has_next) break;
     f = fnext;
   }
@@ -331,14 +423,19 @@ constexpr int kMixLen1 = kN1 + kHalo;                     // 1050
 constexpr int kImg1 = T1 * 17 + ((T1 * 17) >> 4) + 4;     // 1160: every m = j + 64 u, u < 17, has a slot
 constexpr int kRing1 = 64;                                // frames per finaliser drain
 constexpr int kRingStride1 = 5;                           // ql, il, qr, ir, flags (odd: conflict-free)
+constexpr int kRingStride1Bb = 11;                        // base band: 2 runs x 5 + 1 pad
 constexpr int kRingOff1 = 2 * kImg1;
 constexpr int kLdsFloats1 = kRingOff1 + kRing1 * kRingStride1;
+constexpr int kTab1Off = kRingOff1 + kRing1 * kRingStride1Bb;   // base band: the second chirp*hann table (8 KiB)
+constexpr int kLdsFloats1Bb = kTab1Off + 2 * kN1;
 static_assert(kImg1 >= kN1, "the FFT tile aliases the mixed image");
+static_assert((kTab1Off & 1) == 0, "complex alignment");
 
-template <int DTYPE>
+template <int DTYPE, bool BB>
 __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats1];
+  __shared__ __attribute__((aligned(16))) float lds[BB ? kLdsFloats1Bb : kLdsFloats1];
   float* ring = lds + kRingOff1;
+  float* tab1l = lds + (BB ? kTab1Off : 0);
   const int j = threadIdx.x;  // = lane
 
   // frames are dealt in groups of G consecutive frames, round robin over the workgroups
@@ -371,6 +468,12 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   v2f ch[16];  // chirp*hann of sample n = j + 64 t
 #pragma unroll
   for (int t = 0; t < 16; t++) ch[t] = buf_ld64(rs_ch, j * 8, T1 * 8 * t);
+  if (BB) {  // the second run's table lives in LDS (no registers left for it, and a load in the loop would queue
+             // behind the frame prefetch): entry n at complex index n, read as n = j + 64 t
+    const __amdgpu_buffer_rsrc_t rs_ch2 = make_rsrc(p.chirp_hann2, kN1 * 8);
+#pragma unroll
+    for (int t = 0; t < 16; t++) lds_st(tab1l, j + T1 * t, buf_ld64(rs_ch2, j * 8, T1 * 8 * t));
+  }
   // pass-2 twiddles W_128^(t k) = W_1024^(8 t k), k = b & 15 = j & 15 for both butterflies b = j, j + 64
   v2f tw2[8];
 #pragma unroll
@@ -408,6 +511,24 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   // finaliser: lane L turns ring slot L into the history record of frame f0 + L
   // (experiments/iq_modulation/Src/main.c:283-303)
   auto finalise = [&](size_t f0, int count) {
+    if (BB) {
+      if (j < count) {
+        const float* e = ring + j * kRingStride1Bb;
+        float ql[2], qr[2];
+        int il[2], ir[2];
+#pragma unroll
+        for (int run = 0; run < 2; run++) {
+          const float* er = e + 5 * run;
+          ql[run] = er[0]; qr[run] = er[2];
+          il[run] = __float_as_int(er[1]); ir[run] = __float_as_int(er[3]);
+          const int flags = __float_as_int(er[4]);
+          if (flags & 1) { ql[run] = __int_as_float(0x7fc00000); il[run] = lo; }
+          if (flags & 2) { qr[run] = __int_as_float(0x7fc00000); ir[run] = center; }
+        }
+        bb_finish(p, f0 + (size_t)j, ql[0], il[0], qr[0], ir[0], ql[1], il[1], qr[1], ir[1], (uint32_t)kN1);
+      }
+      return;
+    }
     if (j < count) {
       const float* e = ring + j * kRingStride1;
       const size_t ff = f0 + (size_t)j;
@@ -491,6 +612,10 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
       ring_f0 = f;
       ring_n = 0;
     }
+    // Base band: two dechirp runs (conj(up), conj(down)) over the same filtered frame, which stays in accA / accB.
+    constexpr int kRuns = BB ? 2 : 1;
+#pragma unroll
+    for (int run = 0; run < kRuns; run++) {
 #pragma unroll
     for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
     __syncthreads();
@@ -499,9 +624,18 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
     v2f v[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rdn[t & 3] + 64 * t);
-    __builtin_amdgcn_sched_barrier(0);
+    if (run == 0) {
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
+    } else {
+      v2f c2[16];
+#pragma unroll
+      for (int t = 0; t < 16; t++) c2[t] = lds_ld(tab1l, j + T1 * t);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], c2[t]);
+    }
     pk_dft16(v, K, H);
     __syncthreads();
 #pragma unroll
@@ -554,7 +688,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
         q[r] = z.x * z.x + z.y * z.y;
       }
     }
-    __syncthreads();  // tile free for the next frame
+    __syncthreads();  // tile free for the next run / frame
 
     // ---- windows (one wave: no merge step) -----------------------------------------------------
     {
@@ -568,15 +702,16 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
       const unsigned long long nl = __ballot(k0 == lo && q[0] != q[0]);
       const unsigned long long nr = __ballot((k0 == center && q[0] != q[0]) || (k1 == center && q1v != q1v));
       if (j == 0) {
-        float* e = ring + ring_n * kRingStride1;
+        float* e = ring + ring_n * (BB ? kRingStride1Bb : kRingStride1) + 5 * run;
         e[0] = ql;
         e[1] = __int_as_float(il);
         e[2] = qr;
         e[3] = __int_as_float(ir);
         e[4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
       }
-      ring_n++;
     }
+    }  // run
+    ring_n++;
     if (!has_next) break;
     f = fnext;
   }
@@ -586,34 +721,48 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
 
 }  // namespace
 
+namespace {
+
+template <typename F>
+int occ(F kernel, int threads, int fallback) {
+  int nb = 0;
+  const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, threads, 0);
+  return (e != hipSuccess || nb <= 0) ? fallback : nb;
+}
+
+}  // namespace
+
+#define UC_IQ_DISPATCH(CALL1024, CALL2048)                                  \
+  do {                                                                      \
+    const bool i32 = dtype == UC_DTYPE_I32;                                 \
+    if (n == kN1) {                                                         \
+      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, true); } else { CALL1024(UC_DTYPE_F32, true); } }     \
+      else    { if (i32) { CALL1024(UC_DTYPE_I32, false); } else { CALL1024(UC_DTYPE_F32, false); } }   \
+    } else {                                                                \
+      if (bb) { if (i32) { CALL2048(UC_DTYPE_I32, true); } else { CALL2048(UC_DTYPE_F32, true); } }     \
+      else    { if (i32) { CALL2048(UC_DTYPE_I32, false); } else { CALL2048(UC_DTYPE_F32, false); } }   \
+    }                                                                       \
+  } while (0)
+
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n) {
   if (grid <= 0) return (int)hipSuccess;
-  if (n == kN1) {
-    if (dtype == UC_DTYPE_I32)
-      hipLaunchKernelGGL((iq1024_kernel<UC_DTYPE_I32>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p);
-    else
-      hipLaunchKernelGGL((iq1024_kernel<UC_DTYPE_F32>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p);
-    return (int)hipGetLastError();
-  }
-  if (dtype == UC_DTYPE_I32)
-    hipLaunchKernelGGL((iq_kernel<UC_DTYPE_I32>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
-  else
-    hipLaunchKernelGGL((iq_kernel<UC_DTYPE_F32>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  const bool bb = p.baseband != 0;
+#define UC_L1024(D, B) hipLaunchKernelGGL((iq1024_kernel<D, B>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p)
+#define UC_L2048(D, B) hipLaunchKernelGGL((iq_kernel<D, B>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p)
+  UC_IQ_DISPATCH(UC_L1024, UC_L2048);
+#undef UC_L1024
+#undef UC_L2048
   return (int)hipGetLastError();
 }
 
-int iq_max_blocks_per_cu(int dtype, int n) {
+int iq_max_blocks_per_cu(int dtype, int n, int baseband) {
+  const bool bb = baseband != 0;
   int nb = 0;
-  if (n == kN1) {
-    hipError_t e1 = dtype == UC_DTYPE_I32
-                        ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq1024_kernel<UC_DTYPE_I32>, T1, 0)
-                        : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq1024_kernel<UC_DTYPE_F32>, T1, 0);
-    if (e1 != hipSuccess || nb <= 0) nb = 8;
-    return nb;
-  }
-  hipError_t e = dtype == UC_DTYPE_I32 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq_kernel<UC_DTYPE_I32>, T, 0)
-                                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, iq_kernel<UC_DTYPE_F32>, T, 0);
-  if (e != hipSuccess || nb <= 0) nb = 4;
+#define UC_O1024(D, B) nb = occ(iq1024_kernel<D, B>, T1, 8)
+#define UC_O2048(D, B) nb = occ(iq_kernel<D, B>, T, 4)
+  UC_IQ_DISPATCH(UC_O1024, UC_O2048);
+#undef UC_O1024
+#undef UC_O2048
   return nb;
 }
 

@@ -63,7 +63,8 @@ struct IqParams {
   size_t n_frames;
   size_t stride;
   const float2* carrier;      // (cos, sin) of the carrier, n entries
-  const float2* chirp_hann;   // down chirp (cos, sin) * hann, n entries
+  const float2* chirp_hann;   // down chirp (cos, sin) * hann, n entries; base band: conj(up chirp) * hann
+  const float2* chirp_hann2;  // base band only: conj(down chirp) * hann
   const float2* tw;
   const float* mag_mean;      // device, 2 per frame (first used), or nullptr
   uint8_t* symbols;
@@ -73,10 +74,15 @@ struct IqParams {
   float fs;
   uint32_t idx_left_zero, center, bw2, bw4;
   uint32_t group;             // frames per round-robin group (power of two, <= 64)
+  // UC_FLAG_IQ_BASEBAND: two histories {up, down} per frame and a symbol; the windows straddle DC:
+  // idx_left_zero = n - bandwidth, center = n (bins are taken mod n), bw2 = bandwidth, bw4 = 2 bandwidth
+  uint32_t baseband;
+  uint32_t ifs;               // (uint32_t)(int32_t)fs for the receiver's integer idx2freq
+  float snr_threshold;
 };
 // n = 2048 (the committed firmware) or 1024 (one wave per frame)
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
-int iq_max_blocks_per_cu(int dtype, int n);
+int iq_max_blocks_per_cu(int dtype, int n, int baseband);
 
 // UC_STREAM: FIR-LPF decimating front-end + overlap-save chirp compression (include/uchirp.h).
 struct StreamParams {

@@ -288,7 +288,16 @@ int build_tables(const uc_config& cfg, Tables& out) {
     out.bandwidth2 = out.bandwidth * 8;
     out.idx_left_zero = n - out.bandwidth2;
   }
-  if (cfg.variant == UC_IQ) {
+  const bool iq_bb = cfg.variant == UC_IQ && (cfg.flags & UC_FLAG_IQ_BASEBAND) != 0;
+  if (iq_bb) {
+    // simulation/IQ_modulation.ipynb cells 28-31: the dechirped tone sits at DC; windows of `bandwidth` bins
+    // either side of it, searched as receiver/Src/main.c:205-215 searches its two
+    out.bandwidth2 = out.bandwidth;  // the window length
+    out.idx_left_zero = n - out.bandwidth;
+    out.center = 0;
+    out.bandwidth4 = 2 * out.bandwidth;
+    if (out.bandwidth == 0 || out.bandwidth4 > n / 2) return -EINVAL;
+  } else if (cfg.variant == UC_IQ) {
     // iq_modulation/Src/main.c:215-219
     out.center = (uint32_t)((cfg.f0 + cfg.f1) * (float)n / cfg.fs);
     out.bandwidth4 = out.bandwidth * 4;
@@ -326,8 +335,11 @@ int build_tables(const uc_config& cfg, Tables& out) {
     }
     case UC_IQ: {
       hann_window(out.hann, n, periodic, tr);
-      chirp_degrees(out.up, n, true, cfg.f0, cfg.f1, tf, cfg.fs, cfg.phase_deg, true, tr);
-      chirp_degrees(out.down, n, false, cfg.f0, cfg.f1, tf, cfg.fs, cfg.phase_deg, true, tr);
+      // UC_FLAG_IQ_BASEBAND: BASE-BAND reference chirps (IQ_modulation.ipynb cell 3: F0 = -BW/2, F1 = +BW/2 around
+      // the carrier) from the firmware's own generator
+      const float off = iq_bb ? cfg.carrier : 0.0f;
+      chirp_degrees(out.up, n, true, cfg.f0 - off, cfg.f1 - off, tf, cfg.fs, cfg.phase_deg, true, tr);
+      chirp_degrees(out.down, n, false, cfg.f0 - off, cfg.f1 - off, tf, cfg.fs, cfg.phase_deg, true, tr);
       // init_iq_modem: iq_modulation/Src/iq_modem.c:34-45
       out.carrier_c.resize(n);
       out.carrier_s.resize(n);
