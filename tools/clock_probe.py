@@ -29,7 +29,7 @@ if zeros:
 sym = torch.empty(nf, dtype=torch.uint8, device=dev)
 variant = int(os.environ.get("UC_VARIANT", "0"))
 e = uchirp.Engine(variant, mag_mean=1000.0)
-dbg = torch.zeros(8192 * 2 * 2, dtype=torch.int64, device=dev)
+dbg = torch.zeros(8192 * 2 * 4, dtype=torch.int64, device=dev)
 os.environ["UC_DEBUG_PTR"] = str(dbg.data_ptr())
 stream = torch.cuda.current_stream(dev)
 want_sym = variant in (0, 1)
@@ -56,8 +56,11 @@ a.record(stream)
 launch()
 b.record(stream)
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(-1, 2)
+d = dbg.cpu().numpy().reshape(-1, 4)
 d = d[d[:, 1] > 0].astype(np.float64)
+t_first, t_last = d[:, 2].min(), d[:, 3].max()
+start_us, end_us, life_us = (d[:, 2] - t_first) / 100.0, (d[:, 3] - t_first) / 100.0, d[:, 1] / 100.0
+pct = lambda v: [float(np.percentile(v, q)) for q in (0, 10, 50, 90, 100)]
 clk = d[:, 0] / d[:, 1] * 100.0  # MHz: s_memrealtime ticks at 100 MHz
 out = {"kernel": "band_kernel variant %d (%s data)" % (variant, "zero" if zeros else "random"), "frames": nf,
        "launches_before_stamp": n, "seconds_of_back_to_back_launches": secs, "ms_per_launch_wall": wall * 1e3,
@@ -65,5 +68,8 @@ out = {"kernel": "band_kernel variant %d (%s data)" % (variant, "zero" if zeros 
        "shader_clock_MHz_median": float(np.median(clk)), "shader_clock_MHz_p10": float(np.percentile(clk, 10)),
        "shader_clock_MHz_p90": float(np.percentile(clk, 90)),
        "loop_cycles_median": float(np.median(d[:, 0])), "loop_us_median": float(np.median(d[:, 1]) / 100.0),
-       "frames_per_s": nf / wall}
+       "frames_per_s": nf / wall,
+       "grid_span_us_first_start_to_last_end": float((t_last - t_first) / 100.0),
+       "wave_start_us_p0_10_50_90_100": pct(start_us), "wave_end_us_p0_10_50_90_100": pct(end_us),
+       "wave_life_us_p0_10_50_90_100": pct(life_us)}
 print(json.dumps(out))

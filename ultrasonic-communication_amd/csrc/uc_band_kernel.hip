@@ -661,8 +661,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #endif
 #ifdef UC_CLOCKSTAMP
   if (lane == 0 && p.debug) {
-    p.debug[((size_t)blockIdx.x * 2 + wave) * 2 + 0] = __builtin_readcyclecounter() - clk0_;
-    p.debug[((size_t)blockIdx.x * 2 + wave) * 2 + 1] = __builtin_amdgcn_s_memrealtime() - rt0_;
+    const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* d_ = p.debug + ((size_t)blockIdx.x * 2 + wave) * 4;
+    d_[0] = __builtin_readcyclecounter() - clk0_;
+    d_[1] = rt1_ - rt0_;
+    d_[2] = rt0_;  // absolute 100 MHz stamps: start / end skew across the grid
+    d_[3] = rt1_;
   }
 #endif
 }

@@ -303,6 +303,14 @@ class Engine:
             stt = stats_out
             if stt is None and want_stats:
                 stt = torch.empty((n_frames, self.spf, 8), dtype=torch.float32, device=dev)
+            # the kernels write n_frames records: a caller's buffer that is too small would be overrun on the device
+            if sym is not None and (sym.dtype != torch.uint8 or sym.numel() < n_frames or not sym.is_contiguous()
+                                    or sym.device != dev):
+                raise ValueError("symbols_out must be a contiguous uint8 tensor of >= %d elements on %s" % (n_frames, dev))
+            if stt is not None and (stt.dtype != torch.float32 or stt.numel() < n_frames * self.spf * 8
+                                    or not stt.is_contiguous() or stt.device != dev):
+                raise ValueError("stats_out must be a contiguous float32 tensor of >= %d x %d x 8 elements on %s"
+                                 % (n_frames, self.spf, dev))
             mm_ptr = None
             if mag_mean is not None:
                 mm = mag_mean.to(device=dev, dtype=torch.float32).contiguous()
