@@ -123,8 +123,10 @@ def test_baseband_noisy_stream_matches_oracle_and_decodes(uchirp, n, dtype):
         clear = clear_symbols(rst)
         assert clear.mean() > 0.98
         assert np.array_equal(gs[clear], rs[clear])
-        # (half the processing gain at n = 1024: 1.3 % of the -10 dB symbols are wrong there -- in the oracle too)
-        assert (gs == bits).mean() > (0.995 if n == 2048 else 0.97), (gs == bits).mean()
+        if mag_mean is None:
+            # (with a per-frame floor the up and down histories are normalised differently: no decode claim there;
+            # half the processing gain at n = 1024: 1.3 % of the -10 dB symbols are wrong -- in the oracle too)
+            assert (gs == bits).mean() > (0.995 if n == 2048 else 0.97), (gs == bits).mean()
         ties = 0
         for h in (0, 1):
             ties += check_history(o, lambda f: x[f * n: f * n + n + 26], gst[:, h], rst[:, h], h, "bb n=%d hist%d" % (n, h),

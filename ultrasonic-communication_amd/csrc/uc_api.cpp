@@ -69,6 +69,8 @@ bool is_device_ptr(const void* p) {
 
 }  // namespace
 
+constexpr unsigned kWorkSlots = 64, kWorkStride = 128;
+
 struct uc_ctx {
   uc_config cfg;
   uc::Tables tab;
@@ -87,13 +89,19 @@ struct uc_ctx {
   DevBuf s_cic_in, s_cic_out;
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
-  int band_blocks_per_cu[3] = {0, 0, 0};
+  int band_blocks_per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}};  // [mode][dtype]: the instantiations differ in registers
   int full_blocks_per_cu = 0;
   int iq_blocks_per_cu = 0;
   int stream_blocks_per_cu = 0;
   DevBuf s_comp, s_peaks;
-  int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID): not part of the ABI
+  int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID / UC_BAND_GROUP / UC_STATIC_DEAL): not part of the ABI
   int grid_override = 0;
+  int band_group = 32;    // frames per group handed to a workgroup at a time
+  bool static_deal = false;
+  // work counters for the dynamic group hand-out: one word per launch, a ring so that launches of one context that
+  // overlap on different streams never share one (each word sits in its own 128-byte line)
+  unsigned int* d_work = nullptr;
+  unsigned work_next = 0;
 };
 
 extern "C" {
@@ -178,6 +186,11 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     if (v >= 2 && v <= 4) c->band_waves = v;
   }
   if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
+  if (const char* g = getenv("UC_BAND_GROUP")) {
+    const int v = atoi(g);
+    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
+  }
+  if (const char* g = getenv("UC_STATIC_DEAL")) c->static_deal = atoi(g) != 0;
   int rc = uc::build_tables(*cfg, c->tab);
   if (rc) {
     delete c;
@@ -281,6 +294,10 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     default:
       break;
   }
+  if (!rc) {
+    e = hipMalloc((void**)&c->d_work, (size_t)kWorkSlots * kWorkStride);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(work counters)");
+  }
   if (!rc) rc = upload((void**)&c->d_tab0, t0.data(), t0.size() * sizeof(float));
   if (!rc) rc = upload((void**)&c->d_tab1, t1.data(), t1.size() * sizeof(float));
   if (!rc && !t2.empty()) rc = upload((void**)&c->d_tab2, t2.data(), t2.size() * sizeof(float));
@@ -299,6 +316,7 @@ void uc_destroy(uc_ctx* c) {
   if (c->d_tab1) (void)hipFree(c->d_tab1);
   if (c->d_tab2) (void)hipFree(c->d_tab2);
   if (c->d_tw) (void)hipFree(c->d_tw);
+  if (c->d_work) (void)hipFree(c->d_work);
   if (c->d_aux) (void)hipFree(c->d_aux);
   if (c->d_cic4) (void)hipFree(c->d_cic4);
   if (c->d_cic1) (void)hipFree(c->d_cic1);
@@ -375,6 +393,7 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
     return fail(-EINVAL, "uc_process_batch: UC_STREAM has no frames, use uc_process_stream");
   if (n_frames == 0) return 0;
   if (!frames) return fail(-EINVAL, "uc_process_batch: frames is NULL");
+  if (n_frames >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_process_batch: at most 2^31 - 1 frames per call");
   const uint32_t n = c->cfg.n;
   if (stride_elems == 0) stride_elems = n;
   const int variant = c->cfg.variant;
@@ -510,11 +529,26 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
 #endif
   const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
                    : (variant == UC_DECHIRP_DOWN) ? uc::kModePair : uc::kModeRxReal;
-  int& bpc = c->band_blocks_per_cu[mode];
+  int& bpc = c->band_blocks_per_cu[mode][dtype == UC_DTYPE_I32 ? 0 : 1];
   if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, c->band_waves);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
-  if (grid > n_frames) grid = n_frames;
+  // units of work: frames, or frame pairs (DECHIRP_DOWN).  Groups of `band_group` units; smaller ones when the batch
+  // would not give every workgroup a few (a small batch then still spreads over the whole chip)
+  const size_t units = (mode == uc::kModePair) ? (n_frames + 1) / 2 : n_frames;
+  uint32_t group = (uint32_t)c->band_group;
+  while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;
+  const size_t ngroups = (units + group - 1) / group;
+  if (grid > ngroups) grid = ngroups;
+  p.group_log2 = 0;
+  while ((1u << p.group_log2) < group) p.group_log2++;
+  p.work_ctr = nullptr;
+  if (!c->static_deal && group >= 2 && ngroups > grid) {
+    // dynamic hand-out: the counter of this launch is zeroed on the stream right before it
+    p.work_ctr = (unsigned int*)((char*)c->d_work + (size_t)(c->work_next++ % kWorkSlots) * kWorkStride);
+    e = hipMemsetAsync(p.work_ctr, 0, sizeof(unsigned int), stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(work counter)");
+  }
   int lrc = uc::launch_band(mode, dtype, c->band_waves, p, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
   }

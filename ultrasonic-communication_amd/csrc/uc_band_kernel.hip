@@ -41,7 +41,8 @@ constexpr int T = kBandThreads;  // 128
 constexpr int kRingFrames = 64;
 constexpr int kRingStride = 13;  // 2 waves x 6 words + 1 pad word (conflict-free lane-strided reads)
 constexpr int kRingOff = 2 * kN;
-constexpr int kLdsFloats = kRingOff + kRingFrames * kRingStride;
+constexpr int kNextOff = kRingOff + kRingFrames * kRingStride;  // one word: the group this workgroup takes next
+constexpr int kLdsFloats = kNextOff + 1;
 
 constexpr float kCos16 = 0.98078528040323044913f;  // cos(pi/16)
 constexpr float kSin16 = 0.19509032201612826785f;  // sin(pi/16)
@@ -282,19 +283,31 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const int wave = j >> 6;
   const int bw2 = (int)p.bw2;
 
-  // Frames are dealt to workgroups in GROUPS of 64 consecutive frames (512 KiB), round robin:
-  // all resident workgroups together sweep a window of a few hundred MiB through the batch
-  // instead of each walking its own multi-MiB chunk of an 8+ GiB buffer (measured: the
-  // per-frame time grew with the batch size with contiguous chunks), while the finaliser
-  // still owns 64 consecutive frames (coalesced symbol stores).
+  // Frames are dealt to workgroups in GROUPS of p.group consecutive frames: all resident workgroups
+  // together sweep a window of a few hundred MiB through the batch instead of each walking its own
+  // multi-MiB chunk of an 8+ GiB buffer (measured: the per-frame time grew with the batch size with
+  // contiguous chunks), while the finaliser still owns consecutive frames (coalesced symbol stores).
+  // Workgroup b starts with group b; every further group comes from an atomic counter (p.work_ctr):
+  // the workgroups do NOT run at the same speed -- with one frame of prefetch per workgroup the ones whose
+  // loads come back late are latency-bound (measured: the same share took 1.32 ms on the fastest and 2.20 ms
+  // on the slowest workgroup, profiles/r02_v0_clock_skew.json) -- so a static deal ends with a long tail.
+  // The id of the next group is fetched one group ahead and parked in LDS (no wait in the loop).
   // kModePair: the unit of work is a PAIR of frames (2u, 2u+1) riding in one complex transform
   constexpr bool kPair = MODE == kModePair;
   constexpr bool kReal = MODE != kModeCplx;  // real reference(s): Hermitian split in the pruned pass
-  const size_t nfr = kPair ? (p.n_frames + 1) / 2 : p.n_frames;
-  const size_t ngroups = (nfr + kRingFrames - 1) / kRingFrames;
-  size_t grp = blockIdx.x;
+  // (32-bit bookkeeping: the host rejects batches of 2^31 frames or more; the frame ADDRESS is 64-bit)
+  const unsigned nfr = (unsigned)(kPair ? (p.n_frames + 1) / 2 : p.n_frames);
+  const unsigned gsh = p.group_log2, gmask = (1u << gsh) - 1u;
+  const unsigned ngroups = (nfr + gmask) >> gsh;
+  unsigned grp = blockIdx.x;
   if (grp >= ngroups) return;
-  size_t f = grp * kRingFrames;
+  unsigned f = grp << gsh;
+  const bool dyn = p.work_ctr != nullptr;
+  unsigned* next_slot = reinterpret_cast<unsigned*>(lds + kNextOff);
+  // thread 0: the group id an in-flight atomic returns.  It is parked in LDS in the first frame of every group
+  // (the frame after the one that issued it), once that frame's loads -- older than the atomic -- are consumed.
+  unsigned fetched = 0;
+  if (dyn && j == 0) fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
 
   // ---- per-thread constants, resident for the whole batch -----------------
   const __amdgpu_buffer_rsrc_t rs_tab0 = make_rsrc(p.tab0, kN * 8);
@@ -351,7 +364,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     if (kPair) {
       const bool has_b = 2 * u + 1 < p.n_frames;  // a ragged last pair: frame b reads as zeros
       const __amdgpu_buffer_rsrc_t ra =
-          make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u) * p.stride * 4, kN * 4);
+          make_rsrc(reinterpret_cast<const char*>(p.frames) + (size_t)(2 * (size_t)u) * p.stride * 4, kN * 4);
       const __amdgpu_buffer_rsrc_t rb = make_rsrc(
           reinterpret_cast<const char*>(p.frames) + (2 * u + (has_b ? 1 : 0)) * p.stride * 4, has_b ? kN * 4 : 0);
 #pragma unroll
@@ -438,15 +451,25 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     }
   };
 
-  size_t ring_f0 = f;  // frame held by ring slot 0
-  int ring_n = 0;      // slots filled
+  unsigned ring_f0 = f;  // frame held by ring slot 0
+  int ring_n = 0;        // slots filled
 
   for (;;) {
     // successor of frame f in this workgroup's visiting order
-    size_t fnext = f + 1;
-    if ((fnext % kRingFrames) == 0 || fnext >= nfr) {
-      grp += gridDim.x;
-      fnext = grp * kRingFrames;
+    unsigned fnext = f + 1;
+    if ((fnext & gmask) == 0 || fnext >= nfr) {
+      if (dyn) {
+        // normally the slot was written several barriers ago; only a one-frame group (the ragged end of the
+        // batch) gets here in the very frame that should park it
+        if ((f & gmask) == 0) {
+          if (j == 0) *next_slot = fetched;
+          __syncthreads();
+        }
+        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)*next_slot);
+      } else {
+        grp += gridDim.x;
+      }
+      fnext = grp << gsh;
     }
     const bool has_next = grp < ngroups;
     // Opaque re-definitions: stop LICM from hoisting the 16 swizzled store
@@ -494,6 +517,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       // prefetch the next frame a whole frame time ahead (HBM latency under load is
       // microseconds; at 3 waves/SIMD the 16 registers are free)
+      if (run == 0 && dyn && (f & gmask) == 0) {
+        // first frame of a group: every load of this frame has been consumed above, so the atomic issued behind
+        // them has returned too (a one-frame group parked it at the loop top already: same value again)
+        if (j == 0) *next_slot = fetched;
+      }
       if (run == kRuns - 1 && has_next) load_unit(fnext);
       if (MODE == kModeRxReal) pk_dft16_finish(v, K, H);
       else pk_dft16(v, K, H);
@@ -503,7 +531,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // It frees the tile (all pruned-pass reads done) and publishes the ring entry.
       __syncthreads();
       UC_STAMP(7);
-      if (run == 0 && ring_n > 0 && (f % kRingFrames) == 0) {  // a new group starts: drain the last one
+      if (run == 0 && ring_n > 0 && (f & gmask) == 0) {  // a new group starts: drain the last one
         if (wave == 0) finalise(ring_f0, ring_n);
         ring_f0 = f;
         ring_n = 0;
@@ -650,6 +678,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       if (run == kRuns - 1) ring_n++;
     }
     if (!has_next) break;
+    if (dyn && (fnext & gmask) == 0 && j == 0) {
+      // a new group was taken: ask for the one after it.  Issued here, where few registers are live.
+      fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
+    }
     f = fnext;
   }
   __syncthreads();

@@ -28,6 +28,9 @@ struct BandParams {
   uint32_t bw2;           // window length (<= 255)
   uint32_t ifs;           // (uint32_t)(int32_t)fs for idx2freq
   uint32_t true_dc;       // UC_FLAG_TRUE_DC
+  uint32_t group_log2;    // log2 of the frames (PAIR: frame pairs) per group: 1..6 with work_ctr, 0..6 without
+  unsigned int* work_ctr; // device word, zero at launch: groups beyond the first one of each workgroup are handed out
+                          // by atomic increments (the workgroups run at different speeds); nullptr = static round robin
   unsigned long long* debug;  // diagnostic builds only (UC_STAMPS), else nullptr
 };
 
