@@ -45,7 +45,7 @@ for target, key in KEY.items():
         # on dispatches of >= 10 ms, reads high on short ones)
         der["effective_clock_MHz_GRBM"] = g("GRBM_GUI_ACTIVE") / 8.0 / (d["ms_per_dispatch_profiled"] * 1e-3) / 1e6
     if g("SQ_WAVES"):
-        for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD"):
+        for k in ("SQ_INSTS_VALU", "SQ_INSTS_LDS", "SQ_INSTS_SALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_MFMA"):
             if g(k) is not None:
                 der[k + "_per_wave"] = g(k) / g("SQ_WAVES")
     d["derived"] = der

@@ -98,6 +98,11 @@ struct uc_ctx {
   int grid_override = 0;
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
+  unsigned iq_stagger = 0;  // (env UC_IQ_STAGGER, MFMA FIR only) start delay of every second wave on a SIMD, x 4096 clocks
+  // UC_IQ at n = 1024, env UC_IQ_FIR=mfma: the FIR as v_mfma_f32_16x16x4_f32 Toeplitz tiles instead of packed VALU.
+  // Off by default: an f32 MFMA and the partner wave's packed-f32 VALU do not overlap on a SIMD (tools/mfma_valu_probe.hip:
+  // together they take the SUM of their times), and the Toeplitz padding makes the matrix form 1.6x the FMA count.
+  bool iq_fir_mfma = false;
   // work counters for the dynamic group hand-out: one word per launch, a ring so that launches of one context that
   // overlap on different streams never share one (each word sits in its own 128-byte line)
   unsigned int* d_work = nullptr;
@@ -191,6 +196,8 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
   }
   if (const char* g = getenv("UC_STATIC_DEAL")) c->static_deal = atoi(g) != 0;
+  if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
+  if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
   int rc = uc::build_tables(*cfg, c->tab);
   if (rc) {
     delete c;
@@ -301,6 +308,18 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   if (!rc) rc = upload((void**)&c->d_tab0, t0.data(), t0.size() * sizeof(float));
   if (!rc) rc = upload((void**)&c->d_tab1, t1.data(), t1.size() * sizeof(float));
   if (!rc && !t2.empty()) rc = upload((void**)&c->d_tab2, t2.data(), t2.size() * sizeof(float));
+  if (!rc && cfg->variant == UC_IQ) {
+    // the taps as the A operand of v_mfma_f32_16x16x4_f32: lane l = (k = l >> 4, i = l & 15) of k-step s holds
+    // T[i][4 s + k] = fir[i + 26 - (4 s + k)] (0 outside the taps): output i of a 16-output block sees the
+    // samples i .. i + 26 of the block's 42-sample window
+    std::vector<float> fa(11 * 64, 0.0f);
+    for (int s = 0; s < 11; s++)
+      for (int l = 0; l < 64; l++) {
+        const int d = (l & 15) + 26 - (4 * s + (l >> 4));
+        if (d >= 0 && d < uc::kFirTaps) fa[(size_t)s * 64 + l] = T.fir[(size_t)d];
+      }
+    rc = upload((void**)&c->d_aux, fa.data(), fa.size() * sizeof(float));
+  }
   if (rc) {
     uc_destroy(c);
     return rc;
@@ -467,7 +486,10 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
       ip.ifs = (uint32_t)(int32_t)c->cfg.fs;
       ip.snr_threshold = c->cfg.snr_threshold;
     }
-    if (c->iq_blocks_per_cu == 0) c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype, (int)n, bb ? 1 : 0);
+    ip.fir_mfma = (n == 1024 && c->iq_fir_mfma) ? c->d_aux : nullptr;
+    ip.stagger = c->iq_stagger;
+    if (c->iq_blocks_per_cu == 0)
+      c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype, (int)n, bb ? 1 : 0, ip.fir_mfma ? 1 : 0);
     size_t grid = (size_t)c->num_cu * (size_t)c->iq_blocks_per_cu;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     if (grid > n_frames) grid = n_frames;

@@ -421,6 +421,10 @@ constexpr int kN1 = 1024;
 constexpr int T1 = 64;
 constexpr int kMixLen1 = kN1 + kHalo;                     // 1050
 constexpr int kImg1 = T1 * 17 + ((T1 * 17) >> 4) + 4;     // 1160: every m = j + 64 u, u < 17, has a slot
+// MFMA variant of the FIR: the image is padded by TWO slots per 16 samples, so that the B-operand reads of a
+// 16 x 16 x 4 tile (lane (k, column): sample 16 block + 4 s + k of 16 blocks) are conflict-free ds_read_b64
+constexpr int kImg1M = T1 * 17 + 2 * ((T1 * 17) >> 4) + 4;  // 1228
+constexpr int kFirKSteps = 11;                            // 16 outputs need 42 inputs: 11 k-steps of 4
 constexpr int kRing1 = 64;                                // frames per finaliser drain
 constexpr int kRingStride1 = 5;                           // ql, il, qr, ir, flags (odd: conflict-free)
 constexpr int kRingStride1Bb = 11;                        // base band: 2 runs x 5 + 1 pad
@@ -430,12 +434,20 @@ constexpr int kTab1Off = kRingOff1 + kRing1 * kRingStride1Bb;   // base band: th
 constexpr int kLdsFloats1Bb = kTab1Off + 2 * kN1;
 static_assert(kImg1 >= kN1, "the FFT tile aliases the mixed image");
 static_assert((kTab1Off & 1) == 0, "complex alignment");
+constexpr int kImgGrow1 = 2 * (kImg1M - kImg1);           // floats the MFMA variant's image is longer by
 
-template <int DTYPE, bool BB>
+typedef float v4acc __attribute__((ext_vector_type(4)));
+
+// FIRM = 1: the 27-tap FIR on the MATRIX pipe (v_mfma_f32_16x16x4_f32, exact f32: a k-ordered fmaf chain), beside
+// the transform's packed-VALU work of the SIMD's other waves: outputs 16 b + i of 16 blocks b = T^ x S, T the
+// 16 x 44 Toeplitz matrix of the taps (rows i, columns = the 42 samples the 16 outputs see, zero padded to 44),
+// S the mixed samples.  11 k-steps x (I, Q) x 4 tile pairs = 88 MFMAs per frame instead of 432 packed FMAs per lane.
+template <int DTYPE, bool BB, int FIRM>
 __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
-  __shared__ __attribute__((aligned(16))) float lds[BB ? kLdsFloats1Bb : kLdsFloats1];
-  float* ring = lds + kRingOff1;
-  float* tab1l = lds + (BB ? kTab1Off : 0);
+  constexpr int kGrow = FIRM ? kImgGrow1 : 0;
+  __shared__ __attribute__((aligned(16))) float lds[(BB ? kLdsFloats1Bb : kLdsFloats1) + kGrow];
+  float* ring = lds + kRingOff1 + kGrow;
+  float* tab1l = lds + (BB ? kTab1Off + kGrow : 0);
   const int j = threadIdx.x;  // = lane
 
   // frames are dealt in groups of G consecutive frames, round robin over the workgroups
@@ -491,6 +503,16 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   v2f taps[14];
 #pragma unroll
   for (int i = 0; i < 14; i++) taps[i] = mkv(p.fir[2 * i], 2 * i + 1 < kFirTapsDev ? p.fir[2 * i + 1] : 0.f);
+  // MFMA variant: this lane's element of the Toeplitz A operand of every k-step, A[i = j & 15][k = j >> 4] =
+  // fir[i + 26 - (4 s + k)] or 0 (host-built table, 11 x 64 floats); B-operand base (lane = (k, column)):
+  // sample 16 b + 4 s + k of block b = 16 T + column sits at image index 18 b + 4 s + k + 2 (s >> 2)
+  float fa[kFirKSteps];
+  if (FIRM) {
+    const __amdgpu_buffer_rsrc_t rs_fa = make_rsrc(p.fir_mfma, kFirKSteps * 64 * 4);
+#pragma unroll
+    for (int s = 0; s < kFirKSteps; s++) fa[s] = buf_ld32(rs_fa, j * 4, 64 * 4 * s);
+  }
+  const int fb_base = 18 * (j & 15) + (j >> 4);
 
   const int s1 = j & 15;
   const int wr1 = 16 * j;  // natural / exchange-1 layout: + (t ^ s1)
@@ -564,6 +586,17 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   size_t ring_f0 = f;
   int ring_n = 0;
 
+  if (FIRM) {
+    // Experiment knob (p.stagger, default 0): delay the odd wave slots of a SIMD (HW_ID.WAVE_ID) at the start, so that
+    // one wave's FIR (matrix pipe) would run beside its partner's transform (VALU).  Measured: no effect at any
+    // delay -- an f32 MFMA and the partner's packed-f32 VALU do not execute concurrently on a SIMD at all
+    // (profiles/r02_mfma_valu_probe.txt: MFMA wave 4.32 ms + VALU wave 0.88 ms alone, 5.20 ms together).
+    const unsigned slot = __builtin_amdgcn_s_getreg((4) | (0 << 6) | ((4 - 1) << 11)) & 15u;  // HW_REG_HW_ID[3:0]
+    if (slot & 1u) {
+      for (unsigned w = 0; w < p.stagger; w++) __builtin_amdgcn_s_sleep(64);
+    }
+  }
+
   for (;;) {
     size_t fnext = f + 1;
     if ((fnext % G) == 0 || fnext >= nfr) {
@@ -578,16 +611,43 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
 #pragma unroll
     for (int u = 0; u < 17; u++) {
       const float x = cvt1<DTYPE>(xn[u]);
-      lds_st(lds, mix_idx(j + T1 * u), mkv(x * cs[u].x, x * cs[u].y));
+      const int m = j + T1 * u;
+      lds_st(lds, FIRM ? m + ((m >> 4) << 1) : mix_idx(m), mkv(x * cs[u].x, x * cs[u].y));
     }
     if (has_next) load_frame(fnext);
     __syncthreads();  // single wave: no s_barrier is emitted, only the LDS wait
 
-    // ---- stage 1: FIR (iq_modem.c:64-65), 16 consecutive outputs per thread --------------------
-    // output o = 16 j + u needs mixed[o + 26 - k], k = 0..26: window w[d] = mixed[16 j + d], d < 42.
-    // Two halves of eight outputs; within a half the eight accumulators advance tap by tap.
-    v2f accA[8], accB[8];
-    {
+    // ---- stage 1: FIR (iq_modem.c:64-65) ---------------------------------------------------------
+    v2f accA[8], accB[8];   // the lane's 16 filtered (I, Q) points, in the order the exchange-1 stores below want them
+    if (FIRM) {
+      // matrix pipe: tile pair T = blocks 16 T .. 16 T + 15; lane (k = j >> 4, column = j & 15) feeds sample
+      // 16 b + 4 s + k of its column's block as the B operand and receives outputs 16 b + 4 (j >> 4) + r, r < 4
+      v4acc dI[4], dQ[4];
+#pragma unroll
+      for (int T = 0; T < 4; T++) {
+        v2f smp[kFirKSteps];
+#pragma unroll
+        for (int sk = 0; sk < kFirKSteps; sk++) smp[sk] = lds_ld(lds, fb_base + 288 * T + 4 * sk + 2 * (sk >> 2));
+        v4acc aI = {0.f, 0.f, 0.f, 0.f}, aQ = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sk = 0; sk < kFirKSteps; sk++) {
+          aI = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sk], smp[sk].x, aI, 0, 0, 0);
+          aQ = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[sk], smp[sk].y, aQ, 0, 0, 0);
+        }
+        dI[T] = aI;
+        dQ[T] = aQ;
+      }
+#pragma unroll
+      for (int T = 0; T < 4; T++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const v2f pt = mkv(dI[T][r], dQ[T][r]);
+          if (T < 2) accA[4 * T + r] = pt; else accB[4 * (T - 2) + r] = pt;
+        }
+      }
+    } else {
+      // output o = 16 j + u needs mixed[o + 26 - k], k = 0..26: window w[d] = mixed[16 j + d], d < 42.
+      // Two halves of eight outputs; within a half the eight accumulators advance tap by tap.
       v2f w[42];
 #pragma unroll
       for (int d = 0; d < 34; d++) w[d] = lds_ld(lds, 17 * j + d + (d >> 4));
@@ -616,8 +676,17 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
     constexpr int kRuns = BB ? 2 : 1;
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
+    if (FIRM) {
+      // point u = 4 T + r of this lane is output o = 16 b + 4 (j >> 4) + r of block b = 16 T + (j & 15); the
+      // exchange-1 layout puts o at (o & ~15) + ((o & 15) ^ (b & 15))
+      const int ob = 16 * (j & 15), oq = 4 * (j >> 4), oc = s1v;
 #pragma unroll
-    for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
+      for (int u = 0; u < 16; u++)
+        lds_st(lds, 256 * (u >> 2) + ob + ((oq + (u & 3)) ^ oc), u < 8 ? accA[u & 7] : accB[u & 7]);
+    } else {
+#pragma unroll
+      for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
+    }
     __syncthreads();
 
     // ---- pass 1: x chirp*hann, radix-16 (Ns = 1) -------------------------------------------
@@ -735,9 +804,12 @@ int occ(F kernel, int threads, int fallback) {
 #define UC_IQ_DISPATCH(CALL1024, CALL2048)                                  \
   do {                                                                      \
     const bool i32 = dtype == UC_DTYPE_I32;                                 \
-    if (n == kN1) {                                                         \
-      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, true); } else { CALL1024(UC_DTYPE_F32, true); } }     \
-      else    { if (i32) { CALL1024(UC_DTYPE_I32, false); } else { CALL1024(UC_DTYPE_F32, false); } }   \
+    if (n == kN1 && mfma) {                                                 \
+      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, true, 1); } else { CALL1024(UC_DTYPE_F32, true, 1); } }     \
+      else    { if (i32) { CALL1024(UC_DTYPE_I32, false, 1); } else { CALL1024(UC_DTYPE_F32, false, 1); } }   \
+    } else if (n == kN1) {                                                  \
+      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, true, 0); } else { CALL1024(UC_DTYPE_F32, true, 0); } }     \
+      else    { if (i32) { CALL1024(UC_DTYPE_I32, false, 0); } else { CALL1024(UC_DTYPE_F32, false, 0); } }   \
     } else {                                                                \
       if (bb) { if (i32) { CALL2048(UC_DTYPE_I32, true); } else { CALL2048(UC_DTYPE_F32, true); } }     \
       else    { if (i32) { CALL2048(UC_DTYPE_I32, false); } else { CALL2048(UC_DTYPE_F32, false); } }   \
@@ -746,8 +818,8 @@ int occ(F kernel, int threads, int fallback) {
 
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n) {
   if (grid <= 0) return (int)hipSuccess;
-  const bool bb = p.baseband != 0;
-#define UC_L1024(D, B) hipLaunchKernelGGL((iq1024_kernel<D, B>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p)
+  const bool bb = p.baseband != 0, mfma = p.fir_mfma != nullptr;
+#define UC_L1024(D, B, M) hipLaunchKernelGGL((iq1024_kernel<D, B, M>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p)
 #define UC_L2048(D, B) hipLaunchKernelGGL((iq_kernel<D, B>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p)
   UC_IQ_DISPATCH(UC_L1024, UC_L2048);
 #undef UC_L1024
@@ -755,10 +827,10 @@ int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n)
   return (int)hipGetLastError();
 }
 
-int iq_max_blocks_per_cu(int dtype, int n, int baseband) {
-  const bool bb = baseband != 0;
+int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma) {
+  const bool bb = baseband != 0, mfma = fir_mfma != 0;
   int nb = 0;
-#define UC_O1024(D, B) nb = occ(iq1024_kernel<D, B>, T1, 8)
+#define UC_O1024(D, B, M) nb = occ(iq1024_kernel<D, B, M>, T1, 8)
 #define UC_O2048(D, B) nb = occ(iq_kernel<D, B>, T, 4)
   UC_IQ_DISPATCH(UC_O1024, UC_O2048);
 #undef UC_O1024

@@ -73,6 +73,9 @@ struct IqParams {
   uint8_t* symbols;
   uc_stats* stats;            // 1 per frame
   float fir[kFirTapsDev];
+  const float* fir_mfma;      // n = 1024: the taps as the Toeplitz A operand of v_mfma_f32_16x16x4_f32, [11 k-steps][64 lanes];
+                              // nullptr = the packed-VALU FIR
+  uint32_t stagger;           // MFMA FIR: start delay of the odd wave slots, in units of s_sleep 64 (4096 clocks)
   float mag_mean_scalar;
   float fs;
   uint32_t idx_left_zero, center, bw2, bw4;
@@ -85,7 +88,7 @@ struct IqParams {
 };
 // n = 2048 (the committed firmware) or 1024 (one wave per frame)
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
-int iq_max_blocks_per_cu(int dtype, int n, int baseband);
+int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma);
 
 // UC_STREAM: FIR-LPF decimating front-end + overlap-save chirp compression (include/uchirp.h).
 struct StreamParams {
