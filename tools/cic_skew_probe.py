@@ -1,0 +1,35 @@
+#!/usr/bin/env python3
+"""Wave start/end skew of sinc5_kernel (diagnostic build libuchirp_clock.so).  Usage: python tools/cic_skew_probe.py [words_log2=28]"""
+import json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+os.environ["UCHIRP_LIB"] = os.path.join(ROOT, "ultrasonic-communication_amd", "libuchirp_clock.so")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
+import numpy as np, torch, uchirp
+lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
+n = (1 << lg) + 4
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(1)
+w = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+out = torch.empty(n - 4, dtype=torch.int32, device=dev)
+e = uchirp.Engine(uchirp.RX_REAL)
+dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
+os.environ["UC_DEBUG_PTR"] = str(dbg.data_ptr())
+for _ in range(200):
+    e.dfsdm(w, out=out)
+torch.cuda.synchronize()
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+a.record(); e.dfsdm(w, out=out); b.record(); torch.cuda.synchronize()
+raw = dbg.cpu().numpy().reshape(-1, 4)
+nw = int((raw[:, 1] > 0).sum())
+blk = np.arange(nw) // 16
+life_all = raw[:nw, 1] / 100.0
+print("median life by block % 8 (XCD under round-robin placement):", [round(float(np.median(life_all[blk % 8 == k])), 1) for k in range(8)])
+print("spread of the 16 waves inside a block (max - min life), median over blocks: %.1f us" % float(np.median([np.ptp(life_all[blk == b]) for b in range(nw // 16)])))
+print("block medians p0/10/50/90/100:", [round(float(np.percentile([np.median(life_all[blk == b]) for b in range(nw // 16)], q)), 1) for q in (0, 10, 50, 90, 100)])
+d = raw; d = d[d[:, 1] > 0].astype(np.float64)
+t0 = d[:, 2].min()
+pct = lambda v: [round(float(np.percentile(v, q)), 2) for q in (0, 10, 50, 90, 100)]
+print(json.dumps({"kernel": "sinc5_kernel", "words": n, "ms_events": a.elapsed_time(b), "waves": int(d.shape[0]),
+                  "clock_MHz_median": float(np.median(d[:, 0] / d[:, 1] * 100.0)),
+                  "wave_start_us": pct((d[:, 2] - t0) / 100.0), "wave_end_us": pct((d[:, 3] - t0) / 100.0),
+                  "wave_life_us": pct(d[:, 1] / 100.0)}))

@@ -39,9 +39,38 @@ __global__ __launch_bounds__(kThreads) void copy_kernel(const v4u* __restrict__ 
   }
 }
 
+// the same copy with a given number of 16-byte loads in flight per lane and threads per block (what a kernel with
+// that footprint can expect: e.g. sinc5_kernel = one 1024-thread block per CU, 2 loads in flight per lane)
+template <int UNROLL, int THREADS>
+__global__ __launch_bounds__(THREADS) void copy_kernel_t(const v4u* __restrict__ src, v4u* __restrict__ dst, size_t n16) {
+  const size_t tile = (size_t)THREADS * UNROLL;
+  for (size_t base = (size_t)blockIdx.x * tile; base + tile <= n16; base += (size_t)gridDim.x * tile) {
+    v4u v[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) v[u] = ld_nt(src + base + (size_t)u * THREADS + threadIdx.x);
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) __builtin_nontemporal_store(v[u], dst + base + (size_t)u * THREADS + threadIdx.x);
+  }
+}
+
 }  // namespace
 
 extern "C" {
+
+// shape: 0 = 1024 threads x 2 in flight, 1 = 1024 x 4, 2 = 1024 x 8, 3 = 256 x 2
+int hbm_probe_copy_shape(const void* src, void* dst, size_t bytes, int blocks, int shape, void* stream) {
+  const v4u* s = (const v4u*)src;
+  v4u* d = (v4u*)dst;
+  hipStream_t st = (hipStream_t)stream;
+  switch (shape) {
+    case 0: hipLaunchKernelGGL((copy_kernel_t<2, 1024>), dim3((unsigned)blocks), dim3(1024), 0, st, s, d, bytes / 16); break;
+    case 1: hipLaunchKernelGGL((copy_kernel_t<4, 1024>), dim3((unsigned)blocks), dim3(1024), 0, st, s, d, bytes / 16); break;
+    case 2: hipLaunchKernelGGL((copy_kernel_t<8, 1024>), dim3((unsigned)blocks), dim3(1024), 0, st, s, d, bytes / 16); break;
+    default: hipLaunchKernelGGL((copy_kernel_t<2, 256>), dim3((unsigned)blocks), dim3(256), 0, st, s, d, bytes / 16); break;
+  }
+  return (int)hipGetLastError();
+}
+
 
 // bytes: a multiple of 32 KiB is read in full (a tail shorter than one tile is skipped); returns hipError_t
 int hbm_probe_read(const void* src, size_t bytes, void* sink, int blocks, void* stream) {

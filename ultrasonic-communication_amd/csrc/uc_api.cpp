@@ -105,6 +105,8 @@ struct uc_ctx {
   bool iq_fir_mfma = false;
   // work counters for the dynamic group hand-out: one word per launch, a ring so that launches of one context that
   // overlap on different streams never share one (each word sits in its own 128-byte line)
+  unsigned int* d_cic_ctr = nullptr;  // sinc5: tile tickets, one word per workgroup x 4 launches
+  size_t cic_ctr_cap = 0;
   unsigned int* d_work = nullptr;
   unsigned work_next = 0;
 };
@@ -336,6 +338,7 @@ void uc_destroy(uc_ctx* c) {
   if (c->d_tab2) (void)hipFree(c->d_tab2);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_work) (void)hipFree(c->d_work);
+  if (c->d_cic_ctr) (void)hipFree(c->d_cic_ctr);
   if (c->d_aux) (void)hipFree(c->d_aux);
   if (c->d_cic4) (void)hipFree(c->d_cic4);
   if (c->d_cic1) (void)hipFree(c->d_cic1);
@@ -631,6 +634,11 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   cp.out = d_out;
   cp.t4 = c->d_cic4;
   cp.t1 = c->d_cic1;
+  cp.ctr = nullptr;
+  cp.debug = nullptr;
+#if defined(UC_CLOCKSTAMP)
+  if (const char* d = getenv("UC_DEBUG_PTR")) cp.debug = (unsigned long long*)strtoull(d, nullptr, 0);
+#endif
   if (c->cic_blocks_per_cu == 0) {
     c->cic_blocks_per_cu = uc::sinc5_max_blocks_per_cu();
     if (c->cic_blocks_per_cu <= 0) {
@@ -642,6 +650,21 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   const size_t need = (n_out + uc::sinc5_tile_outputs() - 1) / uc::sinc5_tile_outputs();
   if (grid > need) grid = need;
+  if (!c->static_deal) {
+    // ticket counters of this launch (one per workgroup), zeroed on the stream right before it
+    const size_t bytes = grid * sizeof(unsigned int);
+    if (bytes > c->cic_ctr_cap) {
+      if (c->d_cic_ctr) (void)hipFree(c->d_cic_ctr);
+      c->d_cic_ctr = nullptr;
+      c->cic_ctr_cap = 0;
+      e = hipMalloc((void**)&c->d_cic_ctr, 4 * bytes);   // a ring of four launches (overlapping streams)
+      if (e != hipSuccess) return hip_fail(e, "hipMalloc(sinc5 tickets)");
+      c->cic_ctr_cap = bytes;
+    }
+    cp.ctr = c->d_cic_ctr + (size_t)(c->work_next++ % 4) * grid;
+    e = hipMemsetAsync(cp.ctr, 0, bytes, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(sinc5 tickets)");
+  }
   int lrc = uc::launch_sinc5(cp, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "sinc5 kernel launch");
   if (host_out) {

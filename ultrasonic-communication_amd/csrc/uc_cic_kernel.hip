@@ -23,23 +23,22 @@ namespace {
 #ifndef UC_CIC_THREADS
 #define UC_CIC_THREADS 1024
 #endif
-#ifndef UC_CIC_R4
-#define UC_CIC_R4 8
-#endif
-#ifndef UC_CIC_R1
-#define UC_CIC_R1 4
-#endif
 constexpr int TC = UC_CIC_THREADS;  // one workgroup per CU shares one set of tables
 constexpr int kTileWords = 256;     // words one wave loads
 constexpr int kTileOut = 252;       // outputs one wave stores
-// The lookups are indexed by DATA bytes: lanes of one LDS access group that need different entries on
-// the same banks are serialised (16 random bytes on 16 bank quads: ~3 per quad).  Replicating the
-// tables -- entry e of replica r at e * R + r, a lane reads replica lane % R -- spreads a group over
-// R times as many bank positions per entry: 2 lanes of a 16-lane group share a replica of the 16-byte
-// table (R4 = 8, 128 KiB), 8 lanes of a 32-lane group a replica of the 4-byte table (R1 = 4, 16 KiB):
-// measured best split of the 160 KiB (4/8: 43.7 %, 8/8: 45.0 %, 8/4: 46.9 % of 8 TB/s).
-constexpr int R4 = UC_CIC_R4;
-constexpr int R1 = UC_CIC_R1;
+// The lookups are indexed by DATA bytes, so with a plain table the bank a lane hits is random (58 % of the LDS
+// cycles were bank conflicts, r01).  Here the bank is a function of the LANE alone:
+//   * every entry is replicated 8 times, a lane reads replica r = lane & 7;
+//   * the lanes that share a replica inside one LDS access group never look at the same BYTE POSITION in the same
+//     instruction: in step i a lane handles byte b = (i + (lane >> 3)) & 3 of its words.  A ds_read_b128 is served
+//     in groups of 16 lanes in which lanes l and l ^ 24 share r (MI355X_MICROARCH.md, LDS): their b differ in bit 0;
+//     a ds_read_b32 in groups of 32 lanes in which l, l + 8, l + 16, l + 24 share r: their b are all different;
+//   * the tables are laid out so that (b, r) picks the bank and the byte value only the ROW:
+//       16-byte table: entry (b, v), replica r at 16-byte slot  ((b >> 1) * 256 + v) * 16 + 8 * (b & 1) + r
+//        4-byte table: entry (b, v), replica r at dword          v * 32 + 8 * b + r
+// 128 KiB + 32 KiB = all 160 KiB of the CU's LDS, one 1024-thread workgroup per CU.
+constexpr int R4 = 8;
+constexpr int R1 = 8;
 constexpr size_t kCicLdsBytes = 1024 * (size_t)R4 * 16 + 1024 * (size_t)R1 * 4;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
@@ -50,17 +49,38 @@ __device__ __forceinline__ int from_prev_lane(int v) {
 }
 
 __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
+#ifdef UC_CLOCKSTAMP
+  const unsigned long long clk0_ = __builtin_readcyclecounter();
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char cic_lds[];
-  v4i* t4 = reinterpret_cast<v4i*>(cic_lds);              // [byte position b][value v][replica] -> outputs m .. m+3 of word m
-  int* t1 = reinterpret_cast<int*>(cic_lds + 1024 * R4 * 16);  //                                 -> output m+4
-  for (int i = threadIdx.x; i < 1024 * R4; i += TC) t4[i] = reinterpret_cast<const v4i*>(p.t4)[i / R4];
-  for (int i = threadIdx.x; i < 1024 * R1; i += TC) t1[i] = p.t1[i / R1];
+  v4i* t4 = reinterpret_cast<v4i*>(cic_lds);                   // (b, v, r) -> outputs m .. m+3 of word m
+  int* t1 = reinterpret_cast<int*>(cic_lds + 1024 * R4 * 16);  // (b, v, r) -> output m+4
+  for (int i = threadIdx.x; i < 1024 * R4; i += TC) {
+    const int e = i >> 3, r = i & 7, b = e >> 8, v = e & 255;
+    t4[((b >> 1) * 256 + v) * 16 + 8 * (b & 1) + r] = reinterpret_cast<const v4i*>(p.t4)[e];
+    t1[v * 32 + 8 * b + r] = p.t1[e];
+  }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
+  // step i of a word: byte b = (i + (lane >> 3)) & 3; byte offsets of the two lookups besides the value's row
+  int sh[4], oa[4], ob[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int b = (i + (lane >> 3)) & 3;
+    sh[i] = 8 * b;
+    oa[i] = ((b >> 1) * 256 * 16 + 8 * (b & 1) + (lane & 7)) * 16;
+    ob[i] = (8 * b + (lane & 7)) * 4;
+  }
+  const unsigned char* t4b = cic_lds;
+  const unsigned char* t1b = cic_lds + 1024 * R4 * 16;
   const size_t n_out = p.n_words - 4;
   const size_t tiles = (n_out + kTileOut - 1) / kTileOut;
-  const size_t wave0 = (size_t)blockIdx.x * (TC / 64) + (threadIdx.x >> 6);
+  // (readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane; without it the tile
+  // index, the buffer resources and all the 64-bit address arithmetic live in VGPRs and every buffer access is
+  // wrapped in a waterfall loop)
+  const size_t wave0 = (size_t)blockIdx.x * (TC / 64) + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const size_t nwaves = (size_t)gridDim.x * (TC / 64);
 
   // words base + 4 lane .. + 3 of a tile; past the end of the buffer the resource returns 0 (those outputs
@@ -72,27 +92,23 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.pdm + (tile < tiles ? base : 0), recs * 4);
     return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, UC_STREAM_CPOL);
   };
-  // A wave has 1 KiB of input in flight per outstanding load; 16 waves per CU with one load each cannot
-  // cover the HBM latency at this rate, so the loads run TWO tiles ahead of the arithmetic.
-  v4u w1 = load_tile(wave0), w2 = load_tile(wave0 + nwaves);
-  for (size_t tile = wave0; tile < tiles; tile += nwaves) {
+  // One tile of a wave: 256 words in, 252 outputs out.
+  auto process = [&](const v4u w, size_t tile) {
     const size_t base = tile * kTileOut;
-    const v4u w = w1;
-    w1 = w2;
-    w2 = load_tile(tile + 2 * nwaves);
     const unsigned wd[4] = {w.x, w.y, w.z, w.w};
     int g[4][5];
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 #pragma unroll
-      for (int b = 0; b < 4; b++) {
-        const int idx = b * 256 + (int)((wd[c] >> (8 * b)) & 255u);
-        const v4i q = t4[idx * R4 + (lane & (R4 - 1))];
+      for (int i = 0; i < 4; i++) {
+        const unsigned v = __builtin_amdgcn_ubfe(wd[c], (unsigned)sh[i], 8u);
+        const v4i q = *reinterpret_cast<const v4i*>(t4b + (v << 8) + oa[i]);
         a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
-        a4 += t1[idx * R1 + (lane & (R1 - 1))];
+        a4 += *reinterpret_cast<const int*>(t1b + (v << 7) + ob[i]);
       }
       g[c][0] = a0; g[c][1] = a1; g[c][2] = a2; g[c][3] = a3; g[c][4] = a4;
+      if (c & 1) __builtin_amdgcn_sched_barrier(0);  // two words' lookups (16 reads, 40 result registers) at a time
     }
     // sums over this lane's own words, and what its words add to the next lane's four outputs
     int y0 = g[0][0];
@@ -114,20 +130,82 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
       v = v < -8388608 ? -8388608 : v;
       return v * 256;
     };
-    if (lane > 0) {
-      // outputs base + 4 (lane - 1) .. + 3
-      const size_t o = base + 4 * (size_t)(lane - 1);
-      if (o + 3 < n_out) {
-        v4i r;
-        r.x = word(y0); r.y = word(y1); r.z = word(y2); r.w = word(y3);
-        __builtin_nontemporal_store(r, reinterpret_cast<v4i*>(p.out + o));  // written once, never read here
+    // outputs base + 4 (lane - 1) .. + 3 through a buffer resource over this tile's outputs: lane 0 (its outputs
+    // belong to the previous tile), lanes past the end of the stream and tiles past the last one fall outside the
+    // resource and are dropped by the range check -- no branch, no 64-bit address registers
+    const size_t left = tile < tiles ? n_out - base : 0;
+    const int recs = left < (size_t)kTileOut ? (int)left : kTileOut;
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + (tile < tiles ? base : 0), recs * 4);
+    v4u r;
+    r.x = (unsigned)word(y0); r.y = (unsigned)word(y1); r.z = (unsigned)word(y2); r.w = (unsigned)word(y3);
+    __builtin_amdgcn_raw_buffer_store_b128(r, rout, (lane - 1) * 16, 0, UC_STREAM_CPOL);  // written once, never read here
+  };
+  // Workgroup b owns the tiles b, b + B, b + 2 B, ... (B workgroups); its 16 waves do NOT run at the same speed (the
+  // SIMD arbitration favours the older wave: with equal static shares the slowest wave of a workgroup ran 1.5 x as
+  // long as the fastest, profiles/r02_sinc5_skew_static.json), so they draw tickets k = 0, 1, 2, ... from the
+  // workgroup's counter in global memory (p.ctr[b], zero at launch; LDS is full): ticket k = tile b + k B.
+  // The loads run two tiles ahead, the ticket for the next load one iteration ahead of its use; the returning
+  // atomic is always OLDER than the loads still in flight, so reading it never drains the load pipeline.
+  const size_t nblocks = gridDim.x;
+  const unsigned my_tiles = (unsigned)((tiles - blockIdx.x + nblocks - 1) / nblocks);  // tickets of this workgroup
+  auto tile_of = [&](unsigned k) { return k < my_tiles ? (size_t)blockIdx.x + (size_t)k * nblocks : tiles; };
+  unsigned* ctr = p.ctr ? p.ctr + blockIdx.x : nullptr;
+  const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  // one ticket = kTicket consecutive tiles of the workgroup (an atomic takes several microseconds to return while
+  // the chip streams: with a ticket per tile every iteration waited for its atomic, 1.3 ms instead of 0.49 ms)
+  constexpr unsigned kTicket = 4;
+  auto ticket = [&]() -> unsigned {  // returns in lane 0 of a VGPR; made scalar when it is used
+    return (lane == 0) ? atomicAdd(ctr, 1u) + (unsigned)(TC / 64) : 0u;
+  };
+  if (ctr) {
+    unsigned kl = kTicket * wv;     // tile (ticket-local numbering) of the next LOAD; every wave's first ticket is fixed
+    unsigned kn_v = ticket();       // the ticket after it, in flight (issued before the loads: see below)
+    auto next_k = [&]() {           // advance kl; at a ticket boundary take the ticket in flight and ask for another
+      if (((kl + 1) & (kTicket - 1)) != 0) {
+        kl++;
       } else {
-        if (o < n_out) p.out[o] = word(y0);
-        if (o + 1 < n_out) p.out[o + 1] = word(y1);
-        if (o + 2 < n_out) p.out[o + 2] = word(y2);
-      }
+        kl = kTicket * (unsigned)__builtin_amdgcn_readfirstlane((int)kn_v);
+        kn_v = ticket();            // BEFORE the next load: vector-memory operations return in order, so reading
+      }                             // this ticket later must not have to wait for loads issued after it
+    };
+    unsigned k0 = kl;
+    v4u q0 = load_tile(tile_of(kl));
+    next_k();
+    unsigned k1 = kl;
+    v4u q1 = load_tile(tile_of(kl));
+    for (;;) {
+      if (k0 >= my_tiles) break;
+      const v4u w = q0;
+      q0 = q1;
+      next_k();
+      const unsigned kn = kl;
+      q1 = load_tile(tile_of(kn));
+      process(w, tile_of(k0));
+      __builtin_amdgcn_sched_barrier(0);
+      k0 = k1;
+      k1 = kn;
+    }
+  } else {
+    // static deal (no counter): tiles wave, wave + W, ... of all W waves of the grid, loads two tiles ahead
+    v4u q0 = load_tile(wave0), q1 = load_tile(wave0 + nwaves);
+    for (size_t tile = wave0; tile < tiles; tile += nwaves) {
+      const v4u w = q0;
+      q0 = q1;
+      q1 = load_tile(tile + 2 * nwaves);
+      process(w, tile);
+      __builtin_amdgcn_sched_barrier(0);
     }
   }
+#ifdef UC_CLOCKSTAMP
+  if (lane == 0 && p.debug) {
+    const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* d_ = p.debug + ((size_t)blockIdx.x * (TC / 64) + (threadIdx.x >> 6)) * 4;
+    d_[0] = __builtin_readcyclecounter() - clk0_;
+    d_[1] = rt1_ - rt0_;
+    d_[2] = rt0_;
+    d_[3] = rt1_;
+  }
+#endif
 }
 
 }  // namespace

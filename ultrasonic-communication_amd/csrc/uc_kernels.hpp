@@ -114,6 +114,8 @@ struct CicParams {
   int32_t* out;          // device, 16-byte aligned, n_words - 4 words: 24-bit result in bits 31:8
   const int32_t* t4;     // [4][256][4] per-byte contributions to outputs m .. m+3 of word m
   const int32_t* t1;     // [4][256]    per-byte contribution to output m+4
+  unsigned int* ctr;     // one word per workgroup, zero at launch: the tile tickets its waves draw; nullptr = static deal
+  unsigned long long* debug;  // diagnostic builds only (UC_CLOCKSTAMP), else nullptr
 };
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
 int sinc5_max_blocks_per_cu();
