@@ -98,6 +98,7 @@ struct uc_ctx {
   int grid_override = 0;
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
+  bool cic_tickets = false;
   unsigned iq_stagger = 0;  // (env UC_IQ_STAGGER, MFMA FIR only) start delay of every second wave on a SIMD, x 4096 clocks
   // UC_IQ at n = 1024, env UC_IQ_FIR=mfma: the FIR as v_mfma_f32_16x16x4_f32 Toeplitz tiles instead of packed VALU.
   // Off by default: an f32 MFMA and the partner wave's packed-f32 VALU do not overlap on a SIMD (tools/mfma_valu_probe.hip:
@@ -198,6 +199,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
   }
   if (const char* g = getenv("UC_STATIC_DEAL")) c->static_deal = atoi(g) != 0;
+  if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
   if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
   if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
   int rc = uc::build_tables(*cfg, c->tab);
@@ -650,7 +652,8 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   const size_t need = (n_out + uc::sinc5_tile_outputs() - 1) / uc::sinc5_tile_outputs();
   if (grid > need) grid = need;
-  if (!c->static_deal) {
+  if (c->cic_tickets) {
+    // (opt-in, env UC_CIC_TICKETS=1: measured no faster than the static deal, profiles/r02_sinc5_notes.txt)
     // ticket counters of this launch (one per workgroup), zeroed on the stream right before it
     const size_t bytes = grid * sizeof(unsigned int);
     if (bytes > c->cic_ctr_cap) {
