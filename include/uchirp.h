@@ -50,7 +50,7 @@
 extern "C" {
 #endif
 
-#define UC_ABI_VERSION 2
+#define UC_ABI_VERSION 3
 
 /* pipeline variants */
 enum {
@@ -216,6 +216,14 @@ typedef struct uc_rx_event {      /* one per processed block */
 int uc_receive_stream(uc_ctx* ctx, const void* samples, int dtype, size_t n_samples,
                       char* text, size_t text_cap,
                       uc_rx_event* trace /*nullable*/, size_t trace_cap, size_t* n_trace /*nullable*/);
+
+/* The same with the ISR's drop-on-busy (receiver/Src/main.c:661: `if (!new_pcm_data && ...)`): busy[b] != 0 says the
+ * main loop had not yet consumed the previous block when block b arrived, so the ISR drops block b (the FIFO is not
+ * shifted, the block is lost, no pass of the switch runs for it).  busy: n_samples / n bytes, host; NULL = never busy
+ * (= uc_receive_stream).  Trace records carry the index of the ACCEPTED block they belong to. */
+int uc_receive_stream_isr(uc_ctx* ctx, const void* samples, int dtype, size_t n_samples,
+                          const uint8_t* busy /*nullable*/, char* text, size_t text_cap,
+                          uc_rx_event* trace /*nullable*/, size_t trace_cap, size_t* n_trace /*nullable*/);
 
 /*
  * UC_STREAM -- BASELINE config 4: streaming FIR-LPF decimate front-end + overlap-save

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "uchirp.h"
+#include "uchirp_mainloop.hpp"
 
 namespace uchirp {
 
@@ -40,6 +41,7 @@ struct history {  // receiver/Src/main.c:124-136
 
 class Receiver {
  public:
+  typedef history history_t;          // (uchirp_mainloop.hpp: what MainLoop<Receiver> keeps per slot)
   float fifo_queue[NN * 3] = {0.0f};  // main.c:94
   bool new_pcm_data = false;          // main.c:84
   uint32_t bandwidth = 0, bandwidth2 = 0, idx_left_zero = 0;  // main.c:138-140
@@ -50,6 +52,11 @@ class Receiver {
     cfg.fs = fs;
     cfg.device = device;
     check(uc_create(&cfg, &ctx_), "uc_create");
+    if (uc_stats_per_frame(ctx_) != 2) {  // dsp() reads the up AND the down history of a frame
+      uc_destroy(ctx_);
+      ctx_ = nullptr;
+      throw std::invalid_argument("Receiver: the variant has no up/down history pair (UC_RX_REAL or UC_SYNC_CPLX)");
+    }
     uc_get_windows(ctx_, &bandwidth, &bandwidth2, &idx_left_zero);
   }
   ~Receiver() { uc_destroy(ctx_); }
@@ -86,22 +93,11 @@ class Receiver {
   }
 
   float symbol_snr(uint32_t sync_position, history* phist, int updown) {
-    dsp(sync_position, phist, phist->mag_mean, updown);
-    return phist->snr;
+    return uchirp::symbol_snr(*this, sync_position, phist, updown);
   }
 
   void resync(float snr, history hist[], uint32_t offset, uint32_t* sync_position, int updown) {
-    const int32_t sync_position_l = (int32_t)*sync_position - (int32_t)offset;
-    const int32_t sync_position_r = (int32_t)*sync_position + (int32_t)offset;
-    float snr_l = -1e38f, snr_r = -1e38f;
-    if (sync_position_l >= 0) snr_l = symbol_snr((uint32_t)sync_position_l, &hist[2], updown);
-    if (sync_position_r <= (int32_t)(2 * NN)) snr_r = symbol_snr((uint32_t)sync_position_r, &hist[3], updown);
-    if ((snr > snr_l) && (snr > snr_r)) return;
-    if (snr_l >= snr_r) {
-      if (sync_position_l >= 0) *sync_position = (uint32_t)sync_position_l;
-    } else if (snr_l < snr_r) {
-      if (sync_position_r <= (int32_t)(2 * NN)) *sync_position = (uint32_t)sync_position_r;
-    }
+    uchirp::resync(*this, NN, snr, hist, offset, sync_position, updown);
   }
 
   uc_ctx* ctx() { return ctx_; }

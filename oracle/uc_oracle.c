@@ -1236,6 +1236,13 @@ static void rx_resync(rx_env* e, float snr, hist_lite* hist, uint32_t offset, ui
 
 int uco_receive_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samples, int precision,
                        char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
+  return uco_receive_stream_isr(c, samples, dtype, n_samples, NULL, precision, text, text_cap, trace, trace_cap, n_trace);
+}
+
+/* busy[b] != 0: the main loop had not cleared `new_pcm_data` when block b arrived, so the ISR's
+ * `if (!new_pcm_data && ...)` (receiver/Src/main.c:661) skips the block: no FIFO shift, no pass of the switch. */
+int uco_receive_stream_isr(uco_ctx* c, const void* samples, int dtype, size_t n_samples, const uint8_t* busy, int precision,
+                           char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
   if (!c || (!samples && n_samples) || !text || text_cap == 0) return -EINVAL;
   if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX) return -ENOTSUP;
   const uint32_t n = c->n;
@@ -1266,6 +1273,8 @@ int uco_receive_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samp
   const size_t n_blocks = n_samples / n;
   for (size_t b = 0; b < n_blocks; b++) {
     /* ISR: main.c:659-668 */
+    int new_pcm_data = (busy && busy[b]) ? 1 : 0; /* still set by the previous block: the consumer is late */
+    if (new_pcm_data) continue;                   /* main.c:661: the block is dropped */
     memmove(e.fifo, e.fifo + n, sizeof(float) * 2 * n);
     for (uint32_t i = 0; i < n; i++) e.fifo[2 * n + i] = load_sample(samples, dtype, b * (size_t)n + i);
 

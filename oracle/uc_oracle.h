@@ -67,6 +67,9 @@ int32_t uco_idx2freq(const uco_ctx* ctx, uint32_t idx);
  * Same outputs as uc_receive_stream (include/uchirp.h). */
 int uco_receive_stream(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples, int precision,
                        char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace);
+/* ... with the ISR's drop-on-busy (main.c:661): same outputs as uc_receive_stream_isr */
+int uco_receive_stream_isr(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples, const uint8_t* busy, int precision,
+                           char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace);
 
 /* UC_STREAM (BASELINE config 4): same outputs as uc_stream_geometry / uc_process_stream,
  * evaluated as the direct float64 time-domain sums of the definition in include/uchirp.h

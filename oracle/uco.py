@@ -64,6 +64,8 @@ def lib():
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int]
         L.uco_receive_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t,
                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.uco_receive_stream_isr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_char_p,
+                                             C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.uco_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
         L.uco_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.uco_dfsdm_sinc5.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
@@ -168,8 +170,9 @@ class Oracle:
             raise RuntimeError("uco_process_batch rc=%d" % rc)
         return sym, stats
 
-    def receive(self, samples, precision=F64):
-        """The receiver's main loop over a recorded stream -> (text, trace[RX_EVENT_DTYPE])."""
+    def receive(self, samples, precision=F64, busy=None):
+        """The receiver's main loop over a recorded stream -> (text, trace[RX_EVENT_DTYPE]).
+        busy: optional per-block flags: the ISR drops those blocks (main.c:661)."""
         a = np.ascontiguousarray(samples).reshape(-1)
         if a.dtype not in (np.int32, np.float32):
             raise TypeError("samples must be int32 or float32")
@@ -178,7 +181,9 @@ class Oracle:
         trace = np.zeros(nb, RX_EVENT_DTYPE)
         text = C.create_string_buffer(4096)
         nt = C.c_size_t(0)
-        rc = lib().uco_receive_stream(self._h, _ptr(a), dt, a.size, precision, text, 4096, _ptr(trace), nb, C.byref(nt))
+        bz = None if busy is None else np.ascontiguousarray(busy, np.uint8).reshape(-1)
+        rc = lib().uco_receive_stream_isr(self._h, _ptr(a), dt, a.size, _ptr(bz) if bz is not None else None, precision, text,
+                                          4096, _ptr(trace), nb, C.byref(nt))
         if rc < 0:
             raise RuntimeError("uco_receive_stream rc=%d" % rc)
         return text.value.decode("latin-1"), trace[:nt.value]

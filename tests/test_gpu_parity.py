@@ -461,10 +461,23 @@ def test_receive_stream_state_machine_matches_oracle(uchirp, variant):
         assert np.allclose(tr_g["snr_up"][act], tr_o["snr_up"][act], rtol=1e-4, atol=1e-3)
         if variant == uco.SYNC_CPLX:
             assert text_g == "Hello World!\n"
+    # the ISR's drop-on-busy (main.c:661): blocks that arrive while the consumer is still busy are lost; the batched
+    # launch then runs over the ACCEPTED blocks only and the trace still equals the oracle's literal loop
+    x = _hello_stream(seed=4, skew=300)
+    nb = x.size // 2048
+    for busy in (np.arange(nb) % 7 == 3, np.arange(nb) % 2 == 1, np.ones(nb, bool), np.zeros(nb, bool)):
+        o, e = uco.Oracle(variant), uchirp.Engine(variant)
+        text_o, tr_o = o.receive(x, precision=uco.F64, busy=busy)
+        text_g, tr_g = e.receive(x, busy=busy)
+        assert text_g == text_o and len(tr_g) == len(tr_o) == int((~busy).sum())
+        for fld in ("block", "state_before", "state_after", "bit", "sync_position"):
+            assert np.array_equal(tr_g[fld], tr_o[fld]), fld
     # device-resident stream, int32 words
     import torch
     xi = torch.from_numpy((np.round(_hello_stream()).astype(np.int64) * 256).astype(np.int32)).to("cuda:0")
     assert uchirp.Engine(uco.SYNC_CPLX).receive(xi)[0] == "Hello World!\n"
+    with pytest.raises(TypeError):
+        uchirp.Engine(uco.SYNC_CPLX).receive(xi.double())   # no silent reinterpretation of other dtypes
 
 
 def _iq_stream(n_frames, seed=5, fs=100000.0, carrier=18000.0, bw=3000.0, amp=1000.0, sigma=100.0):
@@ -624,6 +637,14 @@ def test_cpp_host_layer_runs_the_firmware_main_loop(uchirp, tmp_path):
         assert out.stdout.decode("latin-1") == want
         if variant == uco.SYNC_CPLX:
             assert want == "Hello World!\n"
+        # every 7th block arrives while the consumer is busy: the ISR callback of the host layer drops it
+        out = subprocess.run([exe, path, str(variant), "busy"], capture_output=True, timeout=300)
+        assert out.returncode == 0, out.stderr.decode()
+        want, _ = uco.Oracle(variant).receive(words, precision=uco.F64, busy=np.arange(words.size // 2048) % 7 == 3)
+        assert out.stdout.decode("latin-1") == want
+    # a variant without an up/down history pair is rejected by the Receiver's constructor
+    out = subprocess.run([exe, path, str(uco.COMPRESS)], capture_output=True, timeout=300)
+    assert out.returncode == 1 and b"up/down history pair" in out.stderr
 
 
 def test_iq_variant_at_1024_points_one_wave_per_frame(uchirp):

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/uchirp.h"
+#include "../../include/uchirp_mainloop.hpp"
 #include "uc_kernels.hpp"
 #include "uc_tables.hpp"
 
@@ -94,6 +95,8 @@ struct uc_ctx {
   int iq_blocks_per_cu = 0;
   int stream_blocks_per_cu = 0;
   DevBuf s_comp, s_peaks;
+  DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream: zero-prefixed stream, (up, down) mag_max per frame
+  std::vector<float2> h_rx_mag;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID / UC_BAND_GROUP / UC_STATIC_DEAL): not part of the ABI
   int grid_override = 0;
   int band_group = 32;    // frames per group handed to a workgroup at a time
@@ -352,6 +355,8 @@ void uc_destroy(uc_ctx* c) {
   c->s_stats.release();
   c->s_comp.release();
   c->s_peaks.release();
+  c->s_rx_pad.release();
+  c->s_rx_mag.release();
   delete c;
 }
 
@@ -408,8 +413,17 @@ int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
   return (int32_t)((ifs * (n - idx) / n) * 0xFFFFFFFFu);
 }
 
+static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
+                              const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream);
+
 int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                      const float* mag_mean, uint8_t* symbols, uc_stats* stats, void* hip_stream) {
+  return process_batch_impl(c, frames, dtype, n_frames, stride_elems, mag_mean, symbols, stats, nullptr, hip_stream);
+}
+
+// d_magmax: device, (up, down) mag_max per frame, nullable (internal: uc_receive_stream)
+static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
+                              const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream) {
   if (!c) return fail(-EINVAL, "uc_process_batch: NULL ctx");
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32)
     return fail(-EINVAL, "uc_process_batch: dtype %d is neither UC_DTYPE_I32 nor UC_DTYPE_F32", dtype);
@@ -544,6 +558,7 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
   p.mag_mean = d_mm;
   p.symbols = d_sym;
   p.stats = d_stats;
+  p.magmax = d_magmax;
   p.mag_mean_scalar = c->cfg.mag_mean;
   p.snr_threshold = c->cfg.snr_threshold;
   p.bw2 = c->tab.bandwidth2;
@@ -791,16 +806,18 @@ int uc_process_frame(uc_ctx* c, const int32_t* pcm_in, float mag_mean, uint8_t* 
 // ---------------------------------------------------------------------------
 // uc_receive_stream: the receiver's main loop over a recorded stream.
 // DSP: ONE batched launch over every 256-sample offset of the zero-prefixed
-// stream; control: main()'s switch replayed on the host over the statistics.
+// stream; control: main()'s switch (include/uchirp_mainloop.hpp, shared with the
+// C++ host layer) replayed on the host over the (up, down) mag_max of every frame.
 // ---------------------------------------------------------------------------
 namespace {
 
-struct HistLite {
+struct HistLite {  // the members of struct history the switch reads
   float mag_max = 0.0f, mag_mean = 0.0f, snr = 0.0f;
 };
 
 struct RxReplay {
-  const uc_stats* stats;  // [n_frames][2]: {up, down}
+  typedef HistLite history_t;
+  const float2* magmax;  // [n_frames]: (up, down)
   size_t n_frames;
   uint32_t n;
   size_t block;  // current block index b: FIFO = padded[b*n, b*n + 3n)
@@ -808,35 +825,17 @@ struct RxReplay {
   // dsp(): receiver/Src/main.c:183-231 -- the frame at FIFO offset pos is frame (b*n + pos)/256
   void dsp(uint32_t pos, HistLite* h, float mag_mean, int updown) const {
     const size_t g = (block * (size_t)n + pos) / 256;
-    const uc_stats& s = stats[2 * g + (updown == UC_UP_CHIRP ? 0 : 1)];
-    h->mag_max = s.mag_max;
+    const float m = updown == UC_UP_CHIRP ? magmax[g].x : magmax[g].y;
+    h->mag_max = m;
     h->mag_mean = mag_mean;
-    h->snr = (s.mag_max - mag_mean) / mag_mean;  // main.c:229
-  }
-  float symbol_snr(uint32_t pos, HistLite* h, int updown) const {  // main.c:233-236
-    dsp(pos, h, h->mag_mean, updown);
-    return h->snr;
-  }
-  // resync(): main.c:243-273, Q8 fixed (bounds first)
-  void resync(float snr, HistLite* hist, uint32_t offset, uint32_t* sync_position, int updown) const {
-    const int32_t pos_l = (int32_t)*sync_position - (int32_t)offset;
-    const int32_t pos_r = (int32_t)*sync_position + (int32_t)offset;
-    float snr_l = -INFINITY, snr_r = -INFINITY;
-    if (pos_l >= 0) snr_l = symbol_snr((uint32_t)pos_l, &hist[2], updown);
-    if (pos_r <= (int32_t)(2 * n)) snr_r = symbol_snr((uint32_t)pos_r, &hist[3], updown);
-    if ((snr > snr_l) && (snr > snr_r)) return;
-    if (snr_l >= snr_r) {
-      if (pos_l >= 0) *sync_position = (uint32_t)pos_l;
-    } else if (snr_l < snr_r) {
-      if (pos_r <= (int32_t)(2 * n)) *sync_position = (uint32_t)pos_r;
-    }
+    h->snr = (m - mag_mean) / mag_mean;  // main.c:229
   }
 };
 
 }  // namespace
 
-extern "C" int uc_receive_stream(uc_ctx* c, const void* samples, int dtype, size_t n_samples, char* text,
-                                 size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
+extern "C" int uc_receive_stream_isr(uc_ctx* c, const void* samples, int dtype, size_t n_samples, const uint8_t* busy,
+                                     char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
   if (!c || !text || text_cap == 0) return fail(-EINVAL, "uc_receive_stream: NULL argument");
   text[0] = '\0';
   if (n_trace) *n_trace = 0;
@@ -850,140 +849,67 @@ extern "C" int uc_receive_stream(uc_ctx* c, const void* samples, int dtype, size
 
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  // zero-prefixed copy of the stream on the device: fifo_queue starts as 3n zeros (main.c:94)
-  const size_t padded = (2 + n_blocks) * (size_t)n;
+  // The ISR (main.c:659-668) appends a block only when the main loop has consumed the previous one: a block that
+  // arrives while `new_pcm_data` is still set is DROPPED, the FIFO is not shifted.  `busy[b] != 0` says the consumer
+  // was still busy when block b arrived (NULL: never -- the GPU evaluates all of a block's dsp() calls at once).
+  // The FIFO therefore only ever holds ACCEPTED blocks, in order: drop the others before the batched launch.
+  std::vector<uint32_t> accepted;
+  accepted.reserve(n_blocks);
+  for (size_t b = 0; b < n_blocks; b++)
+    if (!busy || !busy[b]) accepted.push_back((uint32_t)b);
+  const size_t na = accepted.size();
+  if (na == 0) return 0;
+  // zero-prefixed copy of the accepted stream on the device: fifo_queue starts as 3n zeros (main.c:94)
+  const size_t padded = (2 + na) * (size_t)n;
   const size_t n_frames = (padded - n) / 256 + 1;
-  void* d_pad = nullptr;
-  uc_stats* d_stats = nullptr;
-  e = hipMalloc(&d_pad, padded * 4);
-  if (e != hipSuccess) return hip_fail(e, "hipMalloc(stream)");
-  e = hipMalloc((void**)&d_stats, n_frames * 2 * sizeof(uc_stats));
-  if (e != hipSuccess) { (void)hipFree(d_pad); return hip_fail(e, "hipMalloc(stats)"); }
-  int rc = 0;
-  std::vector<uc_stats> stats(n_frames * 2);
-  e = hipMemset(d_pad, 0, 2 * (size_t)n * 4);
-  if (e == hipSuccess)
-    e = hipMemcpy((char*)d_pad + 2 * (size_t)n * 4, samples, n_blocks * (size_t)n * 4,
-                  is_device_ptr(samples) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
-  if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(stream)");
-  if (!rc) rc = uc_process_batch(c, d_pad, dtype, n_frames, 256, nullptr, nullptr, d_stats, nullptr);
-  if (!rc) {
-    e = hipMemcpy(stats.data(), d_stats, stats.size() * sizeof(uc_stats), hipMemcpyDeviceToHost);  // syncs stream 0
-    if (e != hipSuccess) rc = hip_fail(e, "hipMemcpy(stats)");
-  }
-  (void)hipFree(d_pad);
-  (void)hipFree(d_stats);
+  int rc = c->s_rx_pad.ensure(padded * 4);
+  if (!rc) rc = c->s_rx_mag.ensure(n_frames * sizeof(float2));
   if (rc) return rc;
+  char* d_pad = (char*)c->s_rx_pad.p;
+  const hipMemcpyKind kind = is_device_ptr(samples) ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  e = hipMemsetAsync(d_pad, 0, 2 * (size_t)n * 4, nullptr);
+  for (size_t i = 0; e == hipSuccess && i < na;) {  // runs of consecutive accepted blocks: one copy each
+    size_t jn = i + 1;
+    while (jn < na && accepted[jn] == accepted[jn - 1] + 1) jn++;
+    e = hipMemcpyAsync(d_pad + (2 + i) * (size_t)n * 4, (const char*)samples + (size_t)accepted[i] * n * 4,
+                       (jn - i) * (size_t)n * 4, kind, nullptr);
+    i = jn;
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(stream)");
+  rc = process_batch_impl(c, d_pad, dtype, n_frames, 256, nullptr, nullptr, nullptr, (float2*)c->s_rx_mag.p, nullptr);
+  if (rc) return rc;
+  c->h_rx_mag.resize(n_frames);
+  e = hipMemcpy(c->h_rx_mag.data(), c->s_rx_mag.p, n_frames * sizeof(float2), hipMemcpyDeviceToHost);  // syncs stream 0
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(mag_max)");
 
-  // main()'s locals: receiver/Src/main.c:314-339
-  RxReplay rx{stats.data(), n_frames, n, 0};
-  uint32_t max_idx = 0, turn = 0;
-  const uint32_t offset = n / 8, shift = n / 4;  // main.c:406-407
-  HistLite history[8];
-  float mag_stat[12];
-  for (float& v : mag_stat) v = 1E37f;
-  float mag_mean = 0.0f;
-  uint32_t sync_cnt = 0, sync_position = n / 2;
-  int state = UC_STATE_IDLE;
-  unsigned char msg = 0;
-  int msg_cnt = 0;
+  RxReplay rx{c->h_rx_mag.data(), n_frames, n, 0};
+  uchirp::MainLoop<RxReplay> loop(n, c->cfg.snr_threshold);
   size_t nt = 0, ntext = 0;
-  const float thr = c->cfg.snr_threshold;
-
-  for (size_t b = 0; b < n_blocks; b++) {
-    rx.block = b;
-    const int prev_state = state;
-    int bit = -1;
-    float snr_up = 0.0f, snr_down = 0.0f;
-    switch (state) {
-      case UC_STATE_IDLE: {
-        sync_cnt = 0;
-        float sum = 0.0f;  // arm_mean_f32(&mag_stat[4], 8, &mag_mean): main.c:431
-        for (int i = 4; i < 12; i++) sum += mag_stat[i];
-        mag_mean = sum / 8.0f;
-      }
-        [[fallthrough]];  // "intentionally no break here": main.c:434
-      case UC_STATE_SYNCHRONIZING: {
-        for (uint32_t i = 0; i < 4; i++) {  // main.c:447-451
-          sync_position = n / 2 + turn * offset + shift * i;
-          rx.dsp(sync_position, &history[i * 2 + turn], mag_mean, UC_UP_CHIRP);
-        }
-        turn = (turn == 0) ? 1 : 0;
-        if (turn == 1) {
-          for (int i = 10; i >= 0; i--) mag_stat[i + 1] = mag_stat[i];
-          float mag_max_max = 0.0f;
-          for (int i = 0; i < 8; i++) {
-            const float mag_max = history[i].mag_max;
-            if (mag_max > mag_max_max) { mag_max_max = mag_max; max_idx = (uint32_t)i; }
-          }
-          mag_stat[0] = mag_max_max;
-          const float snr = (mag_max_max - mag_mean) / mag_mean;
-          if (snr >= thr) {
-            state = UC_STATE_SYNCHRONIZING;
-            if (++sync_cnt >= 3) {
-              state = UC_STATE_SYNCHRONIZED;
-              sync_position = n / 2 + max_idx * offset;
-            }
-          } else {
-            state = UC_STATE_IDLE;
-          }
-        }
-        break;
-      }
-      case UC_STATE_SYNCHRONIZED:  // main.c:491-510
-        snr_up = rx.symbol_snr(sync_position, &history[0], UC_UP_CHIRP);
-        snr_down = rx.symbol_snr(sync_position, &history[1], UC_DOWN_CHIRP);
-        if ((snr_up >= thr) || (snr_down >= thr)) {
-          if (snr_down > snr_up) {
-            rx.resync(snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
-            state = UC_STATE_DATA_RECEIVING;
-          } else {
-            rx.resync(snr_up, history, offset, &sync_position, UC_UP_CHIRP);
-          }
-        } else {
-          state = UC_STATE_IDLE;
-        }
-        break;
-      case UC_STATE_DATA_RECEIVING:  // main.c:512-550
-        snr_up = rx.symbol_snr(sync_position, &history[0], UC_UP_CHIRP);
-        snr_down = rx.symbol_snr(sync_position, &history[1], UC_DOWN_CHIRP);
-        if ((snr_up >= thr) || (snr_down >= thr)) {
-          if (snr_down > snr_up) {
-            bit = 0;
-            msg = (unsigned char)((msg << 1) + 0);
-            rx.resync(snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
-          } else {
-            bit = 1;
-            msg = (unsigned char)((msg << 1) + 1);
-            rx.resync(snr_up, history, offset, &sync_position, UC_UP_CHIRP);
-          }
-          if (++msg_cnt >= 8) {
-            if (ntext + 1 < text_cap) text[ntext++] = (char)msg;
-            msg = 0;
-            msg_cnt = 0;
-          }
-        } else {
-          if (ntext + 1 < text_cap) text[ntext++] = '\n';
-          state = UC_STATE_IDLE;
-          msg = 0;
-          msg_cnt = 0;
-        }
-        break;
-    }
+  auto put = [&](char ch) {
+    if (ntext + 1 < text_cap) text[ntext++] = ch;
+  };
+  for (size_t i = 0; i < na; i++) {
+    rx.block = i;
+    const uchirp::loop_event le = loop.step(rx, put);
     if (trace && nt < trace_cap) {
       uc_rx_event& ev = trace[nt];
-      ev.block = (uint32_t)b;
-      ev.sync_position = sync_position;
-      ev.state_before = (uint8_t)prev_state;
-      ev.state_after = (uint8_t)state;
-      ev.bit = (int8_t)bit;
+      ev.block = accepted[i];
+      ev.sync_position = le.sync_position;
+      ev.state_before = (uint8_t)le.state_before;
+      ev.state_after = (uint8_t)le.state_after;
+      ev.bit = (int8_t)le.bit;
       ev.reserved = 0;
-      ev.snr_up = snr_up;
-      ev.snr_down = snr_down;
+      ev.snr_up = le.snr_up;
+      ev.snr_down = le.snr_down;
     }
     nt++;
   }
   text[ntext] = '\0';
   if (n_trace) *n_trace = nt;
   return (int)ntext;
+}
+
+extern "C" int uc_receive_stream(uc_ctx* c, const void* samples, int dtype, size_t n_samples, char* text,
+                                 size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
+  return uc_receive_stream_isr(c, samples, dtype, n_samples, nullptr, text, text_cap, trace, trace_cap, n_trace);
 }

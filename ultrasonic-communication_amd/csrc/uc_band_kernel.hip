@@ -439,6 +439,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           store_hist(p.stats + 2 * ff, h0, mm_up);
           store_hist(p.stats + 2 * ff + 1, h1, mm_dn);
         }
+        if (p.magmax) p.magmax[ff] = make_float2(h0.mag_max, h1.mag_max);
         if (p.symbols) {
           // receiver/Src/main.c:521-531
           uint8_t sym = (uint8_t)UC_SYM_NONE;

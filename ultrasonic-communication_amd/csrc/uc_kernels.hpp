@@ -23,6 +23,8 @@ struct BandParams {
   const float* mag_mean;  // device, 2 per frame {up,down}, or nullptr
   uint8_t* symbols;       // device or nullptr
   uc_stats* stats;        // device or nullptr
+  float2* magmax;         // device or nullptr: (up, down) mag_max of every frame only (uc_receive_stream's replay needs no
+                          // more: 8 instead of 64 bytes per frame to bring back); RX_REAL / SYNC_CPLX
   float mag_mean_scalar;
   float snr_threshold;
   uint32_t bw2;           // window length (<= 255)

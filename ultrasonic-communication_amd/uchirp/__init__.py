@@ -29,7 +29,7 @@ FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP, FLAG_IQ_BASEBAND = 1, 2, 8, 16
 
 EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", "uc_destroy",
            "uc_process_frame", "uc_process_batch", "uc_stats_per_frame", "uc_iq_halo",
-           "uc_get_table", "uc_get_windows", "uc_idx2freq", "uc_receive_stream",
+           "uc_get_table", "uc_get_windows", "uc_idx2freq", "uc_receive_stream", "uc_receive_stream_isr",
            "uc_stream_geometry", "uc_process_stream", "uc_dfsdm_sinc5"]
 
 
@@ -101,6 +101,8 @@ def lib():
     L.uc_idx2freq.restype = C.c_int32
     L.uc_receive_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_char_p, C.c_size_t,
                                     C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    L.uc_receive_stream_isr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_char_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
     L.uc_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
     L.uc_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.uc_dfsdm_sinc5.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -164,14 +166,22 @@ class Engine:
     def idx2freq(self, idx):
         return lib().uc_idx2freq(self._h, int(idx))
 
-    def receive(self, samples):
-        """uc_receive_stream: the receiver's main loop over a recorded stream.
-        samples: numpy int32/float32 array or a torch device tensor.  Returns (text, trace)."""
+    def receive(self, samples, busy=None):
+        """uc_receive_stream / uc_receive_stream_isr: the receiver's main loop over a recorded stream.
+        samples: numpy int32/float32 array or a torch int32/float32 device tensor.
+        busy: optional per-block flags (the consumer had not finished when the block arrived: the ISR drops it).
+        Returns (text, trace)."""
         if _is_torch(samples):
             import torch
             if not samples.is_contiguous():
                 raise ValueError("samples tensor must be contiguous")
+            if samples.dtype not in (torch.int32, torch.float32):
+                raise TypeError("samples must be int32 or float32")
+            if samples.device.type != "cuda":
+                raise ValueError("torch samples must live on the GPU (numpy arrays take the host path)")
             dt = DTYPE_I32 if samples.dtype == torch.int32 else DTYPE_F32
+            # the call copies on the null stream and blocks: whatever produced `samples` on torch's stream must be done
+            torch.cuda.current_stream(samples.device).synchronize()
             ptr, count = C.c_void_p(samples.data_ptr()), samples.numel()
         else:
             a = np.ascontiguousarray(samples).reshape(-1)
@@ -183,8 +193,14 @@ class Engine:
         trace = np.zeros(max(nb, 1), RX_EVENT_DTYPE)
         text = C.create_string_buffer(4096)
         nt = C.c_size_t(0)
-        _check(lib().uc_receive_stream(self._h, ptr, dt, count, text, 4096, trace.ctypes.data_as(C.c_void_p),
-                                       nb, C.byref(nt)), "uc_receive_stream")
+        bz = None
+        if busy is not None:
+            bz = np.ascontiguousarray(busy, np.uint8).reshape(-1)
+            if bz.size != nb:
+                raise ValueError("busy must hold one flag per %d-sample block" % self.n)
+        _check(lib().uc_receive_stream_isr(self._h, ptr, dt, count, bz.ctypes.data_as(C.c_void_p) if bz is not None else None,
+                                           text, 4096, trace.ctypes.data_as(C.c_void_p), nb, C.byref(nt)),
+               "uc_receive_stream")
         return text.value.decode("latin-1"), trace[:nt.value]
 
     def stream_geometry(self, n_samples):
@@ -317,6 +333,9 @@ class Engine:
                 if mm.numel() != 2 * n_frames:
                     raise ValueError("mag_mean must hold 2 floats per frame")
                 mm_ptr = C.c_void_p(mm.data_ptr())
+                # `mm` may be a temporary and the launch is asynchronous on a stream torch's allocator may not know
+                # about: keep it alive until the next call of this engine
+                self._mm_keep = mm
             if stream is None:
                 stream = torch.cuda.current_stream(dev).cuda_stream
             _check(lib().uc_process_batch(self._h, C.c_void_p(t.data_ptr() + 4 * halo), dt, n_frames, st,
