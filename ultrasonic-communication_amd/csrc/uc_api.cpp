@@ -56,6 +56,9 @@ struct DevBuf {
   }
 };
 
+// (Not cached: device and host allocations share one virtual address space, so an address that was device memory can
+// later be host memory; a stale "device" verdict would hand a host pointer to a kernel.  The query costs a few
+// microseconds per pointer argument, which only small batches notice.)
 bool is_device_ptr(const void* p) {
   if (!p) return false;
   hipPointerAttribute_t attr;
@@ -91,9 +94,9 @@ struct uc_ctx {
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
   int band_blocks_per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}};  // [mode][dtype]: the instantiations differ in registers
-  int full_blocks_per_cu = 0;
-  int iq_blocks_per_cu = 0;
-  int stream_blocks_per_cu = 0;
+  int full_blocks_per_cu[2] = {0, 0};    // [dtype]: the int32 / f32 instantiations differ in registers
+  int iq_blocks_per_cu[2] = {0, 0};
+  int stream_blocks_per_cu[2] = {0, 0};
   DevBuf s_comp, s_peaks;
   DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream: zero-prefixed stream, (up, down) mag_max per frame
   std::vector<float2> h_rx_mag;
@@ -507,9 +510,9 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     }
     ip.fir_mfma = (n == 1024 && c->iq_fir_mfma) ? c->d_aux : nullptr;
     ip.stagger = c->iq_stagger;
-    if (c->iq_blocks_per_cu == 0)
-      c->iq_blocks_per_cu = uc::iq_max_blocks_per_cu(dtype, (int)n, bb ? 1 : 0, ip.fir_mfma ? 1 : 0);
-    size_t grid = (size_t)c->num_cu * (size_t)c->iq_blocks_per_cu;
+    int& iq_bpc = c->iq_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
+    if (iq_bpc == 0) iq_bpc = uc::iq_max_blocks_per_cu(dtype, (int)n, bb ? 1 : 0, ip.fir_mfma ? 1 : 0);
+    size_t grid = (size_t)c->num_cu * (size_t)iq_bpc;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     if (grid > n_frames) grid = n_frames;
     // groups of up to 64 consecutive frames (one finaliser drain each), dealt round robin;
@@ -537,8 +540,9 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     fp.symbols = d_sym;
     fp.stats = d_stats;
     fp.mag_mean_scalar = c->cfg.mag_mean;
-    if (c->full_blocks_per_cu == 0) c->full_blocks_per_cu = uc::compress_max_blocks_per_cu(dtype);
-    size_t grid = (size_t)c->num_cu * (size_t)c->full_blocks_per_cu;
+    int& full_bpc = c->full_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
+    if (full_bpc == 0) full_bpc = uc::compress_max_blocks_per_cu(dtype);
+    size_t grid = (size_t)c->num_cu * (size_t)full_bpc;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     const size_t npairs = (n_frames + 1) / 2;
     if (grid > npairs) grid = npairs;
@@ -765,8 +769,9 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
     sp.rots[2 * sub] = c->stab.rot[2 * (size_t)(sub * (4096 / D))];
     sp.rots[2 * sub + 1] = c->stab.rot[2 * (size_t)(sub * (4096 / D)) + 1];
   }
-  if (c->stream_blocks_per_cu == 0) c->stream_blocks_per_cu = uc::stream_max_blocks_per_cu(dtype, D);
-  size_t grid = (size_t)c->num_cu * (size_t)c->stream_blocks_per_cu;
+  int& st_bpc = c->stream_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
+  if (st_bpc == 0) st_bpc = uc::stream_max_blocks_per_cu(dtype, D);
+  size_t grid = (size_t)c->num_cu * (size_t)st_bpc;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   if (grid > n_blocks) grid = n_blocks;
   int lrc = uc::launch_stream(dtype, D, sp, (int)grid, stream);
