@@ -1,0 +1,125 @@
+"""Scale coverage: 64 Ki frames at -10 dB through every batch variant, EVERY record --
+symbols, window magnitudes, peak indices -- against the float64 oracle (this box's CPU share), with the usual bars:
+magnitudes within MAG_TOL x the frame's largest window magnitude, every index mismatch a proven near-tie, symbols
+exact on every clear frame.  The 1 Mi-frame symbol gate of the bench's own batch is in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import synth
+from oracle import uco
+from parity_util import MAG_TOL, check_history, clear_symbols
+
+pytestmark = pytest.mark.gpu
+
+N_FRAMES = 1 << 16
+
+
+@pytest.fixture(scope="module")
+def uchirp():
+    import uchirp as m
+    m.lib()
+    return m
+
+
+def _threads():
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    from bench import host_cpu_share
+    return host_cpu_share()
+
+
+def _frames(seed, dtype=np.float32, **kw):
+    parts, bits = [], []
+    for c in range(N_FRAMES // 8192):
+        f, b = synth.make_frames(8192, seed=seed * 100 + c, snr_db=-10.0, dtype=dtype, **kw)
+        parts.append(f)
+        bits.append(b)
+    return np.concatenate(parts), np.concatenate(bits)
+
+
+@pytest.mark.parametrize("variant,dtype", [(uco.SYNC_CPLX, np.float32), (uco.RX_REAL, np.int32), (uco.SYNC_CPLX, np.int32)])
+def test_64ki_frames_two_history_variants(uchirp, variant, dtype):
+    import torch
+    frames, bits = _frames(11 + variant, dtype=dtype)
+    mm = 1000.0 * (256.0 if dtype == np.int32 else 1.0)
+    o = uco.Oracle(variant, mag_mean=mm)
+    e = uchirp.Engine(variant, mag_mean=mm)
+    gs, gst = e.process(torch.from_numpy(frames).to("cuda:0"))
+    torch.cuda.synchronize()
+    gs, gst = gs.cpu().numpy(), uchirp.stats_from_tensor(gst)
+    rs, rst = o.process(frames, precision=uco.F64, threads=_threads())
+    clear = clear_symbols(rst)
+    assert clear.mean() > 0.98
+    assert np.array_equal(gs[clear], rs[clear])
+    ties = 0
+    for h in (0, 1):
+        ties += check_history(o, lambda f: frames[f], gst[:, h], rst[:, h], h, "variant %d hist%d" % (variant, h))
+        np.testing.assert_array_equal(gst[:, h]["mag_mean"], rst[:, h]["mag_mean"])
+    assert ties <= 0.01 * N_FRAMES
+    print("variant %d %s: %d frames, %d unclear symbols, %d proven index near-ties" % (variant, dtype.__name__, N_FRAMES,
+                                                                                     int((~clear).sum()), ties))
+
+
+def test_64ki_frames_dechirp_down(uchirp):
+    import torch
+    frames, _ = _frames(31, fs=100000.0, f0=17000.0, f1=18000.0)
+    o = uco.Oracle(uco.DECHIRP_DOWN, mag_mean=1000.0)
+    e = uchirp.Engine(uchirp.DECHIRP_DOWN, mag_mean=1000.0)
+    gs, gst = e.process(torch.from_numpy(frames).to("cuda:0"))
+    torch.cuda.synchronize()
+    gst = uchirp.stats_from_tensor(gst)
+    rs, rst = o.process(frames, precision=uco.F64, threads=_threads())
+    ties = check_history(o, lambda f: frames[f], gst[:, 0], rst[:, 0], 0, "dechirp_down", raw_idx=True)
+    assert np.allclose(gst[:, 0]["snr"], rst[:, 0]["snr"], rtol=1e-4, atol=1e-4)
+    assert ties <= 0.01 * N_FRAMES
+    print("dechirp_down: %d frames, %d proven index near-ties" % (N_FRAMES, ties))
+
+
+def test_64ki_frames_compress(uchirp):
+    import torch
+    rng = np.random.default_rng(5)
+    o = uco.Oracle(uco.COMPRESS, mag_mean=1.0)
+    e = uchirp.Engine(uchirp.COMPRESS, mag_mean=1.0)
+    up = o.table(uco.TABLE_UP).astype(np.float32)
+    parts = []
+    for c in range(N_FRAMES // 8192):   # circularly shifted up chirps at -10 dB
+        sh = rng.integers(0, 2048, size=8192)
+        idx = (np.arange(2048)[None, :] - sh[:, None]) % 2048
+        parts.append((1000.0 * up[idx] + 1000.0 * 10 ** 0.5 * rng.standard_normal((8192, 2048))).astype(np.float32))
+    frames = np.concatenate(parts)
+    gs, gst = e.process(torch.from_numpy(frames).to("cuda:0"))
+    torch.cuda.synchronize()
+    g = uchirp.stats_from_tensor(gst)[:, 0]
+    rs, rst = o.process(frames, precision=uco.F64, threads=_threads())
+    r = rst[:, 0]
+    scale = np.abs(r["mag_max"].astype(np.float64))
+    assert (np.abs(g["mag_max"].astype(np.float64) - r["mag_max"]) / scale).max() <= MAG_TOL
+    bad = np.nonzero(g["max_freq"] != r["max_freq"])[0]
+    for f in bad:  # every index mismatch must be a near-tie in the oracle's own compressed signal
+        y = o.spectrum(frames[f])[0]
+        assert y.max() - y[g["max_freq"][f]] <= MAG_TOL * abs(y.max()), f
+    assert len(bad) <= 0.01 * N_FRAMES
+    print("compress: %d frames, %d proven index near-ties" % (N_FRAMES, len(bad)))
+
+
+@pytest.mark.parametrize("n", [1024, 2048])
+def test_64ki_frames_iq_baseband(uchirp, n):
+    import torch
+    from test_gpu_iq_baseband import BB, iq_stream
+    nf = N_FRAMES // 2
+    x, bits = iq_stream(nf, n, sigma=1000.0 * 10 ** 0.5, seed=77)
+    cfg = dict(BB, n=n, time_frame=n / BB["fs"], flags=uco.FLAG_IQ_BASEBAND, mag_mean=1000.0)
+    o, e = uco.Oracle(uco.IQ, **cfg), uchirp.Engine(uchirp.IQ, **cfg)
+    gs, gst = e.process(torch.from_numpy(x).to("cuda:0"), n_frames=nf)
+    torch.cuda.synchronize()
+    gs, gst = gs.cpu().numpy(), uchirp.stats_from_tensor(gst)
+    rs, rst = o.process(x, halo=26, n_frames=nf, precision=uco.F64, threads=_threads())
+    clear = clear_symbols(rst)
+    assert np.array_equal(gs[clear], rs[clear]) and clear.mean() > 0.98
+    ties = 0
+    for h in (0, 1):
+        ties += check_history(o, lambda f: x[f * n: f * n + n + 26], gst[:, h], rst[:, h], h, "iq bb n=%d hist%d" % (n, h),
+                              spectrum_kw={"halo": 26})
+    assert ties <= 0.01 * nf
+    print("iq base band n=%d: %d frames, BER %.4f, %d proven index near-ties" % (n, nf, float((gs != bits).mean()), ties))
