@@ -10,7 +10,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["UCHIRP_LIB"] = os.path.join(ROOT, "ultrasonic-communication_amd", "libuchirp_clock.so")
+os.environ.setdefault("UCHIRP_LIB", os.path.join(ROOT, "ultrasonic-communication_amd", "libuchirp_clock.so"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
 import numpy as np
