@@ -92,8 +92,23 @@ def cpu_baseline(frames_host, mag_mean):
     except OSError:
         pass
     rs, _ = o.process(frames_host[:4096], precision=uco.F64, threads=cores)
+    # SURVEY.md section 8d's optional NumPy line: the same decision with numpy.fft.rfft (pocketfft), one process
+    up, down, hann = o.table(uco.TABLE_UP), o.table(uco.TABLE_DOWN), o.table(uco.TABLE_HANN)
+    bw2 = o.bandwidth2
+    xs = frames_host[: 1 << 14]
+    t2 = time.perf_counter()
+    def window_max(ref):  # both windows of dsp(): bins [0, bw2) and the mirror of [1, bw2]; mag[0] is the packed pair (Q2)
+        X = np.fft.rfft((xs * ref) * hann, axis=1)
+        m = np.abs(X[:, : bw2 + 1])
+        m[:, 0] = np.hypot(X[:, 0].real, X[:, -1].real)
+        return m.max(axis=1)
+    mu, md = window_max(up), window_max(down)
+    sym_np = np.where((np.maximum(mu, md) - mag_mean) / mag_mean >= 2.0, (md <= mu).astype(np.uint8), 255)
+    numpy_rate = xs.shape[0] / (time.perf_counter() - t2)
+    numpy_agree = float((sym_np[:4096] == rs).mean())
     return {"symbols_f64_oracle_head": rs, "value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "one_thread_value": one_thread, "cpu_model": model,
+            "numpy_rfft_value": numpy_rate, "numpy_rfft_agrees_with_oracle": numpy_agree,
             "sample": "%d passes over the first %d frames of the same batch, oracle/uc_oracle.c "
                       "(float32 butterflies), OpenMP %d threads = this box's CPU share (%d hardware threads visible), "
                       "%.1f s" % (passes, n // passes, cores, os.cpu_count() or 1, dt)}
