@@ -583,6 +583,7 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   // would not give every workgroup a few (a small batch then still spreads over the whole chip)
   const size_t units = (mode == uc::kModePair) ? (n_frames + 1) / 2 : n_frames;
   uint32_t group = (uint32_t)c->band_group;
+  if (c->band_waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
   while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;
   const size_t ngroups = (units + group - 1) / group;
   if (grid > ngroups) grid = ngroups;

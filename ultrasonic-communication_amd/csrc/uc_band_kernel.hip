@@ -38,11 +38,17 @@ namespace {
 constexpr int T = kBandThreads;  // 128
 // LDS: the 2048-point complex tile, then a ring of per-frame window partials that a
 // 64-lane finaliser drains once per 64 frames.
-constexpr int kRingFrames = 64;
+constexpr int kRingFrames = 64;  // (32 in the 4-waves-per-SIMD build: groups of at most 32 frames there)
 constexpr int kRingStride = 13;  // 2 waves x 6 words + 1 pad word (conflict-free lane-strided reads)
 constexpr int kRingOff = 2 * kN;
-constexpr int kNextOff = kRingOff + kRingFrames * kRingStride;  // one word: the group this workgroup takes next
-constexpr int kLdsFloats = kNextOff + 1;
+// WAVES = 4 (8 workgroups per CU, 128 VGPRs): the 15 pass-2 twiddles of a thread do not fit the registers any more; the
+// 16 x 16 table W_256^(t k) sits in LDS instead (2 KiB, read with broadcast inside the 16-lane rows), and the ring
+// shrinks to 32 frames so that eight workgroups still fit the CU's 160 KiB
+constexpr int ring_frames(int waves) { return waves >= 4 ? 32 : kRingFrames; }
+constexpr int next_off(int waves) { return kRingOff + ring_frames(waves) * kRingStride; }  // one word: the next group
+constexpr int tw2_off(int waves) { return (next_off(waves) + 2) & ~1; }                     // 256 complex, 8-byte aligned
+constexpr int lds_floats(int waves) { return waves >= 4 ? tw2_off(waves) + 2 * 256 : next_off(waves) + 1; }
+static_assert(lds_floats(4) * 4 * 8 <= 160 * 1024, "eight workgroups per CU");
 
 constexpr float kCos16 = 0.98078528040323044913f;  // cos(pi/16)
 constexpr float kSin16 = 0.19509032201612826785f;  // sin(pi/16)
@@ -121,7 +127,7 @@ struct Common {
 // carry the up search and lanes 32-63 the down search; four row rotations and one row broadcast then
 // leave the up maximum in lane 31 and the down maximum in lane 63 (7 cross-lane steps instead of 12).
 template <bool HAS1>
-__device__ __forceinline__ void common_partial2(float a0, float b0, int k0, float a1, float b1, int k1, int bw2,
+__device__ __forceinline__ void common_partial2(float a0, float b0, int k0, int base0, float a1, float b1, int k1, int bw2,
                                                 Common& up, Common& dn) {
   const float ninf = -INFINITY;
   const bool in0 = (k0 >= 1 && k0 < bw2);
@@ -151,7 +157,7 @@ __device__ __forceinline__ void common_partial2(float a0, float b0, int k0, floa
   up.m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31));
   dn.m = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
   // the attaining bins from ballots and scalar bit scans (slot 0 holds the smaller bins)
-  const int base = __builtin_amdgcn_readfirstlane(k0);
+  const int base = base0;
   const unsigned long long ua0 = __ballot(ca0 == up.m), ub0 = __ballot(cb0 == dn.m);
   unsigned long long ua1 = 0, ub1 = 0;
   if (HAS1) {
@@ -275,12 +281,15 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const unsigned long long clk0_ = __builtin_readcyclecounter();
   const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
 #endif
-  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
+  constexpr bool kTw2Lds = WAVES >= 4;
+  constexpr int kNextOff = next_off(WAVES);
+  __shared__ __attribute__((aligned(16))) float lds[lds_floats(WAVES)];
+  float* tw2l = lds + tw2_off(WAVES);
   float* ring = lds + kRingOff;
 
   const int j = threadIdx.x;
   const int lane = j & 63;
-  const int wave = j >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(j >> 6);  // scalar: the compiler cannot see that it is wave-uniform
   const int bw2 = (int)p.bw2;
 
   // Frames are dealt to workgroups in GROUPS of p.group consecutive frames: all resident workgroups
@@ -341,8 +350,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // pass-2 twiddles W_256^(t*k), k = j & 15: all 15 resident (at 3 waves/SIMD the
   // registers are there; the factored form wa[n2]*wb[n1] costs 9 more products per frame)
   v2f tw2[16];
+  if (kTw2Lds) {
+    for (int e = j; e < 256; e += T) lds_st(tw2l, e, ld_tw(p.tw, 8 * (e >> 4) * (e & 15)));  // entry 16 t + k
+    __syncthreads();
+  } else {
 #pragma unroll
-  for (int t = 1; t < 16; t++) tw2[t] = ld_tw(p.tw, 8 * t * (j & 15));
+    for (int t = 1; t < 16; t++) tw2[t] = ld_tw(p.tw, 8 * t * (j & 15));
+  }
+  const int tw2o = j & 15;
   // pass-3 twiddles: W_2048^j and its square (the pruned pass is evaluated in Horner form)
   const v2f tw3_1 = ld_tw(p.tw, j), tw3_2 = ld_tw(p.tw, 2 * j);
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);  // SGPR pairs
@@ -478,7 +493,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     // would sit in registers for the whole batch).
     int s1v = s1;
     v2f t3a = tw3_1, t3b = tw3_2;
-    asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b));
+    if (kTw2Lds) {
+      // (128-register build: W^2j is squared from W^j every frame instead of living in two more registers;
+      // one rounding more than the table value, ~1e-7 relative on the twiddle)
+      asm volatile("" : "+v"(s1v), "+v"(t3a));
+      t3b = pk_cmul(t3a, t3a);
+    } else {
+      asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b));
+    }
     constexpr int kRuns = (MODE == kModeCplx) ? 2 : 1;
     float pv[4] = {0.f, 0.f, 0.f, 0.f};  // this wave's partials: up right/left, down right/left
     unsigned kpack = 0, flags = 0;
@@ -553,13 +575,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rd1 + 128 * t);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], tw2[t]);
+      for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], kTw2Lds ? lds_ld(tw2l, tw2o + 16 * t) : tw2[t]);
       pk_dft16(v, K, H);
       UC_STAMP(3);
       __syncthreads();  // B2: every pass-2 read is done before the tile is overwritten
       UC_STAMP(4);
 #pragma unroll
       for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[4 * (t & 3) + (t >> 2)]);
+
       __syncthreads();  // B3
       UC_STAMP(5);
       // ---- pass 3: radix-8, Ns = 256, only bins i in [0, bw2] and n - i -----
@@ -570,7 +593,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       float m_a[2] = {0.f, 0.f}, m_b[2] = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 2; r++) {
-        const int i = (r == 0) ? j : 128 + lane;
+        int lane_r = lane;
+        if (kTw2Lds) asm volatile("" : "+v"(lane_r));  // 128-register build: re-derive the round's addresses every frame
+        const int i = (r == 0) ? j : 128 + lane_r;
         if (i <= bw2 && (r == 0 || wave == 1)) {
           // issue the 16 reads of the round first, derive the twiddles under their latency
           const int ib = (256 - i) & 255;
@@ -589,7 +614,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             w2 = t3b;
           } else {
             // wave 1: W_2048^(j+64) = W_2048^j * W_32, squared: * W_16
-            w1 = pk_cmul(t3a, mkv(kCos16, -kSin16));
+            w1 = pk_cmul_s(t3a, mkv(kCos16, -kSin16));
             w2 = pk_mul_w1(t3b, K);
           }
           constexpr bool do_a = true, do_b = true;
@@ -649,8 +674,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       if (kReal) {
         // up history looks at m_a, down history at m_b; wave 1 also holds slot 1
         Common up, dn;
-        if (wave == 0) common_partial2<false>(m_a[0], m_b[0], j, 0.f, 0.f, k1, bw2, up, dn);
-        else common_partial2<true>(m_a[0], m_b[0], j, m_a[1], m_b[1], k1, bw2, up, dn);
+        // (base0 = the bin of the wave's lane 0 in slot 0: 64 * wave, a scalar)
+        if (wave == 0) common_partial2<false>(m_a[0], m_b[0], j, 0, 0.f, 0.f, k1, bw2, up, dn);
+        else common_partial2<true>(m_a[0], m_b[0], j, 64, m_a[1], m_b[1], k1, bw2, up, dn);
         if (lane == 0) {
           e[0] = up.m;
           e[1] = dn.m;

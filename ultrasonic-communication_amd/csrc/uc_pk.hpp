@@ -28,6 +28,15 @@ __device__ __forceinline__ v2f pk_cmul(v2f a, v2f w) {
   return r;
 }
 
+// a * w with w a wave-uniform constant (SGPR pair)
+__device__ __forceinline__ v2f pk_cmul_s(v2f a, v2f w) {
+  v2f r;
+  asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,1] op_sel_hi:[1,0] neg_lo:[0,1]\n\t"
+      "v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]"
+      : "=&v"(r) : "v"(a), "s"(w));
+  return r;
+}
+
 // a * conj(w)
 __device__ __forceinline__ v2f pk_cmulc(v2f a, v2f w) {
   v2f r;
