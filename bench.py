@@ -26,6 +26,8 @@ import subprocess
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
@@ -272,7 +274,6 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
-    import numpy as np
     import torch
     # UC_BENCH_REHEARSE=1: plumbing rehearsal of the N > 1 path (spawn, rendezvous, symbol gather, concatenation
     # check, text decode, JSON line) with gloo.  On a ONE-GPU box every rank runs the real kernel on device 0; on a
