@@ -713,3 +713,38 @@ def test_unsupported_configurations_fail_loudly(uchirp):
     e = uchirp.Engine(uchirp.COMPRESS)
     with pytest.raises(uchirp.UchirpError):
         e.receive(np.zeros(4096, np.float32))               # no up/down state machine for this variant
+
+
+@pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX, uco.DECHIRP_DOWN])
+def test_band_frame_groups_dynamic_hand_out(uchirp, variant, monkeypatch):
+    """The band kernel deals frames in groups; a workgroup's first group is fixed, every further one comes from an
+    atomic counter fetched one group ahead (csrc/uc_band_kernel.hip).  Tiny grids (UC_GRID), small groups
+    (UC_BAND_GROUP), the static deal (UC_STATIC_DEAL) and batch sizes around the group boundaries -- a one-frame last
+    group is the case that reads its ticket in the frame that should park it -- must all give bit-identical records."""
+    kw = dict(fs=100000.0, f0=17000.0, f1=18000.0) if variant == uco.DECHIRP_DOWN else {}
+    frames, _ = synth.make_frames(1200, seed=41, snr_db=-5.0, **kw)
+    ref = uchirp.Engine(variant, mag_mean=1000.0)
+    gs0, gst0 = ref.process(frames)
+    for env in ({"UC_GRID": "1"}, {"UC_GRID": "3", "UC_BAND_GROUP": "2"}, {"UC_GRID": "2", "UC_BAND_GROUP": "8"},
+                {"UC_GRID": "5", "UC_BAND_GROUP": "64"}, {"UC_GRID": "3", "UC_STATIC_DEAL": "1"}, {"UC_BAND_WAVES": "4", "UC_GRID": "2"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = uchirp.Engine(variant, mag_mean=1000.0)
+        for k in env:
+            monkeypatch.delenv(k)
+        for cnt in (1200, 1, 2, 3, 31, 32, 33, 63, 64, 65, 129, 257, 1025, 1199):
+            gs, gst = e.process(frames[:cnt])
+            assert np.array_equal(gs, gs0[:cnt]), (env, cnt)
+            if "UC_BAND_WAVES" in env:
+                # the 128-register build squares W^j every frame instead of reading W^2j from the table: one more
+                # rounding on a twiddle, so its magnitudes agree to float32 round-off, not bit for bit
+                for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+                    assert np.allclose(gst[fld], gst0[:cnt][fld], rtol=2e-6, atol=0.0), (env, cnt, fld)
+                assert (gst["max_freq"] == gst0[:cnt]["max_freq"]).mean() > 0.99
+            else:
+                # (DECHIRP_DOWN transforms frames in pairs: the last frame of an odd count rides with zeros instead of
+                # its neighbour, which changes its rounding, not its value)
+                same = cnt - (cnt & 1) if variant == uco.DECHIRP_DOWN else cnt
+                assert np.array_equal(gst[:same].view(np.uint32), gst0[:same].view(np.uint32)), (env, cnt)
+                for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+                    assert np.allclose(gst[same:][fld], gst0[same:cnt][fld], rtol=2e-6, atol=0.0), (env, cnt, fld)
