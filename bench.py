@@ -257,7 +257,9 @@ def launch_ranks(args):
     if rc:
         sys.stderr.write(text)
         raise SystemExit("bench.py: a rank failed (exit %s)" % rc)
-    sys.stdout.write(text)
+    # stdout carries the JSON line(s) only; anything a library printed on rank 0's stdout goes to stderr
+    for ln in text.splitlines():
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
 
 
