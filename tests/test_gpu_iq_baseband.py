@@ -145,15 +145,18 @@ def test_baseband_frame_groups_strides_and_small_batches(uchirp, n, monkeypatch)
     x, _ = iq_stream(n_frames, n, sigma=500.0, seed=21)
     o, e0 = _bb_engines(uchirp, n)
     gs0, gst0 = e0.process(x, n_frames=n_frames)
-    for grid in ("1", "3"):
-        monkeypatch.setenv("UC_GRID", grid)
+    for env in ({"UC_GRID": "1"}, {"UC_GRID": "3"}, {"UC_GRID": "2", "UC_IQ_GROUP": "2"}, {"UC_GRID": "3", "UC_IQ_GROUP": "8"},
+                {"UC_GRID": "2", "UC_STATIC_DEAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         _, e = _bb_engines(uchirp, n)
-        monkeypatch.delenv("UC_GRID")
+        for k in env:
+            monkeypatch.delenv(k)
         gs, gst = e.process(x, n_frames=n_frames)
-        assert np.array_equal(gs, gs0) and np.array_equal(gst.view(np.uint32), gst0.view(np.uint32)), grid
-        for cnt in (1, 31, 32, 33, 63, 64, 65):
+        assert np.array_equal(gs, gs0) and np.array_equal(gst.view(np.uint32), gst0.view(np.uint32)), env
+        for cnt in (1, 2, 3, 9, 31, 32, 33, 63, 64, 65, 129):
             a, ast = e.process(x, n_frames=cnt)
-            assert np.array_equal(a, gs0[:cnt]) and np.array_equal(ast.view(np.uint32), gst0[:cnt].view(np.uint32)), (grid, cnt)
+            assert np.array_equal(a, gs0[:cnt]) and np.array_equal(ast.view(np.uint32), gst0[:cnt].view(np.uint32)), (env, cnt)
     stride = n // 4
     nf = 200
     rs, rst = o.process(x, halo=26, stride=stride, n_frames=nf)

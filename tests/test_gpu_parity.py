@@ -683,17 +683,23 @@ def test_iq_frame_groups_ring_and_round_robin(uchirp, n, monkeypatch):
     ref_eng = uchirp.Engine(uchirp.IQ, n=n, mag_mean=1.0)
     mm = (np.arange(2 * n_frames, dtype=np.float32) % 7.0) + 1.0     # per-frame noise floors (first of each pair used)
     gs0, gst0 = ref_eng.process(x, n_frames=n_frames, mag_mean=mm)
-    for grid in ("1", "2", "3"):
-        monkeypatch.setenv("UC_GRID", grid)
+    # (with more groups than workgroups every group after a workgroup's first comes from the atomic hand-out counter,
+    # asked for one frame before the group's last: UC_IQ_GROUP = 2 asks in every group's first frame)
+    for env in ({"UC_GRID": "1"}, {"UC_GRID": "2"}, {"UC_GRID": "3"}, {"UC_GRID": "2", "UC_IQ_GROUP": "2"},
+                {"UC_GRID": "3", "UC_IQ_GROUP": "8"}, {"UC_GRID": "2", "UC_IQ_GROUP": "64"},
+                {"UC_GRID": "3", "UC_STATIC_DEAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         e = uchirp.Engine(uchirp.IQ, n=n, mag_mean=1.0)
-        monkeypatch.delenv("UC_GRID")
+        for k in env:
+            monkeypatch.delenv(k)
         gs, gst = e.process(x, n_frames=n_frames, mag_mean=mm)
         assert (gs == uchirp.SYM_NONE).all() and len(gs) == n_frames
-        assert np.array_equal(gst.view(np.uint32), gst0.view(np.uint32)), "grid %s changes the records" % grid
-        # fewer frames than one group, and exactly one group
-        for cnt in (1, 63, 64, 65):
+        assert np.array_equal(gst.view(np.uint32), gst0.view(np.uint32)), "%s changes the records" % env
+        # fewer frames than one group, exactly one group, ragged last groups of one and two frames
+        for cnt in (1, 2, 3, 7, 8, 9, 31, 32, 33, 63, 64, 65, 129, 130):
             a, ast = e.process(x, n_frames=cnt, mag_mean=mm[:2 * cnt])
-            assert np.array_equal(ast.view(np.uint32), gst0[:cnt].view(np.uint32)), (grid, cnt)
+            assert np.array_equal(ast.view(np.uint32), gst0[:cnt].view(np.uint32)), (env, cnt)
     o = uco.Oracle(uco.IQ, n=n, mag_mean=1.0)
     rs, rst = o.process(x, halo=26, n_frames=n_frames, mag_mean=mm)
     specs = [o.spectrum(x[f * n: f * n + n + 26], halo=26)[0] for f in range(0, n_frames, 7)]

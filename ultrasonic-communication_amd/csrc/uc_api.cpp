@@ -105,6 +105,7 @@ struct uc_ctx {
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
   bool cic_tickets = false;
+  int iq_group = 32;        // (env UC_IQ_GROUP) frames per hand-out group of the IQ kernels: a power of two <= 64
   unsigned iq_stagger = 0;  // (env UC_IQ_STAGGER, MFMA FIR only) start delay of every second wave on a SIMD, x 4096 clocks
   // UC_IQ at n = 1024, env UC_IQ_FIR=mfma: the FIR as v_mfma_f32_16x16x4_f32 Toeplitz tiles instead of packed VALU.
   // Off by default: an f32 MFMA and the partner wave's packed-f32 VALU do not overlap on a SIMD (tools/mfma_valu_probe.hip:
@@ -208,6 +209,10 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
   if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
   if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
+  if (const char* g = getenv("UC_IQ_GROUP")) {
+    const int v = atoi(g);
+    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->iq_group = v;
+  }
   int rc = uc::build_tables(*cfg, c->tab);
   if (rc) {
     delete c;
@@ -517,11 +522,21 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     if (grid > n_frames) grid = n_frames;
     // groups of up to 64 consecutive frames (one finaliser drain each), dealt round robin;
     // smaller groups when the batch would not give every workgroup one
-    ip.group = (bb && n == 2048) ? 32 : 64;  // (the base-band ring of the n = 2048 kernel holds 32 frames)
+    ip.group = (uint32_t)c->iq_group;
+    if (bb && n == 2048 && ip.group > 32) ip.group = 32;  // (the base-band ring of the n = 2048 kernel holds 32 frames)
     while (ip.group > 1 && n_frames < (size_t)ip.group * grid) ip.group >>= 1;
     {
       const size_t ngroups = (n_frames + ip.group - 1) / ip.group;
       if (grid > ngroups) grid = ngroups;
+    }
+    ip.work_ctr = nullptr;
+    if (!c->static_deal && ip.group >= 2) {
+      const size_t ngroups = (n_frames + ip.group - 1) / ip.group;
+      if (ngroups > grid) {  // dynamic hand-out: this launch's counter is zeroed on the stream right before it
+        ip.work_ctr = (unsigned int*)((char*)c->d_work + (size_t)(c->work_next++ % kWorkSlots) * kWorkStride);
+        e = hipMemsetAsync(ip.work_ctr, 0, sizeof(unsigned int), stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(work counter)");
+      }
     }
     int lrc = uc::launch_iq(dtype, ip, (int)grid, stream, (int)n);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "iq kernel launch");

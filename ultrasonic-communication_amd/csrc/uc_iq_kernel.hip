@@ -116,7 +116,8 @@ constexpr int kRingFrBb = 32;
 constexpr int kTileOff = 2 * kImg;
 constexpr int kRingO = kTileOff + 2 * kN;
 constexpr int kTw2O = kRingO + kRingFr * kRingSt;  // even: 8-byte aligned
-constexpr int kLdsAll = kTw2O + 2 * 256;
+constexpr int kNextO = kTw2O + 2 * 256;  // one word: the group a dynamic hand-out gave this workgroup next
+constexpr int kLdsAll = kNextO + 2;
 static_assert((kTw2O & 1) == 0, "complex alignment");
 static_assert(kImg >= kN, "exchange 1 lives in the image area");
 static_assert(kRingFrBb * kRingStBb <= kRingFr * kRingSt, "the base-band ring fits the same LDS");
@@ -133,13 +134,19 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   const int lane = j & 63;
   const int wave = j >> 6;
 
-  // frames are dealt in groups of G consecutive frames, round robin over the workgroups
-  const size_t nfr = p.n_frames;
-  const size_t G = p.group;
-  const size_t ngroups = (nfr + G - 1) / G;
-  size_t grp = blockIdx.x;
+  // frames are dealt in groups of G = 2^gsh consecutive frames (32-bit bookkeeping: the host rejects batches of 2^31
+  // frames or more; the frame ADDRESS is 64-bit).  Static deal: round robin over the workgroups.  Dynamic hand-out
+  // (p.work_ctr, G >= 2) as in iq1024_kernel below: thread 0 asks for the next group behind the FIR of a group's
+  // second-to-last frame; at the top of the last frame it passes the id to both waves through one LDS word.
+  const unsigned nfr = (unsigned)p.n_frames;
+  const unsigned gsh = (unsigned)__builtin_ctz(p.group), gmask = (1u << gsh) - 1u;
+  const unsigned ngroups = (nfr + gmask) >> gsh;
+  unsigned grp = blockIdx.x;
   if (grp >= ngroups) return;
-  size_t f = grp * G;
+  unsigned f = grp << gsh;
+  const bool dyn = p.work_ctr != nullptr;
+  unsigned fetched = ~0u;  // thread 0: the id the atomic in flight returns; ~0 = none asked for (the ragged last group)
+  unsigned* next_slot = reinterpret_cast<unsigned*>(lds + kNextO);
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN * 8);
@@ -260,14 +267,21 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     }
   };
 
-  size_t ring_f0 = f;
+  unsigned ring_f0 = f;
   int ring_n = 0;
 
   for (;;) {
-    size_t fnext = f + 1;
-    if ((fnext % G) == 0 || fnext >= nfr) {
-      grp += gridDim.x;
-      fnext = grp * G;
+    unsigned fnext = f + 1;
+    if ((fnext & gmask) == 0 || fnext >= nfr) {
+      if (dyn) {
+        if (j == 0) *next_slot = fetched;
+        fetched = ~0u;
+        __syncthreads();  // (the slot is next written a whole group later)
+        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)*next_slot);
+      } else {
+        grp += gridDim.x;
+      }
+      fnext = grp << gsh;
     }
     const bool has_next = grp < ngroups;
     int s1v = s1;
@@ -281,7 +295,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     }
     if (has_next) load_frame(fnext);
     __syncthreads();  // B1: image complete; the previous frame's pruned-pass reads of the tile are done
-    if (ring_n > 0 && (f % G) == 0) {  // a new group starts: drain the last one
+    if (ring_n > 0 && (f & gmask) == 0) {  // a new group starts: drain the last one
       if (wave == 0) finalise(ring_f0, ring_n);
       ring_f0 = f;
       ring_n = 0;
@@ -313,6 +327,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
       for (int u = 0; u < 16; u++) lds_st(tile, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
     }
     __syncthreads();  // B2: filtered frame in the tile; every window read of the image is done
+    if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
 
     // ---- stage 2: (I + jQ) * down_chirp * hann, FFT pass 1 -------------------------------
     // Base band: two dechirp runs (conj(up), conj(down)) over the SAME filtered frame.  Run 0 keeps the
@@ -450,13 +465,20 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   float* tab1l = lds + (BB ? kTab1Off + kGrow : 0);
   const int j = threadIdx.x;  // = lane
 
-  // frames are dealt in groups of G consecutive frames, round robin over the workgroups
-  const size_t nfr = p.n_frames;
-  const size_t G = p.group;
-  const size_t ngroups = (nfr + G - 1) / G;
-  size_t grp = blockIdx.x;
+  // frames are dealt in groups of G = 2^gsh consecutive frames (32-bit bookkeeping: the host rejects batches of 2^31
+  // frames or more; the frame ADDRESS is 64-bit).  Static deal: round robin over the workgroups.
+  // Dynamic hand-out (p.work_ctr, G >= 2): the workgroups do not run at the same speed, so after its first group a
+  // workgroup takes the next free one from an atomic counter.  The request goes out behind the FIR of a group's
+  // second-to-last frame -- where the register file has room for the returning id -- and is read at the top of the
+  // last frame, behind loads that are waited for there anyway.
+  const unsigned nfr = (unsigned)p.n_frames;
+  const unsigned gsh = (unsigned)__builtin_ctz(p.group), gmask = (1u << gsh) - 1u;
+  const unsigned ngroups = (nfr + gmask) >> gsh;
+  unsigned grp = blockIdx.x;
   if (grp >= ngroups) return;
-  size_t f = grp * G;
+  unsigned f = grp << gsh;
+  const bool dyn = p.work_ctr != nullptr;
+  unsigned fetched = ~0u;  // lane 0: the group id the atomic in flight returns; ~0 = none asked for (the ragged last group)
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN1 * 8);
   const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN1 * 8);
@@ -583,7 +605,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
     }
   };
 
-  size_t ring_f0 = f;
+  unsigned ring_f0 = f;
   int ring_n = 0;
 
   if (FIRM) {
@@ -598,10 +620,15 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   }
 
   for (;;) {
-    size_t fnext = f + 1;
-    if ((fnext % G) == 0 || fnext >= nfr) {
-      grp += gridDim.x;
-      fnext = grp * G;
+    unsigned fnext = f + 1;
+    if ((fnext & gmask) == 0 || fnext >= nfr) {
+      if (dyn) {
+        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)fetched);
+        fetched = ~0u;
+      } else {
+        grp += gridDim.x;
+      }
+      fnext = grp << gsh;
     }
     const bool has_next = grp < ngroups;
     int s1v = s1;
@@ -667,7 +694,8 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
         pk_tap8x2(accB, &w[8 + kHalo - k - 1], taps[k >> 1], taps[(k >> 1) + 1]);
     }
     __syncthreads();
-    if (ring_n > 0 && (f % G) == 0) {  // a new group starts: drain the last one
+    if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
+    if (ring_n > 0 && (f & gmask) == 0) {  // a new group starts: drain the last one
       finalise(ring_f0, ring_n);
       ring_f0 = f;
       ring_n = 0;

@@ -87,6 +87,8 @@ struct IqParams {
   uint32_t baseband;
   uint32_t ifs;               // (uint32_t)(int32_t)fs for the receiver's integer idx2freq
   float snr_threshold;
+  unsigned int* work_ctr;     // device word, zero at launch: groups beyond a workgroup's first are handed out
+                              // dynamically, group id = gridDim.x + the value an atomic increment returns; nullptr = static deal
 };
 // n = 2048 (the committed firmware) or 1024 (one wave per frame)
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
