@@ -176,6 +176,34 @@ def test_stream_edge_sizes(uchirp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("decim", [4, 8, 16])
+def test_stream_block_chunks_dynamic_hand_out(uchirp, decim, monkeypatch):
+    """The stream kernel deals overlap-save blocks in chunks of consecutive blocks; a workgroup's first chunk is fixed,
+    every further one comes from an atomic counter asked one block ahead (csrc/uc_stream_kernel.hip).  Tiny grids
+    (UC_GRID), chunk sizes 1 / 2 / 4 / 8 (UC_STREAM_CHUNK), the static partition (UC_STATIC_DEAL) and stream lengths
+    around the chunk boundaries must give the same bytes as the default launch."""
+    ref = uchirp.Engine(uchirp.STREAM, decim=decim)
+    halo, _, _, hop = ref.stream_geometry(0)
+    rng = np.random.default_rng(77)
+    x = (1000.0 * rng.standard_normal(halo + decim * (41 * hop + 13))).astype(np.float32)
+    for env in ({"UC_GRID": "1", "UC_STREAM_CHUNK": "1"}, {"UC_GRID": "2", "UC_STREAM_CHUNK": "2"},
+                {"UC_GRID": "3", "UC_STREAM_CHUNK": "4"}, {"UC_GRID": "1", "UC_STREAM_CHUNK": "8"},
+                {"UC_GRID": "2", "UC_STREAM_CHUNK": "1"}, {"UC_GRID": "3", "UC_STATIC_DEAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = uchirp.Engine(uchirp.STREAM, decim=decim)
+        for k in env:
+            monkeypatch.delenv(k)
+        for blocks in (42, 41, 40, 33, 32, 31, 17, 16, 9, 8, 5, 4, 3, 2, 1):
+            n = halo + decim * ((blocks - 1) * hop + 13)
+            c0, p0 = ref.process_stream(x[:n])
+            c1, p1 = e.process_stream(x[:n])
+            assert len(p0) == blocks
+            assert np.array_equal(c0.view(np.uint32), c1.view(np.uint32)), (env, blocks)
+            assert np.array_equal(p0, p1), (env, blocks)
+
+
+@pytest.mark.gpu
 def test_stream_up_template_flag(uchirp):
     o = uco.Oracle(uco.STREAM, flags=uco.FLAG_STREAM_UP)
     e = uchirp.Engine(uchirp.STREAM, flags=uchirp.FLAG_STREAM_UP)

@@ -1,5 +1,5 @@
 # usage: res.sh file.hip [filter]
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -load-store-opt -I../include -Icsrc -Rpass-analysis=kernel-resource-usage -c $1 -o /dev/null 2>&1 | python3 -c "
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -Xclang -target-feature -Xclang -load-store-opt -mllvm -amdgpu-atomic-optimizer-strategy=None -I../include -Icsrc -Rpass-analysis=kernel-resource-usage -c $1 -o /dev/null 2>&1 | python3 -c "
 import sys,re
 cur=None;d={}
 for l in sys.stdin:

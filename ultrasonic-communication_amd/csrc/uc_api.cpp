@@ -105,6 +105,7 @@ struct uc_ctx {
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
   bool cic_tickets = false;
+  int stream_chunk = 2;     // (env UC_STREAM_CHUNK) blocks per hand-out chunk of the stream kernel: a power of two
   int iq_group = 32;        // (env UC_IQ_GROUP) frames per hand-out group of the IQ kernels: a power of two <= 64
   unsigned iq_stagger = 0;  // (env UC_IQ_STAGGER, MFMA FIR only) start delay of every second wave on a SIMD, x 4096 clocks
   // UC_IQ at n = 1024, env UC_IQ_FIR=mfma: the FIR as v_mfma_f32_16x16x4_f32 Toeplitz tiles instead of packed VALU.
@@ -209,6 +210,10 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
   if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
   if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
+  if (const char* g = getenv("UC_STREAM_CHUNK")) {
+    const int v = atoi(g);
+    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->stream_chunk = v;
+  }
   if (const char* g = getenv("UC_IQ_GROUP")) {
     const int v = atoi(g);
     if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->iq_group = v;
@@ -421,6 +426,20 @@ int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
   return (int32_t)((ifs * (n - idx) / n) * 0xFFFFFFFFu);
 }
 
+// The counter of one dynamically dealt launch: a slot of the context's ring, zeroed on `stream` right before the
+// launch.  nullptr (static deal) while `stream` is being captured into a graph: a replayed graph would keep using the
+// slot it was captured with, next to whatever eager launch the ring hands the same slot to later.
+static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out) {
+  *out = nullptr;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;
+  unsigned int* w = (unsigned int*)((char*)c->d_work + (size_t)(c->work_next++ % kWorkSlots) * kWorkStride);
+  const hipError_t e = hipMemsetAsync(w, 0, sizeof(unsigned int), stream);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(work counter)");
+  *out = w;
+  return 0;
+}
+
 static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                               const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream);
 
@@ -532,10 +551,9 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     ip.work_ctr = nullptr;
     if (!c->static_deal && ip.group >= 2) {
       const size_t ngroups = (n_frames + ip.group - 1) / ip.group;
-      if (ngroups > grid) {  // dynamic hand-out: this launch's counter is zeroed on the stream right before it
-        ip.work_ctr = (unsigned int*)((char*)c->d_work + (size_t)(c->work_next++ % kWorkSlots) * kWorkStride);
-        e = hipMemsetAsync(ip.work_ctr, 0, sizeof(unsigned int), stream);
-        if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(work counter)");
+      if (ngroups > grid) {  // dynamic hand-out
+        const int wrc = take_work_counter(c, stream, &ip.work_ctr);
+        if (wrc) return wrc;
       }
     }
     int lrc = uc::launch_iq(dtype, ip, (int)grid, stream, (int)n);
@@ -606,10 +624,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   while ((1u << p.group_log2) < group) p.group_log2++;
   p.work_ctr = nullptr;
   if (!c->static_deal && group >= 2 && ngroups > grid) {
-    // dynamic hand-out: the counter of this launch is zeroed on the stream right before it
-    p.work_ctr = (unsigned int*)((char*)c->d_work + (size_t)(c->work_next++ % kWorkSlots) * kWorkStride);
-    e = hipMemsetAsync(p.work_ctr, 0, sizeof(unsigned int), stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(work counter)");
+    const int wrc = take_work_counter(c, stream, &p.work_ctr);  // dynamic hand-out
+    if (wrc) return wrc;
   }
   int lrc = uc::launch_band(mode, dtype, c->band_waves, p, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
@@ -790,6 +806,19 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
   size_t grid = (size_t)c->num_cu * (size_t)st_bpc;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   if (grid > n_blocks) grid = n_blocks;
+  if (n_blocks >= ((size_t)1 << 32)) return fail(-EINVAL, "uc_process_stream: at most 2^32 - 1 blocks per call");
+  sp.work_ctr = nullptr;
+  sp.chunk_log2 = 0;
+  if (!c->static_deal && n_blocks > (size_t)c->stream_chunk * grid) {  // more chunks than workgroups
+    // dynamic hand-out of chunks of consecutive blocks
+    const int wrc = take_work_counter(c, stream, &sp.work_ctr);
+    if (wrc) return wrc;
+    if (sp.work_ctr) {
+      while ((1u << sp.chunk_log2) < (unsigned)c->stream_chunk) sp.chunk_log2++;
+      const size_t nchunks = (n_blocks + ((size_t)1 << sp.chunk_log2) - 1) >> sp.chunk_log2;
+      if (grid > nchunks) grid = nchunks;
+    }
+  }
   int lrc = uc::launch_stream(dtype, D, sp, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "stream kernel launch");
 

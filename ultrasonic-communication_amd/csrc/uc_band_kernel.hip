@@ -316,7 +316,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // thread 0: the group id an in-flight atomic returns.  It is parked in LDS in the first frame of every group
   // (the frame after the one that issued it), once that frame's loads -- older than the atomic -- are consumed.
   unsigned fetched = 0;
-  if (dyn && j == 0) fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
+  if (dyn && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is READ: nothing may wait for it here)
 
   // ---- per-thread constants, resident for the whole batch -----------------
   const __amdgpu_buffer_rsrc_t rs_tab0 = make_rsrc(p.tab0, kN * 8);
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           if (j == 0) *next_slot = fetched;
           __syncthreads();
         }
-        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)*next_slot);
+        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)*next_slot) + gridDim.x;
       } else {
         grp += gridDim.x;
       }
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     if (!has_next) break;
     if (dyn && (fnext & gmask) == 0 && j == 0) {
       // a new group was taken: ask for the one after it.  Issued here, where few registers are live.
-      fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
+      fetched = atomicAdd(p.work_ctr, 1u);
     }
     f = fnext;
   }

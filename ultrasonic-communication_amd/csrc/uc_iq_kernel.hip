@@ -30,6 +30,9 @@ namespace uc {
 
 namespace {
 
+// "no group asked for": stays beyond every group count when gridDim.x is added (batches hold fewer than 2^31 frames)
+constexpr unsigned kNoGroup = 0x7fffffffu;
+
 constexpr int T = kBandThreads;          // 128
 constexpr int kHalo = 26;                // FIR taps - 1
 constexpr int kMixLen = kN + kHalo;      // 2074 mixed samples
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   if (grp >= ngroups) return;
   unsigned f = grp << gsh;
   const bool dyn = p.work_ctr != nullptr;
-  unsigned fetched = ~0u;  // thread 0: the id the atomic in flight returns; ~0 = none asked for (the ragged last group)
+  unsigned fetched = kNoGroup;  // thread 0: what the atomic in flight returns; kNoGroup = none asked for (the ragged last group)
   unsigned* next_slot = reinterpret_cast<unsigned*>(lds + kNextO);
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN * 8);
@@ -275,9 +278,9 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     if ((fnext & gmask) == 0 || fnext >= nfr) {
       if (dyn) {
         if (j == 0) *next_slot = fetched;
-        fetched = ~0u;
+        fetched = kNoGroup;
         __syncthreads();  // (the slot is next written a whole group later)
-        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)*next_slot);
+        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)*next_slot) + gridDim.x;
       } else {
         grp += gridDim.x;
       }
@@ -327,7 +330,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
       for (int u = 0; u < 16; u++) lds_st(tile, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
     }
     __syncthreads();  // B2: filtered frame in the tile; every window read of the image is done
-    if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
+    if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is read)
 
     // ---- stage 2: (I + jQ) * down_chirp * hann, FFT pass 1 -------------------------------
     // Base band: two dechirp runs (conj(up), conj(down)) over the SAME filtered frame.  Run 0 keeps the
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   if (grp >= ngroups) return;
   unsigned f = grp << gsh;
   const bool dyn = p.work_ctr != nullptr;
-  unsigned fetched = ~0u;  // lane 0: the group id the atomic in flight returns; ~0 = none asked for (the ragged last group)
+  unsigned fetched = kNoGroup;  // lane 0: what the atomic in flight returns; kNoGroup = none asked for (the ragged last group)
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN1 * 8);
   const __amdgpu_buffer_rsrc_t rs_ch = make_rsrc(p.chirp_hann, kN1 * 8);
@@ -623,8 +626,8 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
     unsigned fnext = f + 1;
     if ((fnext & gmask) == 0 || fnext >= nfr) {
       if (dyn) {
-        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)fetched);
-        fetched = ~0u;
+        grp = (unsigned)__builtin_amdgcn_readfirstlane((int)fetched) + gridDim.x;
+        fetched = kNoGroup;
       } else {
         grp += gridDim.x;
       }
@@ -694,7 +697,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
         pk_tap8x2(accB, &w[8 + kHalo - k - 1], taps[k >> 1], taps[(k >> 1) + 1]);
     }
     __syncthreads();
-    if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u) + gridDim.x;
+    if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is read)
     if (ring_n > 0 && (f & gmask) == 0) {  // a new group starts: drain the last one
       finalise(ring_f0, ring_n);
       ring_f0 = f;

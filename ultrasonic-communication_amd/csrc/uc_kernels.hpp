@@ -107,6 +107,9 @@ struct StreamParams {
   uc_peak* peaks;        // device or nullptr
   float ctap[2 * kFirTapsDev];  // fir[k] e^{+j 2 pi carrier k / fs}, (re, im)
   float rots[16];               // rot[s * 4096 / D], s < D/2: rotation of sub-tile s, (re, im)
+  unsigned int* work_ctr;       // device word, zero at launch: chunks of 2^chunk_log2 consecutive blocks, the ones after a
+  uint32_t chunk_log2;          // workgroup's first handed out by atomic increments; nullptr = a
+                                // balanced contiguous partition of the blocks
 };
 int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream);
 int stream_max_blocks_per_cu(int dtype, int decim);

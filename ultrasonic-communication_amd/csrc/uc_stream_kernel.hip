@@ -82,12 +82,36 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   const int j = threadIdx.x;
   const int wave = j >> 6;
 
-  // balanced contiguous partition of the blocks: workgroup w takes base (+1 for the first `rem`) blocks
-  const size_t base = p.n_blocks / gridDim.x, rem = p.n_blocks % gridDim.x;
-  const size_t w_ = blockIdx.x;
-  size_t b = w_ * base + (w_ < rem ? w_ : rem);
-  const size_t bend = b + base + (w_ < rem ? 1 : 0);
-  if (b >= bend) return;
+  // Static: a balanced contiguous partition of the blocks, workgroup w takes base (+1 for the first `rem`) blocks.
+  // Dynamic (p.work_ctr): chunks of G = 2^chunk_log2 consecutive blocks; a workgroup starts with chunk blockIdx.x and
+  // takes every further one from an atomic counter -- the workgroups do not run at the same speed.  Thread 0 asks one
+  // block before a chunk's last block (right before a batch of input loads, which are waited for two sub-tiles
+  // later) and hands the id to the workgroup through one LDS word at the top of the chunk's last block.
+  // (32-bit block bookkeeping: the host rejects streams of 2^32 blocks; sample offsets are 64-bit)
+  const unsigned nblk = (unsigned)p.n_blocks;
+#ifdef UC_STREAM_NO_DYN  // (A/B build: the hand-out code compiled out)
+  constexpr bool dyn = false;
+#else
+  const bool dyn = p.work_ctr != nullptr;
+#endif
+  const unsigned gsh = p.chunk_log2, gmask = (1u << gsh) - 1u;
+  const unsigned nchunks = (nblk + gmask) >> gsh;
+  unsigned b, bend;
+  if (dyn) {
+    if (blockIdx.x >= nchunks) return;
+    b = blockIdx.x << gsh;
+    bend = b + gmask + 1u < nblk ? b + gmask + 1u : nblk;
+  } else {
+    const unsigned base = nblk / gridDim.x, rem = nblk % gridDim.x;
+    const unsigned w_ = blockIdx.x;
+    b = w_ * base + (w_ < rem ? w_ : rem);
+    bend = b + base + (w_ < rem ? 1u : 0u);
+    if (b >= bend) return;
+  }
+  constexpr unsigned kNoChunk = 0x7fffffffu;  // stays beyond every chunk count when gridDim.x is added
+  unsigned fetched = kNoChunk;  // thread 0: what the atomic in flight returns; kNoChunk = none asked for (ragged last chunk)
+  // (chunks of ONE block: every block asks for the one after its successor, so the first request goes out here)
+  if (dyn && gsh == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);
 
   const __amdgpu_buffer_rsrc_t rs_hn = make_rsrc(p.hn, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
@@ -121,8 +145,8 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   // buffer, and the tail load of threads >= 7, fall outside the resource and return 0.
   // Two register sets: the loads run TWO sub-tiles ahead of the FIR (and through the transforms).
   v4u stg[2][9];
-  auto issue_loads = [&](size_t blk, int sub, v4u (&dst)[9]) {
-    const size_t first = blk * (size_t)(HOP * D) + (size_t)sub * kSubIn;
+  auto issue_loads = [&](unsigned blk, int sub, v4u (&dst)[9]) {
+    const size_t first = (size_t)blk * (size_t)(HOP * D) + (size_t)sub * kSubIn;
     const size_t left = p.n_samples > first ? p.n_samples - first : 0;
     const int recs = left < (size_t)(kSubIn + 28) ? (int)left : kSubIn + 28;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.samples) + first * 4, recs * 4);
@@ -140,14 +164,27 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     int s1v = xa.s1;
     v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
     asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
-    const size_t bn = b + 1;
-    const bool more = bn < bend;
+    unsigned bn = b + 1;
+    bool more = bn < bend;
+    // last block of a chunk: the next block is the first of the chunk the hand-out gave (known behind the barrier below)
+    const bool hop = dyn && !more;
+    if (hop && j == 0) red[8] = __uint_as_float(fetched);
+    if (hop) fetched = kNoChunk;
 
     // ---- front end: FIR + decimation, sub-tile by sub-tile, into the FFT tile ----------------
 #pragma unroll
     for (int s = 0; s < NSUB; s++) {
       v4u (&cur)[9] = stg[s & 1];
       __syncthreads();  // the windows of the previous sub-tile (and the previous block's transforms) are read
+      if (s == 0) {
+        if (hop) {
+          const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(red[8])) + gridDim.x;
+          more = c < nchunks;
+          bn = c << gsh;
+        }
+        // one block before a chunk's last block: ask for the next chunk, ahead of the loads issued below
+        if (dyn && ((b + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is read)
+      }
 #pragma unroll
       for (int r = 0; r < 8; r++) {
         const int q = j + T * r;  // float4 index inside the sub-tile
@@ -220,7 +257,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     xf_invC<false>(tile, y16, xa, y16, t3a, t3b, t3c, K, H);
 
     // ---- |y[i]|, i = j + 128 t; outputs i >= L-1 are free of circular wrap-around ---------------------
-    const size_t q0 = b * (size_t)HOP;                       // first output of this block
+    const size_t q0 = (size_t)b * (size_t)HOP;               // first output of this block
     const size_t room = p.n_out - q0;                        // > 0
     const int valid = room < (size_t)HOP ? (int)room : HOP;  // outputs of this block that exist
     // Branch-free: the stores go through a buffer resource that covers exactly this block's `valid`
@@ -261,6 +298,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     }
     if (!more) break;
     b = bn;
+    if (hop) bend = b + gmask + 1u < nblk ? b + gmask + 1u : nblk;
   }
 }
 
