@@ -721,6 +721,31 @@ def test_unsupported_configurations_fail_loudly(uchirp):
         e.receive(np.zeros(4096, np.float32))               # no up/down state machine for this variant
 
 
+def test_compress_pair_chunks_dynamic_hand_out(uchirp, monkeypatch):
+    """The compress kernel deals frame PAIRS in chunks of consecutive pairs; a workgroup's first chunk is fixed, every
+    further one comes from an atomic counter asked one pair ahead (csrc/uc_full_kernel.hip).  Tiny grids (UC_GRID),
+    chunk sizes (UC_COMPRESS_CHUNK), the static partition (UC_STATIC_DEAL) and frame counts around the chunk
+    boundaries -- odd counts end in a half-empty pair -- must give the same bytes as the default launch."""
+    rng = np.random.default_rng(91)
+    up = uco.Oracle(uco.COMPRESS, mag_mean=1.0).table(uco.TABLE_UP).astype(np.float64)
+    n_frames = 300
+    frames = np.stack([np.roll(up, s) * 1000.0 for s in rng.integers(0, 2048, size=n_frames)])
+    frames = (frames + 300.0 * rng.standard_normal(frames.shape)).astype(np.float32)
+    mm = (np.arange(2 * n_frames, dtype=np.float32) % 5.0) + 1.0
+    ref = uchirp.Engine(uchirp.COMPRESS, mag_mean=1.0)
+    for env in ({"UC_GRID": "1", "UC_COMPRESS_CHUNK": "2"}, {"UC_GRID": "2", "UC_COMPRESS_CHUNK": "4"},
+                {"UC_GRID": "3"}, {"UC_GRID": "1", "UC_COMPRESS_CHUNK": "16"}, {"UC_GRID": "3", "UC_STATIC_DEAL": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        e = uchirp.Engine(uchirp.COMPRESS, mag_mean=1.0)
+        for k in env:
+            monkeypatch.delenv(k)
+        for cnt in (300, 299, 1, 2, 3, 4, 5, 7, 8, 9, 15, 16, 17, 31, 32, 33, 63, 64, 65, 129, 257):
+            _, st0 = ref.process(frames[:cnt], mag_mean=mm[:2 * cnt])
+            _, st1 = e.process(frames[:cnt], mag_mean=mm[:2 * cnt])
+            assert np.array_equal(st0.view(np.uint32), st1.view(np.uint32)), (env, cnt)
+
+
 @pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX, uco.DECHIRP_DOWN])
 def test_band_frame_groups_dynamic_hand_out(uchirp, variant, monkeypatch):
     """The band kernel deals frames in groups; a workgroup's first group is fixed, every further one comes from an

@@ -105,6 +105,7 @@ struct uc_ctx {
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
   bool cic_tickets = false;
+  int compress_chunk = 8;   // (env UC_COMPRESS_CHUNK) frame pairs per hand-out chunk of the compress kernel: a power of two >= 2
   int stream_chunk = 2;     // (env UC_STREAM_CHUNK) blocks per hand-out chunk of the stream kernel: a power of two
   int iq_group = 32;        // (env UC_IQ_GROUP) frames per hand-out group of the IQ kernels: a power of two <= 64
   unsigned iq_stagger = 0;  // (env UC_IQ_STAGGER, MFMA FIR only) start delay of every second wave on a SIMD, x 4096 clocks
@@ -210,6 +211,10 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
   if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
   if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
+  if (const char* g = getenv("UC_COMPRESS_CHUNK")) {
+    const int v = atoi(g);
+    if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->compress_chunk = v;
+  }
   if (const char* g = getenv("UC_STREAM_CHUNK")) {
     const int v = atoi(g);
     if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->stream_chunk = v;
@@ -579,6 +584,17 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     const size_t npairs = (n_frames + 1) / 2;
     if (grid > npairs) grid = npairs;
+    fp.work_ctr = nullptr;
+    fp.chunk_log2 = 0;
+    if (!c->static_deal && c->compress_chunk >= 2 && npairs > (size_t)c->compress_chunk * grid) {  // more chunks than workgroups
+      const int wrc = take_work_counter(c, stream, &fp.work_ctr);  // dynamic hand-out of chunks of consecutive pairs
+      if (wrc) return wrc;
+      if (fp.work_ctr) {
+        while ((1u << fp.chunk_log2) < (unsigned)c->compress_chunk) fp.chunk_log2++;
+        const size_t nchunks = (npairs + ((size_t)1 << fp.chunk_log2) - 1) >> fp.chunk_log2;
+        if (grid > nchunks) grid = nchunks;
+      }
+    }
     int lrc = uc::launch_compress(dtype, fp, (int)grid, stream);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "compress kernel launch");
     goto copy_back;

@@ -109,13 +109,29 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   const int lane = j & 63;
   const int wave = j >> 6;
 
-  const size_t npairs = (p.n_frames + 1) / 2;
-  // balanced contiguous partition of the pairs
-  const size_t base = npairs / gridDim.x, rem = npairs % gridDim.x;
-  const size_t w_ = blockIdx.x;
-  size_t q = w_ * base + (w_ < rem ? w_ : rem);
-  const size_t qend = q + base + (w_ < rem ? 1 : 0);
-  if (q >= qend) return;
+  // Static: a balanced contiguous partition of the frame pairs.  Dynamic (p.work_ctr): chunks of G = 2^chunk_log2
+  // consecutive pairs; a workgroup starts with chunk blockIdx.x and takes every further one from an atomic counter
+  // (the workgroups do not run at the same speed).  Thread 0 asks one pair before a chunk's last pair, right before
+  // that pair's prefetch, and hands the id to the workgroup through one LDS word at the top of the chunk's last pair.
+  // (32-bit bookkeeping: the host rejects batches of 2^31 frames or more; the frame ADDRESS is 64-bit)
+  const unsigned npairs = (unsigned)((p.n_frames + 1) / 2);
+  const bool dyn = p.work_ctr != nullptr;
+  const unsigned gsh = p.chunk_log2, gmask = (1u << gsh) - 1u;
+  const unsigned nchunks = (npairs + gmask) >> gsh;
+  unsigned q, qend;
+  if (dyn) {
+    if (blockIdx.x >= nchunks) return;
+    q = blockIdx.x << gsh;
+    qend = q + gmask + 1u < npairs ? q + gmask + 1u : npairs;
+  } else {
+    const unsigned base = npairs / gridDim.x, rem = npairs % gridDim.x;
+    const unsigned w_ = blockIdx.x;
+    q = w_ * base + (w_ < rem ? w_ : rem);
+    qend = q + base + (w_ < rem ? 1u : 0u);
+    if (q >= qend) return;
+  }
+  constexpr unsigned kNoChunk = 0x7fffffffu;  // stays beyond every chunk count when gridDim.x is added
+  unsigned fetched = kNoChunk;  // thread 0: what the atomic in flight returns; kNoChunk = none asked for (ragged last chunk)
 
   const __amdgpu_buffer_rsrc_t rs_hn = make_rsrc(p.hn, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_tw = make_rsrc(p.tw, kN * 8);
@@ -153,7 +169,8 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
 
   // raw words of the pair: sample j + 128 t of frame 2q in the low, of frame 2q+1 in the high half
   v2f xp[16];
-  auto load_pair = [&](size_t u) {
+  auto load_pair = [&](unsigned uq) {
+    const size_t u = uq;
     const bool hb = 2 * u + 1 < p.n_frames;  // a ragged last pair: frame b reads as zeros
     const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u) * p.stride * 4, kN * 4);
     const __amdgpu_buffer_rsrc_t rb =
@@ -164,7 +181,8 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   load_pair(q);
 
   // result of one pair: merged by thread 0/1 after the NEXT barrier (red is rewritten three barriers later)
-  auto publish = [&](size_t qq) {
+  auto publish = [&](unsigned qu) {
+    const size_t qq = qu;
     const bool hb = 2 * qq + 1 < p.n_frames;
     if (j < 2 && (j == 0 || hb) && p.stats) {
       // merge the two waves: value, then smallest index; a NaN partial only survives
@@ -189,7 +207,14 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   };
 
   bool pending = false;
-  for (; q < qend; q++) {
+  unsigned qprev = q;
+  for (;;) {
+    unsigned qn = q + 1;
+    bool more = qn < qend;
+    // last pair of a chunk: the next pair is the first of the chunk the hand-out gave (known behind the barrier below)
+    const bool hop = dyn && !more;
+    if (hop && j == 0) red[8] = __uint_as_float(fetched);
+    if (hop) fetched = kNoChunk;
     int s1v = xa.s1;
     v2f t3a = tw3_1, t3b = tw3_2, t3c = tw3_4;
     asm volatile("" : "+v"(s1v), "+v"(t3a), "+v"(t3b), "+v"(t3c));
@@ -203,12 +228,22 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
         v[2 * m] = pk_scale_lo(cvt_pair<DTYPE>(xp[2 * m]), hw[m]);
         v[2 * m + 1] = pk_scale_hi(cvt_pair<DTYPE>(xp[2 * m + 1]), hw[m]);
       }
-      if (q + 1 < qend) load_pair(q + 1);  // a whole pair time ahead
+      if (!dyn && more) load_pair(qn);  // a whole pair time ahead
       pk_dft16(v, K, H);
       xf_store1(ta, xa, s1v, v);
     }
     __syncthreads();
-    if (pending) publish(q - 1);
+    if (dyn) {
+      if (hop) {
+        const unsigned c = (unsigned)__builtin_amdgcn_readfirstlane((int)__float_as_uint(red[8])) + gridDim.x;
+        more = c < nchunks;
+        qn = c << gsh;
+      }
+      // one pair before a chunk's last pair: ask for the next chunk, ahead of the prefetch issued below
+      if (((q + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is read)
+      if (more) load_pair(qn);
+    }
+    if (pending) publish(qprev);
 
     xf_fwd2(ta, tb, tw2t, xa, j, K, H);                        // forward pass 2 (A -> B)
     __syncthreads();
@@ -231,9 +266,13 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
       red[4 * wave + 3] = __int_as_float(ib);
     }
     pending = true;
+    qprev = q;
+    if (!more) break;
+    q = qn;
+    if (hop) qend = q + gmask + 1u < npairs ? q + gmask + 1u : npairs;
   }
   __syncthreads();
-  if (pending) publish(qend - 1);
+  if (pending) publish(qprev);
 }
 
 }  // namespace

@@ -57,6 +57,9 @@ struct FullParams {
   uint8_t* symbols;       // device or nullptr (always UC_SYM_NONE)
   uc_stats* stats;        // device or nullptr, 1 per frame
   float mag_mean_scalar;
+  unsigned int* work_ctr;  // device word, zero at launch: chunks of 2^chunk_log2 consecutive frame pairs, the ones after a
+  uint32_t chunk_log2;     // workgroup's first handed out by atomic increments (chunk_log2 >= 1); nullptr = a balanced
+                           // contiguous partition of the pairs
 };
 int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream);
 int compress_max_blocks_per_cu(int dtype);
