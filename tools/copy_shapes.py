@@ -20,5 +20,18 @@ for name, shape, blocks in (("1024 thr x 2 in flight, 1 block/CU", 0, 256), ("10
                             ("256 x 2, 4/CU", 3, 1024), ("256 x 2, 8/CU", 3, 2048)):
     t = timed(lambda: L.hbm_probe_copy_shape(a.data_ptr(), b.data_ptr(), n, blocks, shape, st.cuda_stream))
     print("%-38s %.3f ms  %.0f GB/s" % (name, t, 2 * n / t / 1e6))
+L.hbm_probe_copy_tiles.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+for name, al in (("sinc5's tiles: 1008-byte stride, 1024 thr, 1/CU", 0), ("the same with 1024-byte tiles", 1)):
+    t = timed(lambda: L.hbm_probe_copy_tiles(a.data_ptr(), b.data_ptr(), n, 256, al, st.cuda_stream))
+    print("%-48s %.3f ms  %.0f GB/s" % (name, t, 2 * n / t / 1e6))
+L.hbm_probe_copy_runs.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_void_p]
+for run in (2, 4, 8, 16, 64, 256):
+    t = timed(lambda: L.hbm_probe_copy_runs(a.data_ptr(), b.data_ptr(), n, 256, run, st.cuda_stream))
+    print("%-48s %.3f ms  %.0f GB/s" % ("1024-byte tiles, runs of %d per wave" % run, t, 2 * n / t / 1e6))
+for run in (8, 16):
+    t = timed(lambda: L.hbm_probe_copy_runs(a.data_ptr() + 16, b.data_ptr(), n - 1024, 256, run, st.cuda_stream))
+    print("%-48s %.3f ms  %.0f GB/s" % ("runs of %d, loads 16 bytes off the line grid" % run, t, 2 * n / t / 1e6))
+    t = timed(lambda: L.hbm_probe_copy_runs(a.data_ptr(), b.data_ptr() + 16, n - 1024, 256, run, st.cuda_stream))
+    print("%-48s %.3f ms  %.0f GB/s" % ("runs of %d, STORES 16 bytes off the line grid" % run, t, 2 * n / t / 1e6))
 t = timed(lambda: L.hbm_probe_copy(a.data_ptr(), b.data_ptr(), n, 2048, st.cuda_stream))
 print("%-38s %.3f ms  %.0f GB/s" % ("256 x 8, 8/CU (bench probe)", t, 2 * n / t / 1e6))
