@@ -721,6 +721,52 @@ def test_unsupported_configurations_fail_loudly(uchirp):
         e.receive(np.zeros(4096, np.float32))               # no up/down state machine for this variant
 
 
+@pytest.mark.parametrize("variant", ["rx_real", "iq1024", "compress"])
+def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch):
+    """uc_process_batch captured ONCE into a hipGraph and replayed over new frames in the same buffers gives the eager
+    launch's bytes.  (While a stream is being captured the launch uses the static deal: a replayed graph would keep the
+    hand-out counter it was captured with.)  A tiny grid makes the eager launches of the same context use the dynamic
+    hand-out in between, on the same counter ring."""
+    import torch
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("UC_GRID", "3")
+    if variant == "rx_real":
+        e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+        batches = [synth.make_frames(300, seed=60 + k, snr_db=-5.0)[0].reshape(-1) for k in range(3)]
+        n_frames = 300
+    elif variant == "iq1024":
+        e = uchirp.Engine(uchirp.IQ, n=1024, mag_mean=1.0)
+        batches = [_iq_stream(150, seed=70 + k) for k in range(3)]
+        n_frames = (batches[0].size - 26) // 1024
+    else:
+        e = uchirp.Engine(uchirp.COMPRESS, mag_mean=1.0)
+        batches = [synth.make_frames(301, seed=80 + k, snr_db=0.0)[0].reshape(-1) for k in range(3)]
+        n_frames = 301
+    monkeypatch.delenv("UC_GRID")
+    buf = torch.zeros(batches[0].size, dtype=torch.float32, device=dev)
+    sym = torch.empty(n_frames, dtype=torch.uint8, device=dev)
+    st = torch.empty((n_frames, e.spf, 8), dtype=torch.float32, device=dev)
+    want = []
+    for b in batches:
+        buf.copy_(torch.from_numpy(b))
+        s0, st0 = e.process(buf, n_frames=n_frames)
+        torch.cuda.synchronize()
+        want.append((s0.cpu().numpy().copy(), st0.cpu().numpy().copy()))
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            e.process(buf, n_frames=n_frames, symbols_out=sym, stats_out=st, stream=s.cuda_stream)
+    for b, (s0, st0) in zip(batches, want):
+        buf.copy_(torch.from_numpy(b))
+        e.process(buf, n_frames=n_frames)          # an eager launch of the same context in between
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(sym.cpu().numpy(), s0)
+        assert np.array_equal(st.cpu().numpy().view(np.uint32), st0.view(np.uint32))
+
+
 def test_compress_pair_chunks_dynamic_hand_out(uchirp, monkeypatch):
     """The compress kernel deals frame PAIRS in chunks of consecutive pairs; a workgroup's first chunk is fixed, every
     further one comes from an atomic counter asked one pair ahead (csrc/uc_full_kernel.hip).  Tiny grids (UC_GRID),
