@@ -170,6 +170,8 @@ int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
  *            1 per frame otherwise; nullable.
  * UC_IQ reads 26 samples of FIR history in front of every frame: frames must
  * point 26 elements into the buffer (see uc_iq_halo()).
+ * With device pointers the call enqueues its work on hip_stream and returns; it may be captured into a
+ * hipGraph (all buffers device-resident) and replayed over new contents of the same buffers.
  */
 int uc_process_batch(uc_ctx* ctx, const void* frames, int dtype,
                      size_t n_frames, size_t stride_elems,
