@@ -647,6 +647,23 @@ def test_cpp_host_layer_runs_the_firmware_main_loop(uchirp, tmp_path):
     assert out.returncode == 1 and b"up/down history pair" in out.stderr
 
 
+def test_plain_c_host_through_the_c_abi(uchirp, tmp_path):
+    """tests/c/host_main.c: a C99 program (gcc -std=c99 -pedantic) that includes include/uchirp.h, links libuchirp.so
+    and runs the receiver's call sequence -- init once, one frame per call, then a batch -- on DFSDM words."""
+    import subprocess
+    exe = str(tmp_path / "host_main")
+    libdir = os.path.join(ROOT_DIR, "ultrasonic-communication_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-I" + os.path.join(ROOT_DIR, "include"),
+                           os.path.join(ROOT_DIR, "tests", "c", "host_main.c"), "-o", exe, "-L" + libdir, "-luchirp", "-lm",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, "9"], capture_output=True, timeout=300)
+    assert out.returncode == 0, out.stdout.decode() + out.stderr.decode()
+    lines = out.stdout.decode().splitlines()
+    assert lines[0].startswith("uc_abi_version 3 (header 3)")
+    assert lines[1].startswith("frame up  : symbol 1") and lines[2].startswith("frame down: symbol 0")
+    assert lines[3] == "batch: 0 1 0 1 0 1 0 1 0"
+
+
 def test_iq_variant_at_1024_points_one_wave_per_frame(uchirp):
     """BASELINE config 3 as worded: I/Q down-convert + 1024-point complex FFT (the README's intention
     for experiments/iq_modulation, README.md:64-68).  One wave per frame, no workgroup barrier."""
