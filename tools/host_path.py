@@ -26,3 +26,14 @@ for name, buf in (("pageable numpy", host), ("pinned (torch pin_memory)", pinned
         sym, _ = eng.process(buf, want_stats=False)
     dt = (time.perf_counter() - t0) / reps
     print("%-28s %8d frames  %7.2f ms  %.3e frames/s  %.1f GB/s of frames over PCIe" % (name, nf, dt * 1e3, nf / dt, nf * 8192 / dt / 1e9))
+
+# the reference's own granularity: ONE frame per call (uc_process_frame = one dsp() pair + decision, host in / host out)
+pcm = (np.round(frames[0]).astype(np.int64) * 256).astype(np.int32)
+for _ in range(50):
+    eng.process_frame(pcm, 1000.0)
+t0 = time.perf_counter()
+reps = 2000
+for _ in range(reps):
+    eng.process_frame(pcm, 1000.0)
+dt = (time.perf_counter() - t0) / reps
+print("uc_process_frame (host words in, symbol + 2 histories out, synchronous): %.1f us per call = %.0f frames/s" % (dt * 1e6, 1.0 / dt))

@@ -118,6 +118,7 @@ struct uc_ctx {
   unsigned int* d_cic_ctr = nullptr;  // sinc5: tile tickets, one word per workgroup x 4 launches
   size_t cic_ctr_cap = 0;
   unsigned int* d_work = nullptr;
+  void* h_slot = nullptr;  // uc_process_frame: pinned, device-mapped host memory for one frame and its results
   unsigned work_next = 0;
 };
 
@@ -361,6 +362,7 @@ void uc_destroy(uc_ctx* c) {
   if (c->d_tab2) (void)hipFree(c->d_tab2);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_work) (void)hipFree(c->d_work);
+  if (c->h_slot) (void)hipHostFree(c->h_slot);
   if (c->d_cic_ctr) (void)hipFree(c->d_cic_ctr);
   if (c->d_aux) (void)hipFree(c->d_aux);
   if (c->d_cic4) (void)hipFree(c->d_cic4);
@@ -446,7 +448,8 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out) 
 }
 
 static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
-                              const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream);
+                              const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream,
+                              bool mapped = false);
 
 int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                      const float* mag_mean, uint8_t* symbols, uc_stats* stats, void* hip_stream) {
@@ -454,8 +457,10 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
 }
 
 // d_magmax: device, (up, down) mag_max per frame, nullable (internal: uc_receive_stream)
+// mapped  : every pointer is device-accessible as it stands (internal: the pinned, mapped frame slot of uc_process_frame)
 static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
-                              const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream) {
+                              const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream,
+                              bool mapped) {
   if (!c) return fail(-EINVAL, "uc_process_batch: NULL ctx");
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32)
     return fail(-EINVAL, "uc_process_batch: dtype %d is neither UC_DTYPE_I32 nor UC_DTYPE_F32", dtype);
@@ -478,7 +483,7 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   bool any_host_out = false;
 
   const void* d_frames = frames;
-  if (!is_device_ptr(frames)) {
+  if (!mapped && !is_device_ptr(frames)) {
     int rc = c->s_frames.ensure(span * 4);
     if (rc) return rc;
     const char* src = (const char*)frames - (size_t)halo * 4;
@@ -487,7 +492,7 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     d_frames = (const char*)c->s_frames.p + (size_t)halo * 4;
   }
   const float* d_mm = mag_mean;
-  if (mag_mean && !is_device_ptr(mag_mean)) {
+  if (mag_mean && !mapped && !is_device_ptr(mag_mean)) {
     int rc = c->s_mm.ensure(n_frames * 2 * sizeof(float));
     if (rc) return rc;
     e = hipMemcpyAsync(c->s_mm.p, mag_mean, n_frames * 2 * sizeof(float), hipMemcpyHostToDevice, stream);
@@ -495,14 +500,14 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     d_mm = (const float*)c->s_mm.p;
   }
   uint8_t* d_sym = symbols;
-  if (symbols && !is_device_ptr(symbols)) {
+  if (symbols && !mapped && !is_device_ptr(symbols)) {
     int rc = c->s_sym.ensure(n_frames);
     if (rc) return rc;
     d_sym = (uint8_t*)c->s_sym.p;
     any_host_out = true;
   }
   uc_stats* d_stats = stats;
-  if (stats && !is_device_ptr(stats)) {
+  if (stats && !mapped && !is_device_ptr(stats)) {
     int rc = c->s_stats.ensure(n_frames * (size_t)spf * sizeof(uc_stats));
     if (rc) return rc;
     d_stats = (uc_stats*)c->s_stats.p;
@@ -856,14 +861,32 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
 int uc_process_frame(uc_ctx* c, const int32_t* pcm_in, float mag_mean, uint8_t* symbol_out, uc_stats st[2]) {
   if (!c || !pcm_in) return fail(-EINVAL, "uc_process_frame: NULL argument");
   if (uc_iq_halo(c)) return fail(-EINVAL, "uc_process_frame: UC_IQ needs FIR history, use uc_process_batch");
-  float mm[2] = {mag_mean, mag_mean};
-  uint8_t sym = UC_SYM_NONE;
-  uc_stats tmp[2];
-  memset(tmp, 0, sizeof(tmp));
-  int rc = uc_process_batch(c, pcm_in, UC_DTYPE_I32, 1, c->cfg.n, mm, &sym, tmp, nullptr);
+  if (c->cfg.variant == UC_STREAM) return fail(-EINVAL, "uc_process_frame: UC_STREAM has no frames, use uc_process_stream");
+  // One frame per call is the firmware's own granularity (dsp(), receiver/Src/main.c:183-231): no staging copies.
+  // The frame, the noise floors, the histories and the symbol live in ONE pinned host slot that the GPU reads and
+  // writes in place over PCIe (8 KiB in, 65 B out); the call is the host memcpy into the slot, one launch, one wait.
+  const size_t n = c->cfg.n;
+  const size_t off_mm = n * 4, off_st = off_mm + 64, off_sym = off_st + 2 * sizeof(uc_stats);
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  if (!c->h_slot) {
+    e = hipHostMalloc(&c->h_slot, off_sym + 64, hipHostMallocMapped);
+    if (e != hipSuccess) { c->h_slot = nullptr; return hip_fail(e, "hipHostMalloc(frame slot)"); }
+  }
+  char* slot = (char*)c->h_slot;
+  memcpy(slot, pcm_in, n * 4);
+  float* mm = (float*)(slot + off_mm);
+  mm[0] = mm[1] = mag_mean;
+  uc_stats* hs = (uc_stats*)(slot + off_st);
+  uint8_t* hsym = (uint8_t*)(slot + off_sym);
+  memset(hs, 0, 2 * sizeof(uc_stats));
+  *hsym = UC_SYM_NONE;
+  int rc = process_batch_impl(c, slot, UC_DTYPE_I32, 1, n, mm, hsym, hs, nullptr, nullptr, /*mapped=*/true);
   if (rc) return rc;
-  if (symbol_out) *symbol_out = sym;
-  if (st) memcpy(st, tmp, sizeof(uc_stats) * (size_t)uc_stats_per_frame(c));
+  e = hipStreamSynchronize(nullptr);
+  if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  if (symbol_out) *symbol_out = *hsym;
+  if (st) memcpy(st, hs, sizeof(uc_stats) * (size_t)uc_stats_per_frame(c));
   return 0;
 }
 
