@@ -2,7 +2,7 @@
 # Counter evidence for one round (every percentage DESIGN.md quotes must be recomputable from profiles/):
 #   - in-kernel shader clock of band_kernel under sustained load (tools/clock_probe.py, diagnostic build)
 #   - GRBM_GUI_ACTIVE and two SQ counter passes (--pmc with --kernel-trace only, one pass each) for
-#     band_kernel<rx_real>, iq1024_kernel, compress_kernel and sinc5_kernel
+#     band_kernel<rx_real>, iq1024_kernel, compress_kernel, stream_kernel and sinc5_kernel
 # usage (on the GPU box): bash tools/pmc_round.sh <tag>   -> gpurun_out/pmc_<tag>.json (+ clock_<tag>.json)
 tag="${1:-rXX}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
@@ -33,11 +33,12 @@ run_pass() {  # <name> <counters> <program args...>
   rm -rf $out/raw
   echo "pass $name: $( [ -n "$f" ] && echo ok || echo NO DATA )"
 }
-for target in ${PMC_TARGETS:-band iq1024 compress sinc5}; do
+for target in ${PMC_TARGETS:-band iq1024 compress stream sinc5}; do
   case $target in
     band)     export UC_VARIANT=0; unset UC_N; prog="tools/run_band.py 20 3" ;;
     iq1024)   export UC_VARIANT=4 UC_N=1024; prog="tools/run_band.py 20 3" ;;
     compress) export UC_VARIANT=2; unset UC_N; prog="tools/run_band.py 20 3" ;;
+    stream)   unset UC_VARIANT UC_N; prog="bench.py --variant stream --steps 5 --warmup 2" ;;
     sinc5)    unset UC_VARIANT UC_N; prog="tools/run_cic.py 28 3" ;;
   esac
   run_pass ${target}_sqa "$SQ_A" $prog

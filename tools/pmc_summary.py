@@ -10,7 +10,8 @@ import sys
 import collections
 
 src = sys.argv[1]
-KEY = {"band": "band_kernel", "iq1024": "iq1024_kernel", "compress": "compress_kernel", "sinc5": "sinc5_kernel"}
+KEY = {"band": "band_kernel", "iq1024": "iq1024_kernel", "compress": "compress_kernel", "stream": "stream_kernel",
+       "sinc5": "sinc5_kernel"}
 res = {}
 for target, key in KEY.items():
     ctr = collections.defaultdict(list)
