@@ -170,6 +170,9 @@ int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
  *            1 per frame otherwise; nullable.
  * UC_IQ reads 26 samples of FIR history in front of every frame: frames must
  * point 26 elements into the buffer (see uc_iq_halo()).
+ * UC_DECHIRP_DOWN and UC_COMPRESS (one real reference) transform frames 2u and 2u + 1 in ONE complex FFT: a
+ * frame's float32 round-off then scales with the larger frame of its pair (about 1e-7 of it), and a NaN / Inf
+ * sample makes the records of BOTH frames NaN.  Every other variant treats frames independently.
  * With device pointers the call enqueues its work on hip_stream and returns; it may be captured into a
  * hipGraph (all buffers device-resident) and replayed over new contents of the same buffers.
  */

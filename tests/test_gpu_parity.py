@@ -177,6 +177,62 @@ def test_edge_frames_zero_nan_inf_and_empty(uchirp):
         uchirp._check(uchirp.lib().uc_process_batch(e._h, z.ctypes.data, 7, 1, 0, None, None, None, None), "bad dtype")
 
 
+@pytest.mark.parametrize("name", ["sync_cplx", "dechirp_down", "compress", "iq", "iq1024"])
+def test_edge_frames_of_the_sibling_variants(uchirp, name):
+    """All-zero frames, an all-NaN frame and an ordinary frame next to each other, and an empty batch, through the
+    sibling kernels: the records are the oracle's (zero frame: every magnitude ties, the FIRST element of each
+    arm_max_f32 window wins; NaN frame: arm_max_f32 keeps its NaN first element, as '<' never replaces it).
+    DECHIRP_DOWN and COMPRESS transform frames (2u, 2u + 1) in ONE complex FFT (include/uchirp.h): there a frame's
+    float32 round-off scales with the LARGER frame of its pair, and a non-finite sample makes both records NaN --
+    the documented difference from the frame-by-frame firmware, asserted here as such."""
+    kw = {"sync_cplx": (uco.SYNC_CPLX, {}), "dechirp_down": (uco.DECHIRP_DOWN, dict(fs=100000.0, f0=17000.0, f1=18000.0)),
+          "compress": (uco.COMPRESS, {}), "iq": (uco.IQ, {}), "iq1024": (uco.IQ, {"n": 1024})}[name]
+    o = uco.Oracle(kw[0], mag_mean=1.0, **kw[1])
+    e = uchirp.Engine(kw[0], mag_mean=1.0, **kw[1])
+    n, halo = o.n, (26 if kw[0] == uco.IQ else 0)
+    paired = name in ("dechirp_down", "compress")
+    rng = np.random.default_rng(3)
+    # frames: 0 zero, 1 zero, 2 NaN, 3 zero, 4 ordinary, 5 zero  (pairs: (0,1) (2,3) (4,5))
+    x = np.zeros(halo + 6 * n, np.float32)
+    x[halo + 2 * n: halo + 3 * n] = np.nan
+    x[halo + 4 * n: halo + 5 * n] = (1000.0 * rng.standard_normal(n)).astype(np.float32)
+    if halo:
+        rs, rst = o.process(x, halo=halo, n_frames=6)
+        gs, gst = e.process(x, n_frames=6)
+    else:
+        rs, rst = o.process(x.reshape(6, n))
+        gs, gst = e.process(x.reshape(6, n))
+    loud = float(np.nanmax(np.abs(rst[4]["mag_max"].astype(np.float64))))
+
+    def same(f):
+        for h in range(o.spf):
+            for fld in ("mag_max", "mag_max_left", "mag_max_right", "snr"):
+                a, b = float(gst[f, h][fld]), float(rst[f, h][fld])
+                assert (np.isnan(a) and np.isnan(b)) or a == b, (f, h, fld, a, b)
+            for fld in ("max_freq", "max_freq_left", "max_freq_right"):
+                assert gst[f, h][fld] == rst[f, h][fld], (f, h, fld)
+        assert gs[f] == rs[f]
+
+    same(0)
+    same(1)
+    same(2)
+    for h in range(o.spf):      # the ordinary frame: within the float32 tolerance
+        for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+            assert abs(float(gst[4, h][fld]) - float(rst[4, h][fld])) <= MAG_TOL * loud, (h, fld)
+    if paired:
+        assert np.isnan(gst[3, 0]["mag_max"]) and rst[3, 0]["mag_max"] == 0.0      # rides with the NaN frame
+        assert abs(float(gst[5, 0]["mag_max"])) <= MAG_TOL * loud                    # rides with the loud frame
+    elif halo:
+        # (frame 3 starts with 26 NaN history samples in its FIR, frame 5 with 26 samples of the ordinary frame:
+        # neither is a zero frame)
+        assert abs(float(gst[5, 0]["mag_max"]) - float(rst[5, 0]["mag_max"])) <= MAG_TOL * loud
+    else:
+        same(3)
+        same(5)
+    s0, st0 = e.process(np.zeros(halo, np.float32) if halo else np.zeros((0, n), np.float32), n_frames=0)
+    assert s0.size == 0 and st0.size == 0
+
+
 def test_true_dc_flag_and_q2_default(uchirp):
     """Q2: default mag[0] = hypot(X0, X[n/2]) as the packed RFFT gives; the flag selects |X0|.
     Input = the up reference itself, amplitude-modulated at Nyquist, so that the
