@@ -98,6 +98,9 @@ enum {
                                          [n - bandwidth, n); signed idx2freq as the receiver's; two uc_stats per
                                          frame {up, down} and an up/down symbol, as RX_REAL / SYNC_CPLX.  The
                                          modulation is the notebook's (cell 4): x = A cos(2 pi (carrier - f_b(t)) t) */
+#define UC_FLAG_NO_FRAME_PAIRS (1u << 5) /* UC_DECHIRP_DOWN / UC_COMPRESS: one frame per transform instead of two
+                                         * (strict independence of the frames, at half the throughput: see
+                                         * uc_process_batch) */
 
 /* table ids for uc_get_table */
 enum {
@@ -172,7 +175,8 @@ int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
  * point 26 elements into the buffer (see uc_iq_halo()).
  * UC_DECHIRP_DOWN and UC_COMPRESS (one real reference) transform frames 2u and 2u + 1 in ONE complex FFT: a
  * frame's float32 round-off then scales with the larger frame of its pair (about 1e-7 of it), and a NaN / Inf
- * sample makes the records of BOTH frames NaN.  Every other variant treats frames independently.
+ * sample makes the records of BOTH frames NaN (UC_FLAG_NO_FRAME_PAIRS gives every frame its own transform).
+ * Every other variant treats frames independently.
  * With device pointers the call enqueues its work on hip_stream and returns; it may be captured into a
  * hipGraph (all buffers device-resident) and replayed over new contents of the same buffers.
  */

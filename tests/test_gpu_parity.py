@@ -231,6 +231,24 @@ def test_edge_frames_of_the_sibling_variants(uchirp, name):
         same(5)
     s0, st0 = e.process(np.zeros(halo, np.float32) if halo else np.zeros((0, n), np.float32), n_frames=0)
     assert s0.size == 0 and st0.size == 0
+    if paired:
+        # UC_FLAG_NO_FRAME_PAIRS: every frame gets its own transform -- strict independence, as the firmware
+        e1 = uchirp.Engine(kw[0], mag_mean=1.0, flags=uchirp.FLAG_NO_FRAME_PAIRS, **kw[1])
+        gs, gst = e1.process(x.reshape(6, n))
+        for f in (0, 1, 2, 3, 5):
+            same(f)
+        for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+            assert abs(float(gst[4, 0][fld]) - float(rst[4, 0][fld])) <= MAG_TOL * loud, fld
+        # ... and agrees with the paired launch on ordinary data, ragged counts included
+        fr = (1000.0 * rng.standard_normal((131, n))).astype(np.float32)
+        mm = rng.uniform(1.0, 9.0, size=(131, 2)).astype(np.float32)
+        for cnt in (131, 64, 3, 1):
+            _, a = e.process(fr[:cnt], mag_mean=mm[:cnt])
+            _, b = e1.process(fr[:cnt], mag_mean=mm[:cnt])
+            sc = np.abs(a[:, 0]["mag_max"].astype(np.float64)).max()
+            for fld in ("mag_max", "mag_max_left", "mag_max_right"):
+                assert (np.abs(a[:, 0][fld].astype(np.float64) - b[:, 0][fld]) / sc).max() <= MAG_TOL, (cnt, fld)
+            assert np.array_equal(a[:, 0]["mag_mean"], b[:, 0]["mag_mean"])
 
 
 def test_true_dc_flag_and_q2_default(uchirp):

@@ -587,7 +587,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     if (full_bpc == 0) full_bpc = uc::compress_max_blocks_per_cu(dtype);
     size_t grid = (size_t)c->num_cu * (size_t)full_bpc;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
-    const size_t npairs = (n_frames + 1) / 2;
+    fp.unpaired = (c->cfg.flags & UC_FLAG_NO_FRAME_PAIRS) ? 1u : 0u;
+    const size_t npairs = fp.unpaired ? n_frames : (n_frames + 1) / 2;  // units of work
     if (grid > npairs) grid = npairs;
     fp.work_ctr = nullptr;
     fp.chunk_log2 = 0;
@@ -635,7 +636,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   // units of work: frames, or frame pairs (DECHIRP_DOWN).  Groups of `band_group` units; smaller ones when the batch
   // would not give every workgroup a few (a small batch then still spreads over the whole chip)
-  const size_t units = (mode == uc::kModePair) ? (n_frames + 1) / 2 : n_frames;
+  p.unpaired = (mode == uc::kModePair && (c->cfg.flags & UC_FLAG_NO_FRAME_PAIRS)) ? 1u : 0u;
+  const size_t units = (mode == uc::kModePair && !p.unpaired) ? (n_frames + 1) / 2 : n_frames;
   uint32_t group = (uint32_t)c->band_group;
   if (c->band_waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
   while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;

@@ -305,7 +305,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   constexpr bool kPair = MODE == kModePair;
   constexpr bool kReal = MODE != kModeCplx;  // real reference(s): Hermitian split in the pruned pass
   // (32-bit bookkeeping: the host rejects batches of 2^31 frames or more; the frame ADDRESS is 64-bit)
-  const unsigned nfr = (unsigned)(kPair ? (p.n_frames + 1) / 2 : p.n_frames);
+  // (UC_FLAG_NO_FRAME_PAIRS: p.unpaired -- every frame rides alone, its partner slot reads as zeros)
+  const unsigned psh = (kPair && !p.unpaired) ? 1u : 0u;  // frames per unit = 1 << psh
+  const unsigned nfr = (unsigned)((p.n_frames + psh) >> psh);
   const unsigned gsh = p.group_log2, gmask = (1u << gsh) - 1u;
   const unsigned ngroups = (nfr + gmask) >> gsh;
   unsigned grp = blockIdx.x;
@@ -377,11 +379,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   v2f xp[NX];
   auto load_unit = [&](size_t u) {
     if (kPair) {
-      const bool has_b = 2 * u + 1 < p.n_frames;  // a ragged last pair: frame b reads as zeros
-      const __amdgpu_buffer_rsrc_t ra =
-          make_rsrc(reinterpret_cast<const char*>(p.frames) + (size_t)(2 * (size_t)u) * p.stride * 4, kN * 4);
+      const size_t fa = u << psh;
+      const bool has_b = psh && fa + 1 < p.n_frames;  // a ragged last pair (or no pairing): frame b reads as zeros
+      const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const char*>(p.frames) + fa * p.stride * 4, kN * 4);
       const __amdgpu_buffer_rsrc_t rb = make_rsrc(
-          reinterpret_cast<const char*>(p.frames) + (2 * u + (has_b ? 1 : 0)) * p.stride * 4, has_b ? kN * 4 : 0);
+          reinterpret_cast<const char*>(p.frames) + (fa + (has_b ? 1 : 0)) * p.stride * 4, has_b ? kN * 4 : 0);
 #pragma unroll
       for (int t = 0; t < NX; t++) xp[t] = mkv(buf_ld32_stream(ra, voff4, T * 4 * t), buf_ld32_stream(rb, voff4, T * 4 * t));
     } else {
@@ -402,8 +404,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       float mm_up = p.mag_mean_scalar, mm_dn = p.mag_mean_scalar;
       if (p.mag_mean) {
         // two floats per frame; the single-history pipeline of PAIR uses the first of each frame
-        mm_up = p.mag_mean[kPair ? 4 * ff : 2 * ff];
-        mm_dn = p.mag_mean[kPair ? ((2 * ff + 1 < p.n_frames) ? 4 * ff + 2 : 4 * ff) : 2 * ff + 1];
+        const size_t fa = ff << psh;
+        mm_up = p.mag_mean[kPair ? 2 * fa : 2 * ff];
+        mm_dn = p.mag_mean[kPair ? ((psh && fa + 1 < p.n_frames) ? 2 * fa + 2 : 2 * fa) : 2 * ff + 1];
       }
       float mr, ml;
       int kr, kl;
@@ -440,14 +443,15 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         if (kPair) {
           // h0 = the only history of frame 2 ff, h1 = of frame 2 ff + 1 (raw bin indices,
           // chirp_compression_freq_domain/Src/main.c:152-156); no symbol in this variant
-          const bool has_b = 2 * ff + 1 < p.n_frames;
+          const size_t fa = ff << psh;
+          const bool has_b = psh && fa + 1 < p.n_frames;
           if (p.stats) {
-            store_hist(p.stats + 2 * ff, h0, mm_up);
-            if (has_b) store_hist(p.stats + 2 * ff + 1, h1, mm_dn);
+            store_hist(p.stats + fa, h0, mm_up);
+            if (has_b) store_hist(p.stats + fa + 1, h1, mm_dn);
           }
           if (p.symbols) {
-            p.symbols[2 * ff] = (uint8_t)UC_SYM_NONE;
-            if (has_b) p.symbols[2 * ff + 1] = (uint8_t)UC_SYM_NONE;
+            p.symbols[fa] = (uint8_t)UC_SYM_NONE;
+            if (has_b) p.symbols[fa + 1] = (uint8_t)UC_SYM_NONE;
           }
         } else {
         if (p.stats) {

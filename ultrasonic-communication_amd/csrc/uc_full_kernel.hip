@@ -114,7 +114,9 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   // (the workgroups do not run at the same speed).  Thread 0 asks one pair before a chunk's last pair, right before
   // that pair's prefetch, and hands the id to the workgroup through one LDS word at the top of the chunk's last pair.
   // (32-bit bookkeeping: the host rejects batches of 2^31 frames or more; the frame ADDRESS is 64-bit)
-  const unsigned npairs = (unsigned)((p.n_frames + 1) / 2);
+  // (UC_FLAG_NO_FRAME_PAIRS: p.unpaired -- every frame rides alone, its partner slot reads as zeros)
+  const unsigned psh = p.unpaired ? 0u : 1u;  // frames per unit = 1 << psh
+  const unsigned npairs = (unsigned)((p.n_frames + psh) >> psh);
   const bool dyn = p.work_ctr != nullptr;
   const unsigned gsh = p.chunk_log2, gmask = (1u << gsh) - 1u;
   const unsigned nchunks = (npairs + gmask) >> gsh;
@@ -170,11 +172,11 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   // raw words of the pair: sample j + 128 t of frame 2q in the low, of frame 2q+1 in the high half
   v2f xp[16];
   auto load_pair = [&](unsigned uq) {
-    const size_t u = uq;
-    const bool hb = 2 * u + 1 < p.n_frames;  // a ragged last pair: frame b reads as zeros
-    const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u) * p.stride * 4, kN * 4);
+    const size_t fa = (size_t)uq << psh;
+    const bool hb = psh && fa + 1 < p.n_frames;  // a ragged last pair (or no pairing): frame b reads as zeros
+    const __amdgpu_buffer_rsrc_t ra = make_rsrc(reinterpret_cast<const char*>(p.frames) + fa * p.stride * 4, kN * 4);
     const __amdgpu_buffer_rsrc_t rb =
-        make_rsrc(reinterpret_cast<const char*>(p.frames) + (2 * u + (hb ? 1 : 0)) * p.stride * 4, hb ? kN * 4 : 0);
+        make_rsrc(reinterpret_cast<const char*>(p.frames) + (fa + (hb ? 1 : 0)) * p.stride * 4, hb ? kN * 4 : 0);
 #pragma unroll
     for (int t = 0; t < 16; t++) xp[t] = mkv(buf_ld32_stream(ra, voff4, T * 4 * t), buf_ld32_stream(rb, voff4, T * 4 * t));
   };
@@ -182,8 +184,8 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
 
   // result of one pair: merged by thread 0/1 after the NEXT barrier (red is rewritten three barriers later)
   auto publish = [&](unsigned qu) {
-    const size_t qq = qu;
-    const bool hb = 2 * qq + 1 < p.n_frames;
+    const size_t fa = (size_t)qu << psh;
+    const bool hb = psh && fa + 1 < p.n_frames;
     if (j < 2 && (j == 0 || hb) && p.stats) {
       // merge the two waves: value, then smallest index; a NaN partial only survives
       // if element 0 was NaN (wave 0 reports it with index 0)
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
       if (v0 != v0) { mx = v0; mi = i0; }
       else if (v1 > v0 || (v1 == v0 && i1 < i0)) { mx = v1; mi = i1; }
       else { mx = v0; mi = i0; }
-      const size_t ff = 2 * qq + j;
+      const size_t ff = fa + j;
       const float mm = has_mm ? p.mag_mean[2 * ff] : p.mag_mean_scalar;
       float4 a, bq;
       a.x = mx; a.y = 0.0f; a.z = mx; a.w = __int_as_float(mi);
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
       d[0] = a;
       d[1] = bq;
     }
-    if (j < 2 && (j == 0 || hb) && p.symbols) p.symbols[2 * qq + j] = (uint8_t)UC_SYM_NONE;
+    if (j < 2 && (j == 0 || hb) && p.symbols) p.symbols[fa + j] = (uint8_t)UC_SYM_NONE;
   };
 
   bool pending = false;

@@ -31,6 +31,7 @@ struct BandParams {
   uint32_t ifs;           // (uint32_t)(int32_t)fs for idx2freq
   uint32_t true_dc;       // UC_FLAG_TRUE_DC
   uint32_t group_log2;    // log2 of the frames (PAIR: frame pairs) per group: 1..6 with work_ctr, 0..6 without
+  uint32_t unpaired;      // kModePair only: 1 = UC_FLAG_NO_FRAME_PAIRS, one frame per transform
   unsigned int* work_ctr; // device word, zero at launch: groups beyond the first one of each workgroup are handed out
                           // by atomic increments (the workgroups run at different speeds); nullptr = static round robin
   unsigned long long* debug;  // diagnostic builds only (UC_STAMPS), else nullptr
@@ -57,6 +58,7 @@ struct FullParams {
   uint8_t* symbols;       // device or nullptr (always UC_SYM_NONE)
   uc_stats* stats;        // device or nullptr, 1 per frame
   float mag_mean_scalar;
+  uint32_t unpaired;       // 1 = UC_FLAG_NO_FRAME_PAIRS: one frame per transform (the partner slot reads as zeros)
   unsigned int* work_ctr;  // device word, zero at launch: chunks of 2^chunk_log2 consecutive frame pairs, the ones after a
   uint32_t chunk_log2;     // workgroup's first handed out by atomic increments (chunk_log2 >= 1); nullptr = a balanced
                            // contiguous partition of the pairs

@@ -23,7 +23,7 @@ RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ, STREAM = range(6)
 DOWN_CHIRP, UP_CHIRP = 0, 1
 DTYPE_I32, DTYPE_F32 = 0, 1
 SYM_DOWN, SYM_UP, SYM_NONE = 0, 1, 0xFF
-FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP, FLAG_IQ_BASEBAND = 1, 2, 8, 16
+FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP, FLAG_IQ_BASEBAND, FLAG_NO_FRAME_PAIRS = 1, 2, 8, 16, 32
 (TABLE_UP, TABLE_DOWN, TABLE_HANN, TABLE_H_UP, TABLE_H_DOWN, TABLE_CARRIER_C, TABLE_CARRIER_S,
  TABLE_FIR, TABLE_TEMPLATE) = range(9)
 
