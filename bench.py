@@ -291,9 +291,19 @@ def main():
     if have_gpu:
         torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # UC_BENCH_HELLO=1: run the N > 1 leg -- configs[4] framing, RCCL process group, async all-gather, digest check,
+    # text decode -- with whatever world size there is, 1 included (what a one-GPU box can exercise of it on RCCL).
+    multi = world > 1 or os.environ.get("UC_BENCH_HELLO") == "1"
+    json_out = sys.stdout
+    if multi:
+        # RCCL prints its version banner on file descriptor 1; stdout must carry the JSON line and nothing else:
+        # keep a private copy of the real stdout for that line and point descriptor 1 at stderr for everyone else
+        sys.stdout.flush()
+        json_out = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -303,7 +313,7 @@ def main():
     from uchirp import synth
     mag_mean = 1000.0
     nf = args.frames
-    hello = world > 1 and args.variant == "rx_real"
+    hello = multi and args.variant == "rx_real"
     eng = None
     if have_gpu:
         import uchirp
@@ -325,7 +335,7 @@ def main():
     # a buffer is rewritten only after the gather that read it has finished (work.wait() orders the
     # launch stream behind it without blocking the host).
     sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
-    gathered2 = [torch.empty(world * nf, dtype=torch.uint8, device=device) for _ in range(2)] if world > 1 else None
+    gathered2 = [torch.empty(world * nf, dtype=torch.uint8, device=device) for _ in range(2)] if multi else None
     works = [None, None]
     stream = torch.cuda.current_stream(device) if have_gpu else None
 
@@ -350,7 +360,7 @@ def main():
             eng.process(frames, want_stats=False, symbols_out=sym2[b], stream=stream.cuda_stream)
             if e1 is not None:
                 e1.record(stream)
-        if world > 1:
+        if multi:
             works[b] = gather(b)
 
     def drain():
@@ -367,7 +377,7 @@ def main():
         step(k)
     drain()
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     sync()
 
@@ -379,17 +389,17 @@ def main():
         step(k, ev[k][0], ev[k][1])
     drain()
     sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     symbols = sym2[(args.steps - 1) & 1]
     gathered_host = None
-    if world > 1:
+    if multi:
         # Every rank holds the concatenation of all ranks' symbols, rank order: its own slice equals what it
         # decoded, and every rank's gathered buffer has the same digest (so the other slices are the owners').
         import hashlib
@@ -448,7 +458,7 @@ def main():
                                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                                "kernel": "band_kernel<rx_real,f32>", "kernel_ms": kern_ms,
                                "bytes_per_frame": BYTES_PER_FRAME}
-            if world == 1:
+            if not multi:
                 ach = achievable_hbm(frames, stream, torch)
                 if ach:
                     out["roofline"]["achievable"] = ach
@@ -470,14 +480,14 @@ def main():
         else:
             # correctness gate on the measured run: decoded symbols vs transmitted bits
             out["bit_error_rate_vs_transmitted"] = float((symbols != sent).float().mean().item())
-        if world == 1 and have_gpu and not args.no_cpu_baseline:
+        if not multi and have_gpu and not args.no_cpu_baseline:
             cb = cpu_baseline(frames[: 1 << 19].cpu().numpy(), mag_mean)
             # the oracle as the checker: GPU symbols of the measured run vs float64 oracle
             head = cb.pop("symbols_f64_oracle_head")
             out["symbols_equal_oracle_head4096"] = float((symbols[:4096].cpu().numpy() == head).mean())
             out["cpu_baseline"] = cb
-        print(json.dumps(out), flush=True)
-    if world > 1:
+        print(json.dumps(out), file=json_out, flush=True)
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 
