@@ -41,3 +41,24 @@ def test_no_gpu_is_a_loud_failure():
     p = _run(["--gpus", "1", "--frames", "64"], {"HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
     assert p.returncode != 0
     assert "no CPU fallback" in p.stderr
+
+
+def test_stdout_is_exactly_one_json_line_for_n_ranks():
+    """The driver reads ONE JSON line from stdout: whatever the libraries of the ranks print on descriptor 1 (RCCL's
+    NCCL_DEBUG=VERSION banner on the GPU boxes, gloo's connection notes here) must not reach it."""
+    p = _run(["--gpus", "2", "--frames", "234", "--steps", "2", "--warmup", "1"],
+             {"UC_BENCH_REHEARSE": "1", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and json.loads(lines[0])["n_gpus"] == 2
+
+
+def test_hello_leg_runs_at_world_size_one():
+    p = _run(["--frames", "1170", "--steps", "2", "--warmup", "1"],
+             {"UC_BENCH_REHEARSE": "1", "UC_BENCH_HELLO": "1", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": "",
+              "MASTER_PORT": "29541"})
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("configs[4]") and d["decoded_text_first"] == "Hello World!"
