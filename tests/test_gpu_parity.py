@@ -856,6 +856,19 @@ def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch):
         torch.cuda.synchronize()
         assert np.array_equal(sym.cpu().numpy(), s0)
         assert np.array_equal(st.cpu().numpy().view(np.uint32), st0.view(np.uint32))
+    # a context whose FIRST call is the captured one (nothing in the call may allocate or synchronise)
+    e2 = uchirp.Engine(e.variant, n=e.n, mag_mean=e.cfg.mag_mean)
+    g2 = torch.cuda.CUDAGraph()
+    sym.zero_()
+    st.zero_()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g2, stream=s):
+            e2.process(buf, n_frames=n_frames, symbols_out=sym, stats_out=st, stream=s.cuda_stream)
+    g2.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(sym.cpu().numpy(), want[-1][0])
+    assert np.array_equal(st.cpu().numpy().view(np.uint32), want[-1][1].view(np.uint32))
 
 
 def test_compress_pair_chunks_dynamic_hand_out(uchirp, monkeypatch):
