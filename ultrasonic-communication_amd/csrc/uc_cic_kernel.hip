@@ -20,6 +20,9 @@ namespace uc {
 
 namespace {
 
+#ifndef UC_CIC_KNOCK
+#define UC_CIC_KNOCK 0  // diagnostic builds: 1 = no stores, 2 = no HBM reads (profiles/r02_sinc5_notes.txt)
+#endif
 #ifndef UC_CIC_THREADS
 #define UC_CIC_THREADS 1024
 #endif
@@ -28,20 +31,31 @@ constexpr int kTileWords = 256;     // words one wave loads
 constexpr int kTileOut = 252;       // outputs one wave stores
 // The lookups are indexed by DATA bytes, so with a plain table the bank a lane hits is random (58 % of the LDS
 // cycles were bank conflicts, r01).  Here the bank is a function of the LANE alone:
-//   * every entry is replicated 8 times, a lane reads replica r = lane & 7;
+//   * every entry is replicated (4 times in the 16-byte table, 8 times in the 4-byte table), a lane reads replica
+//     lane & 3 resp. lane & 7;
 //   * the lanes that share a replica inside one LDS access group never look at the same BYTE POSITION in the same
 //     instruction: in step i a lane handles byte b = (i + (lane >> 3)) & 3 of its words.  A ds_read_b128 is served
-//     in groups of 16 lanes in which lanes l and l ^ 24 share r (MI355X_MICROARCH.md, LDS): their b differ in bit 0;
-//     a ds_read_b32 in groups of 32 lanes in which l, l + 8, l + 16, l + 24 share r: their b are all different;
-//   * the tables are laid out so that (b, r) picks the bank and the byte value only the ROW:
-//       16-byte table: entry (b, v), replica r at 16-byte slot  ((b >> 1) * 256 + v) * 16 + 8 * (b & 1) + r
-//        4-byte table: entry (b, v), replica r at dword          v * 32 + 8 * b + r
-// 128 KiB + 32 KiB = all 160 KiB of the CU's LDS, one 1024-thread workgroup per CU.
-constexpr int R4 = 8;
+//     in groups of 16 lanes -- {0-3, 12-15, 20-27}, ... (MI355X_MICROARCH.md, LDS): four runs of four lanes with four
+//     different lane >> 3, so (b, lane & 3) takes all 16 values; a ds_read_b32 in groups of 32 lanes: (b, lane & 7)
+//     takes all 32 values;
+//   * the tables are laid out so that (b, replica) picks the bank and the byte value only the ROW, and a row is 256
+//     bytes in BOTH tables, so that each address is ONE v_perm_b32 of the data word (byte 1 = the data byte):
+//       16-byte table: entry (b, v), replica r at byte            v * 256 + (4 b + r) * 16
+//        4-byte table: entry (b, v), replica r at byte  0x10000 + v * 256 + (8 b + r) * 4      (half of each row unused)
+// 64 KiB + 64 KiB of the CU's 160 KiB, one 1024-thread workgroup per CU.
+constexpr int R4 = 4;
 constexpr int R1 = 8;
-constexpr size_t kCicLdsBytes = 1024 * (size_t)R4 * 16 + 1024 * (size_t)R1 * 4;
+constexpr size_t kT1Base = 0x10000;
+constexpr size_t kCicLdsBytes = 2 * 0x10000;
 
 typedef int v4i __attribute__((ext_vector_type(4)));
+
+// LDS access by ABSOLUTE byte address: the v_perm_b32 result is the address itself (the kernel's dynamic LDS starts at
+// byte 0 -- it declares no static LDS; checked once at kernel start), no base to add per lookup
+template <typename V>
+__device__ __forceinline__ const __attribute__((address_space(3))) V* lds_at(unsigned byte_address) {
+  return reinterpret_cast<const __attribute__((address_space(3))) V*>(static_cast<uintptr_t>(byte_address));
+}
 
 // value of lane - 1 (lane 0 receives 0)
 __device__ __forceinline__ int from_prev_lane(int v) {
@@ -54,27 +68,31 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
   const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned char cic_lds[];
-  v4i* t4 = reinterpret_cast<v4i*>(cic_lds);                   // (b, v, r) -> outputs m .. m+3 of word m
-  int* t1 = reinterpret_cast<int*>(cic_lds + 1024 * R4 * 16);  // (b, v, r) -> output m+4
-  for (int i = threadIdx.x; i < 1024 * R4; i += TC) {
+  if ((unsigned)reinterpret_cast<uintptr_t>(cic_lds) != 0u) __builtin_trap();  // (low half of a flat LDS address = the LDS offset)
+  // entry e = 256 b + v of the host tables -> the replicated, bank-steered LDS layout.  The -2^24 of
+  // y = 2 B - 2^25 rides in the table: every output sums exactly one "word m, byte 0, output m" entry.
+  for (int i = threadIdx.x; i < 1024 * R1; i += TC) {
     const int e = i >> 3, r = i & 7, b = e >> 8, v = e & 255;
-    t4[((b >> 1) * 256 + v) * 16 + 8 * (b & 1) + r] = reinterpret_cast<const v4i*>(p.t4)[e];
-    t1[v * 32 + 8 * b + r] = p.t1[e];
+    if (r < R4) {
+      v4i q = reinterpret_cast<const v4i*>(p.t4)[e];
+      if (b == 0) q.x -= 1 << 24;
+      *reinterpret_cast<v4i*>(cic_lds + v * 256 + (4 * b + r) * 16) = q;
+    }
+    *reinterpret_cast<int*>(cic_lds + kT1Base + v * 256 + (8 * b + r) * 4) = p.t1[e];
   }
   __syncthreads();
 
   const int lane = threadIdx.x & 63;
-  // step i of a word: byte b = (i + (lane >> 3)) & 3; byte offsets of the two lookups besides the value's row
-  int sh[4], oa[4], ob[4];
+  // step i of a word: byte b = (i + (lane >> 3)) & 3.  Both addresses are v_perm_b32(word, constant, selector):
+  // byte 0 and byte 2 from the lane's constant (slot inside the row, table base), byte 1 = data byte b, byte 3 = 0.
+  unsigned sel[4], c4[4], c1[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int b = (i + (lane >> 3)) & 3;
-    sh[i] = 8 * b;
-    oa[i] = ((b >> 1) * 256 * 16 + 8 * (b & 1) + (lane & 7)) * 16;
-    ob[i] = (8 * b + (lane & 7)) * 4;
+    const unsigned b = (unsigned)(i + (lane >> 3)) & 3u;
+    sel[i] = 0x0c020000u | ((4u + b) << 8);              // {0, const.byte2, word.byte b, const.byte0}
+    c4[i] = (4u * b + ((unsigned)lane & 3u)) << 4;
+    c1[i] = (unsigned)kT1Base | ((8u * b + ((unsigned)lane & 7u)) << 2);
   }
-  const unsigned char* t4b = cic_lds;
-  const unsigned char* t1b = cic_lds + 1024 * R4 * 16;
   const size_t n_out = p.n_words - 4;
   const size_t tiles = (n_out + kTileOut - 1) / kTileOut;
   // (readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane; without it the tile
@@ -90,7 +108,12 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     const size_t left = tile < tiles ? p.n_words - base : 0;
     const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
     const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.pdm + (tile < tiles ? base : 0), recs * 4);
+#if UC_CIC_KNOCK == 2  // (knock-out build: every tile re-reads the stream's first KiB -- no HBM reads)
+    const __amdgpu_buffer_rsrc_t rin0 = make_rsrc(p.pdm, recs * 4);
+    return __builtin_amdgcn_raw_buffer_load_b128(rin0, lane * 16, 0, 0);
+#else
     return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, UC_STREAM_CPOL);
+#endif
   };
   // One tile of a wave: 256 words in, 252 outputs out.
   auto process = [&](const v4u w, size_t tile) {
@@ -102,10 +125,9 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
       int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
 #pragma unroll
       for (int i = 0; i < 4; i++) {
-        const unsigned v = __builtin_amdgcn_ubfe(wd[c], (unsigned)sh[i], 8u);
-        const v4i q = *reinterpret_cast<const v4i*>(t4b + (v << 8) + oa[i]);
+        const v4i q = *lds_at<v4i>(__builtin_amdgcn_perm(wd[c], c4[i], sel[i]));
         a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
-        a4 += *reinterpret_cast<const int*>(t1b + (v << 7) + ob[i]);
+        a4 += *lds_at<int>(__builtin_amdgcn_perm(wd[c], c1[i], sel[i]));
       }
       g[c][0] = a0; g[c][1] = a1; g[c][2] = a2; g[c][3] = a3; g[c][4] = a4;
       if (c & 1) __builtin_amdgcn_sched_barrier(0);  // two words' lookups (16 reads, 40 result registers) at a time
@@ -123,9 +145,9 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     y1 += from_prev_lane(c1);
     y2 += from_prev_lane(c2);
     y3 += from_prev_lane(c3);
-    // B = sum of the taps that met a 1 bit: y = 2 B - 2^25; result = clip(y >> 2) << 8
+    // B = sum of the taps that met a 1 bit: y = 2 B - 2^25; result = clip(y >> 2) << 8  (bsum = B - 2^24: see the fill)
     auto word = [](int bsum) {
-      int v = (bsum - (1 << 24)) >> 1;
+      int v = bsum >> 1;
       v = v > 8388607 ? 8388607 : v;
       v = v < -8388608 ? -8388608 : v;
       return v * 256;
@@ -138,7 +160,11 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + (tile < tiles ? base : 0), recs * 4);
     v4u r;
     r.x = (unsigned)word(y0); r.y = (unsigned)word(y1); r.z = (unsigned)word(y2); r.w = (unsigned)word(y3);
+#if UC_CIC_KNOCK == 1  // (knock-out build: one lane of 63 stores)
+    if (lane == 1) __builtin_amdgcn_raw_buffer_store_b128(r, rout, (lane - 1) * 16, 0, UC_STREAM_CPOL);  // 1/63 of the bytes
+#else
     __builtin_amdgcn_raw_buffer_store_b128(r, rout, (lane - 1) * 16, 0, UC_STREAM_CPOL);  // written once, never read here
+#endif
   };
   // Workgroup b owns the tiles b, b + B, b + 2 B, ... (B workgroups); its 16 waves do NOT run at the same speed (the
   // SIMD arbitration favours the older wave: with equal static shares the slowest wave of a workgroup ran 1.5 x as
