@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Random strides (overlapping and gapped FIFO reads), counts, dtypes and per-frame noise floors through the frame kernels
+vs the oracle (default configuration).  Usage: python tools/fuzz_strides.py [cases=200] [seed=1]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
+import numpy as np
+import uchirp
+from oracle import uco
+import synth
+from parity_util import check_history, MARGIN, MAG_TOL
+
+cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+eng = {}
+bad = 0
+for case in range(cases):
+    variant = int(rng.choice([uco.RX_REAL, uco.SYNC_CPLX, uco.DECHIRP_DOWN, uco.COMPRESS]))
+    kw = dict(fs=100000.0, f0=17000.0, f1=18000.0) if variant == uco.DECHIRP_DOWN else {}
+    if variant not in eng:
+        eng[variant] = (uco.Oracle(variant, **kw), uchirp.Engine(variant, **kw))
+    o, e = eng[variant]
+    n_frames = int(rng.choice([1, 2, 3, 5, 31, 32, 33, 64, 65, 127]))
+    stride = int(rng.choice([0, 1, 7, 256, 512, 1000, 2047, 2048, 2049, 3000]))
+    dtype = np.int32 if rng.random() < 0.4 else np.float32
+    st = stride or 2048
+    total = (n_frames - 1) * st + 2048
+    src, _ = synth.make_frames(-(-total // 2048), seed=int(rng.integers(1 << 30)), snr_db=float(rng.choice([-6.0, 0.0, 6.0])), dtype=dtype, **kw)
+    buf = src.reshape(-1)[:total]
+    mm = rng.uniform(50.0, 5000.0, size=(n_frames, 2)).astype(np.float32) if rng.random() < 0.5 else None
+    try:
+        rs, rst = o.process(buf, n_frames=n_frames, stride=stride, mag_mean=mm)
+        gs, gst = e.process(buf, n_frames=n_frames, stride=stride, mag_mean=mm)
+        if variant == uco.COMPRESS:
+            r, g = rst[:, 0], gst[:, 0]
+            scale = np.abs(r["mag_max"].astype(np.float64))
+            assert (np.abs(g["mag_max"].astype(np.float64) - r["mag_max"]) / scale).max() <= MAG_TOL
+            for f in np.nonzero(g["max_freq"] != r["max_freq"])[0]:
+                y = o.spectrum(buf[f * st: f * st + 2048])[0]
+                assert y.max() - y[g["max_freq"][f]] <= MAG_TOL * abs(y.max())
+        else:
+            for h in range(o.spf):
+                check_history(o, lambda f: buf[f * st: f * st + 2048], gst[:, h], rst[:, h], h, "case %d" % case,
+                              raw_idx=(variant == uco.DECHIRP_DOWN))
+            if o.spf == 2:
+                su, sd = rst["snr"][:, 0].astype(np.float64), rst["snr"][:, 1].astype(np.float64)
+                margin = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30)
+                near = (np.abs(su - 2.0) < 2e-3) | (np.abs(sd - 2.0) < 2e-3)
+                clear = (margin >= MARGIN) & ~near
+                assert np.array_equal(gs[clear], rs[clear])
+    except AssertionError as ex:
+        bad += 1
+        print("FAIL case %d variant %d n_frames %d stride %d dtype %s mm %s: %s" % (case, variant, n_frames, stride, np.dtype(dtype).name, mm is not None, str(ex)[:300]), flush=True)
+    if case % 50 == 49:
+        print("%d cases, %d failures" % (case + 1, bad), flush=True)
+print("done: %d cases, %d failures" % (cases, bad))
+sys.exit(1 if bad else 0)
