@@ -150,9 +150,17 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     const size_t left = p.n_samples > first ? p.n_samples - first : 0;
     const int recs = left < (size_t)(kSubIn + 28) ? (int)left : kSubIn + 28;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.samples) + first * 4, recs * 4);
+    // The last sub-tile of a block holds the (L - 1) D samples the NEXT block reads again (overlap-save): those loads keep
+    // the default cache policy so that the re-read can hit; everything else is read once and streams past the caches.
+    if (sub == NSUB - 1) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) dst[r] = buf_ld128_stream(rx, voff16, T * 16 * r);
-    dst[8] = buf_ld128_stream(rx, voff16, kSubIn * 4);
+      for (int r = 0; r < 8; r++) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, T * 16 * r, 0);
+      dst[8] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, kSubIn * 4, 0);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; r++) dst[r] = buf_ld128_stream(rx, voff16, T * 16 * r);
+      dst[8] = buf_ld128_stream(rx, voff16, kSubIn * 4);
+    }
   };
 
   issue_loads(b, 0, stg[0]);
