@@ -565,9 +565,13 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         ring_f0 = f;
         ring_n = 0;
       }
+      // (wave priority: low while it issues a burst of LDS stores, raised otherwise -- the SIMD's other waves get their
+      // arithmetic issued ahead of the store burst; measured +0.5-0.7 %, the opposite assignment -1.5 %)
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int t = 0; t < 16; t += 2)
         lds_st2(lds, wr1 + (t ^ s1v), v[4 * (t & 3) + (t >> 2)], v[4 * ((t + 1) & 3) + ((t + 1) >> 2)]);
+      __builtin_amdgcn_s_setprio(2);
       UC_STAMP(1);
       __syncthreads();  // B1
       UC_STAMP(2);
@@ -584,8 +588,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       UC_STAMP(3);
       __syncthreads();  // B2: every pass-2 read is done before the tile is overwritten
       UC_STAMP(4);
+      __builtin_amdgcn_s_setprio(0);
 #pragma unroll
       for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[4 * (t & 3) + (t >> 2)]);
+      __builtin_amdgcn_s_setprio(2);
 
       __syncthreads();  // B3
       UC_STAMP(5);
