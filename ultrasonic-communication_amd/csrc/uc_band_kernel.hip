@@ -595,6 +595,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 
       __syncthreads();  // B3
       UC_STAMP(5);
+      __builtin_amdgcn_s_setprio(3);  // the pruned pass and the window search end the frame: first in line (+0.4 %)
       // ---- pass 3: radix-8, Ns = 256, only bins i in [0, bw2] and n - i -----
       // Round 0: bin j on every thread.  Round 1: bins 128 + lane on wave 1 only (wave 0
       // owns the finaliser).  A round is latency- not throughput-bound: splitting round 1
@@ -714,6 +715,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         }
       }
       UC_STAMP(8);
+      __builtin_amdgcn_s_setprio(2);
       if (run == kRuns - 1) ring_n++;
     }
     if (!has_next) break;
