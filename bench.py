@@ -216,6 +216,8 @@ def parse_args(argv=None):
     ap.add_argument("--frames", type=int, default=1 << 20, help="frames per GPU per step")
     ap.add_argument("--snr", type=float, default=-10.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ramp-ms", type=float, default=150.0,
+                    help="untimed kernel launches before the warm-up steps until the GPU's clocks have settled (0 = none)")
     ap.add_argument("--variant", default="rx_real",
                     choices=["rx_real", "sync_cplx", "compress", "dechirp_down", "iq", "iq1024", "stream"],
                     help="default rx_real = BASELINE configs[1]; the others are side measurements")
@@ -373,6 +375,18 @@ def main():
         if have_gpu:
             torch.cuda.synchronize()
 
+    # Clock ramp (untimed, BEFORE the W warm-up steps; --ramp-ms, default 150): an idle MI355X needs ~20 launches
+    # (~40 ms) of this kernel before its launch time settles -- 2.9, 3.0, 2.7, 2.5 ms for the first four launches,
+    # 2.22 ms for launches 5-14, 2.10 ms from launch 20 on (tools/ramp_probe.py, profiles/r02_v5_ramp.txt).  The ramp
+    # runs the kernel only (no gather), on the same resident batch, and is reported as `ramp_ms` in the JSON line.
+    ramp_launches = 0
+    if have_gpu and args.ramp_ms > 0:
+        t_r = time.perf_counter()
+        while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+            for _ in range(4):
+                eng.process(frames, want_stats=False, symbols_out=sym2[0], stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            ramp_launches += 4
     for k in range(args.warmup):
         step(k)
     drain()
@@ -425,6 +439,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "ramp_ms": args.ramp_ms if have_gpu else 0.0, "ramp_launches": ramp_launches,
         }
         if hello:
             out["config"] = {"workload": "configs[4]: %d x 2048-sample fp32 frames per GPU, frame-sharded 'Hello World!' "
