@@ -17,7 +17,9 @@
  *                           receiver/Src/main.c:659-668
  *   uc_idx2freq          <- idx2freq(), receiver/Src/main.c:154-160
  *   uc_get_table         <- the globals up_chirp/down_chirp/hann_window,
- *                           receiver/Src/chirp.c:13-14, receiver/Src/main.c:99
+ *   uc_set_table            receiver/Src/chirp.c:13-14, receiver/Src/main.c:99
+ *   uc_window_spectrum   <- pipeline(), receiver/Src/main.c:163-180: the magnitudes it leaves in
+ *                           signal[0..NN), for the bins dsp() then looks at (main.c:205-208)
  *   uc_destroy           <- (none; the firmware never frees)
  *
  * Variants select the sibling pipelines:
@@ -50,7 +52,7 @@
 extern "C" {
 #endif
 
-#define UC_ABI_VERSION 3
+#define UC_ABI_VERSION 4
 
 /* pipeline variants */
 enum {
@@ -179,6 +181,12 @@ int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
  * Every other variant treats frames independently.
  * With device pointers the call enqueues its work on hip_stream and returns; it may be captured into a
  * hipGraph (all buffers device-resident) and replayed over new contents of the same buffers.
+ * Work distribution: a large launch hands its frame groups to the workgroups through one atomic counter.  Eager
+ * launches take that counter from a ring of 64 per context; a slot is reused only once the launch that last used it
+ * has finished (otherwise the launch falls back to the static round-robin deal: same results, a few percent slower),
+ * so any number of launches of one context may be in flight on any number of streams.  A launch recorded during
+ * stream capture gets a counter that its graph owns for the life of the context (960 per context, then static deal);
+ * its zeroing is recorded as a memset node in front of the kernel node.
  */
 int uc_process_batch(uc_ctx* ctx, const void* frames, int dtype,
                      size_t n_frames, size_t stride_elems,
@@ -193,6 +201,30 @@ int uc_iq_halo(const uc_ctx* ctx);
 
 /* copy a host copy of a reference table; returns the element count or <0 */
 int uc_get_table(const uc_ctx* ctx, int table_id, float* out, size_t cap);
+
+/*
+ * Replace a reference table: the firmware's tables are plain globals (up_chirp / down_chirp, receiver/Src/chirp.c:13-14;
+ * hann_window, receiver/Src/main.c:99) that a host program may fill with a reference of its own -- a measured chirp,
+ * all ones (then RX_REAL is Hann -> RFFT -> magnitude, the `basic` experiment, experiments/basic/Src/main.c:107-131), a
+ * complex exponential (SYNC_CPLX: the windows then look at any part of the spectrum).
+ * table_id: UC_TABLE_UP, UC_TABLE_DOWN or UC_TABLE_HANN; count must equal what uc_get_table returns for it.
+ * RX_REAL, SYNC_CPLX and DECHIRP_DOWN only (-ENOTSUP otherwise).  Synchronous: waits for the device, then rebuilds the
+ * fused reference * Hann tables the kernels read.  Window geometry (bandwidth, idx_left_zero) is unchanged.
+ */
+int uc_set_table(uc_ctx* ctx, int table_id, const float* data, size_t count);
+
+/*
+ * pipeline() for a batch: the magnitudes it leaves in signal[] (receiver/Src/main.c:176-179), restricted to the bins
+ * dsp() looks at.  mags: n_frames x uc_stats_per_frame() x uc_window_bins() floats, host or device;
+ * record [frame][history][bandwidth2 + k] = |X[k]| for k = -bandwidth2 .. +bandwidth2 (k < 0: bin n + k), history 0 = up
+ * reference, 1 = down (one history for DECHIRP_DOWN).  Bin 0 follows UC_FLAG_TRUE_DC (Q2).  With real references both
+ * sides of DC hold the same value (Q1: Hermitian mirror).  RX_REAL, SYNC_CPLX, DECHIRP_DOWN; same frame addressing,
+ * dtype and stream semantics as uc_process_batch.  A diagnostic / capture-comparison path (it runs the three-round build
+ * of the band kernel), not the throughput path.
+ */
+int uc_window_bins(const uc_ctx* ctx);   /* 2 * bandwidth2 + 1, or <0 */
+int uc_window_spectrum(uc_ctx* ctx, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
+                       float* mags, void* hip_stream);
 
 /* derived integers of main(): bandwidth, bandwidth2, idx_left_zero */
 int uc_get_windows(const uc_ctx* ctx, uint32_t* bandwidth, uint32_t* bandwidth2,

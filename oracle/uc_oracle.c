@@ -583,6 +583,25 @@ int uco_get_table(const uco_ctx* c, int id, float* out, size_t cap) {
   return (int)cnt;
 }
 
+/* the firmware's tables are plain globals (receiver/Src/chirp.c:13-14, main.c:99): a host may fill them itself */
+int uco_set_table(uco_ctx* c, int id, const float* data, size_t count) {
+  if (!c || !data) return -EINVAL;
+  if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX && c->cfg.variant != UC_DECHIRP_DOWN) return -ENOTSUP;
+  int cplx = (c->cfg.variant == UC_SYNC_CPLX);
+  float* dst = NULL;
+  size_t cnt = 0;
+  switch (id) {
+    case UC_TABLE_UP: dst = c->up; cnt = c->n * (cplx ? 2 : 1); break;
+    case UC_TABLE_DOWN: dst = c->down; cnt = c->n * (cplx ? 2 : 1); break;
+    case UC_TABLE_HANN: dst = c->hann; cnt = c->n; break;
+    default: return -EINVAL;
+  }
+  if (!dst) return -ENOENT;
+  if (count != cnt) return -EINVAL;
+  memcpy(dst, data, sizeof(float) * cnt);
+  return 0;
+}
+
 /* idx2freq: receiver/Src/main.c:154-160 -- integer arithmetic on (int32_t)fs */
 static int32_t idx2freq_n(float fs, uint32_t n, uint32_t idx) {
   uint32_t ifs = (uint32_t)(int32_t)fs;

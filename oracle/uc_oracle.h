@@ -58,6 +58,8 @@ int uco_spectrum(uco_ctx* ctx, const void* frame, int dtype, int precision,
 
 int uco_stats_per_frame(const uco_ctx* ctx);
 int uco_get_table(const uco_ctx* ctx, int table_id, float* out, size_t cap);
+/* same meaning as uc_set_table (include/uchirp.h): UC_TABLE_UP / _DOWN / _HANN of RX_REAL, SYNC_CPLX, DECHIRP_DOWN */
+int uco_set_table(uco_ctx* ctx, int table_id, const float* data, size_t count);
 int uco_get_windows(const uco_ctx* ctx, uint32_t* bandwidth, uint32_t* bandwidth2,
                     uint32_t* idx_left_zero);
 int32_t uco_idx2freq(const uco_ctx* ctx, uint32_t idx);

@@ -73,6 +73,7 @@ def lib():
         L.uco_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         L.uco_stats_per_frame.argtypes = [C.c_void_p]
         L.uco_get_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+        L.uco_set_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
         L.uco_get_windows.argtypes = [C.c_void_p] + [C.POINTER(C.c_uint32)] * 3
         L.uco_idx2freq.argtypes = [C.c_void_p, C.c_uint32]
         L.uco_idx2freq.restype = C.c_int32
@@ -140,6 +141,12 @@ class Oracle:
 
     def idx2freq(self, idx):
         return lib().uco_idx2freq(self._h, int(idx))
+
+    def set_table(self, tid, data):
+        a = np.ascontiguousarray(data, np.float32).reshape(-1)
+        rc = lib().uco_set_table(self._h, tid, _ptr(a), a.size)
+        if rc:
+            raise ValueError("uco_set_table rc=%d" % rc)
 
     def process(self, frames, n_frames=None, stride=0, mag_mean=None, precision=F64, threads=0,
                 halo=0):

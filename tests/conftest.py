@@ -31,3 +31,9 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+@pytest.fixture
+def uc_tuning(monkeypatch):
+    """The library reads its experiment switches (UC_GRID, UC_*_GROUP, UC_STATIC_DEAL, ...) only under UC_TUNING=1."""
+    monkeypatch.setenv("UC_TUNING", "1")

@@ -6,7 +6,7 @@ vector for it: the oracle's Hogenauer restatement is pinned against the direct 1
 import numpy as np
 import pytest
 
-import synth
+from uchirp import synth
 from oracle import uco
 
 

@@ -138,7 +138,7 @@ def test_baseband_noisy_stream_matches_oracle_and_decodes(uchirp, n, dtype):
 
 
 @pytest.mark.parametrize("n", [1024, 2048])
-def test_baseband_frame_groups_strides_and_small_batches(uchirp, n, monkeypatch):
+def test_baseband_frame_groups_strides_and_small_batches(uchirp, n, monkeypatch, uc_tuning):
     """Group / ring / round-robin paths of the kernels in base-band mode (two ring entries per frame): a tiny grid
     gives bit-identical records; overlapping strides and batches around the group size agree with the oracle."""
     n_frames = 300

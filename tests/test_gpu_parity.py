@@ -14,7 +14,7 @@ import pytest
 
 ROOT_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-import synth
+from uchirp import synth
 from oracle import uco
 from parity_util import MAG_TOL, MARGIN, check_history, check_magnitudes, clear_symbols, index_mismatches, prove_ties
 
@@ -733,7 +733,7 @@ def test_plain_c_host_through_the_c_abi(uchirp, tmp_path):
     out = subprocess.run([exe, "9"], capture_output=True, timeout=300)
     assert out.returncode == 0, out.stdout.decode() + out.stderr.decode()
     lines = out.stdout.decode().splitlines()
-    assert lines[0].startswith("uc_abi_version 3 (header 3)")
+    assert lines[0].startswith("uc_abi_version 4 (header 4)")
     assert lines[1].startswith("frame up  : symbol 1") and lines[2].startswith("frame down: symbol 0")
     assert lines[3] == "batch: 0 1 0 1 0 1 0 1 0"
 
@@ -762,7 +762,7 @@ def test_iq_variant_at_1024_points_one_wave_per_frame(uchirp):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("n", [1024, 2048])
-def test_iq_frame_groups_ring_and_round_robin(uchirp, n, monkeypatch):
+def test_iq_frame_groups_ring_and_round_robin(uchirp, n, monkeypatch, uc_tuning):
     """The IQ kernels deal frames to workgroups in groups of up to 64 (one finaliser drain per group: a
     ring of window partials in LDS, one lane per frame).  A tiny grid (UC_GRID, a tuning knob read at
     uc_create) forces full groups, a ragged last group, several groups per workgroup and the
@@ -802,7 +802,7 @@ def test_iq_frame_groups_ring_and_round_robin(uchirp, n, monkeypatch):
 
 def test_unsupported_configurations_fail_loudly(uchirp):
     with pytest.raises(uchirp.UchirpError, match="bandwidth2"):
-        uchirp.Engine(uchirp.RX_REAL, f1=25000.0)          # 2*bandwidth = 470 bins > the 191 the kernel evaluates
+        uchirp.Engine(uchirp.RX_REAL, f1=25000.0)          # 2*bandwidth = 470 bins > the 319 the kernel evaluates
     with pytest.raises(uchirp.UchirpError, match="unsupported"):
         uchirp.Engine(uchirp.RX_REAL, n=4096)
     with pytest.raises(uchirp.UchirpError):
@@ -813,11 +813,12 @@ def test_unsupported_configurations_fail_loudly(uchirp):
 
 
 @pytest.mark.parametrize("variant", ["rx_real", "iq1024", "compress"])
-def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch):
+def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch, uc_tuning):
     """uc_process_batch captured ONCE into a hipGraph and replayed over new frames in the same buffers gives the eager
-    launch's bytes.  (While a stream is being captured the launch uses the static deal: a replayed graph would keep the
-    hand-out counter it was captured with.)  A tiny grid makes the eager launches of the same context use the dynamic
-    hand-out in between, on the same counter ring."""
+    launch's bytes.  A tiny grid makes every launch -- the captured ones too -- use the dynamic hand-out: a captured launch
+    gets a counter slot that its graph owns (zeroed by a memset node in front of the kernel node), the eager launches of
+    the same context in between draw theirs from the ring.  Two graphs of one context replayed on two streams at the same
+    time must not share a slot."""
     import torch
     dev = torch.device("cuda:0")
     monkeypatch.setenv("UC_GRID", "3")
@@ -869,9 +870,36 @@ def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch):
     torch.cuda.synchronize()
     assert np.array_equal(sym.cpu().numpy(), want[-1][0])
     assert np.array_equal(st.cpu().numpy().view(np.uint32), want[-1][1].view(np.uint32))
+    # two graphs of ONE context, each with its own output buffers, replayed on two streams without a wait in between
+    sA, sB = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    graphs = []
+    for ss in (sA, sB):
+        sy = torch.zeros(n_frames, dtype=torch.uint8, device=dev)
+        stt = torch.zeros((n_frames, e.spf, 8), dtype=torch.float32, device=dev)
+        gg = torch.cuda.CUDAGraph()
+        ss.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(ss):
+            with torch.cuda.graph(gg, stream=ss):
+                e.process(buf, n_frames=n_frames, symbols_out=sy, stats_out=stt, stream=ss.cuda_stream)
+        graphs.append(gg)
+        outs.append((sy, stt))
+    torch.cuda.synchronize()
+    for rep in range(8):
+        for sy, stt in outs:
+            sy.zero_()
+            stt.zero_()
+        torch.cuda.synchronize()
+        for gg, ss in zip(graphs, (sA, sB)):
+            with torch.cuda.stream(ss):
+                gg.replay()
+        torch.cuda.synchronize()
+        for sy, stt in outs:
+            assert np.array_equal(sy.cpu().numpy(), want[-1][0]), rep
+            assert np.array_equal(stt.cpu().numpy().view(np.uint32), want[-1][1].view(np.uint32)), rep
 
 
-def test_compress_pair_chunks_dynamic_hand_out(uchirp, monkeypatch):
+def test_compress_pair_chunks_dynamic_hand_out(uchirp, monkeypatch, uc_tuning):
     """The compress kernel deals frame PAIRS in chunks of consecutive pairs; a workgroup's first chunk is fixed, every
     further one comes from an atomic counter asked one pair ahead (csrc/uc_full_kernel.hip).  Tiny grids (UC_GRID),
     chunk sizes (UC_COMPRESS_CHUNK), the static partition (UC_STATIC_DEAL) and frame counts around the chunk
@@ -897,7 +925,7 @@ def test_compress_pair_chunks_dynamic_hand_out(uchirp, monkeypatch):
 
 
 @pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX, uco.DECHIRP_DOWN])
-def test_band_frame_groups_dynamic_hand_out(uchirp, variant, monkeypatch):
+def test_band_frame_groups_dynamic_hand_out(uchirp, variant, monkeypatch, uc_tuning):
     """The band kernel deals frames in groups; a workgroup's first group is fixed, every further one comes from an
     atomic counter fetched one group ahead (csrc/uc_band_kernel.hip).  Tiny grids (UC_GRID), small groups
     (UC_BAND_GROUP), the static deal (UC_STATIC_DEAL) and batch sizes around the group boundaries -- a one-frame last

@@ -5,7 +5,7 @@ exact on every clear frame.  The 1 Mi-frame symbol gate of the bench's own batch
 import numpy as np
 import pytest
 
-import synth
+from uchirp import synth
 from oracle import uco
 from parity_util import MAG_TOL, check_history, clear_symbols
 

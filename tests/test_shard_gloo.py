@@ -47,7 +47,7 @@ def _worker(rank, world, port, n_frames, q):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        import synth
+        from uchirp import synth
         from oracle import uco
         frames, bits = synth.make_frames(n_frames, seed=42, snr_db=0.0)
         lo, hi = shard.partition(n_frames, world, rank)

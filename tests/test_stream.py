@@ -9,7 +9,7 @@ and the HIP path against the oracle (GPU tests, through the C-ABI).
 import numpy as np
 import pytest
 
-import synth
+from uchirp import synth
 from oracle import uco
 
 STREAM_TOL = 2e-5  # |GPU - oracle| relative to the largest compressed value of the stream
@@ -177,7 +177,7 @@ def test_stream_edge_sizes(uchirp):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("decim", [4, 8, 16])
-def test_stream_block_chunks_dynamic_hand_out(uchirp, decim, monkeypatch):
+def test_stream_block_chunks_dynamic_hand_out(uchirp, decim, monkeypatch, uc_tuning):
     """The stream kernel deals overlap-save blocks in chunks of consecutive blocks; a workgroup's first chunk is fixed,
     every further one comes from an atomic counter asked one block ahead (csrc/uc_stream_kernel.hip).  Tiny grids
     (UC_GRID), chunk sizes 1 / 2 / 4 / 8 (UC_STREAM_CHUNK), the static partition (UC_STATIC_DEAL) and stream lengths

@@ -15,6 +15,7 @@ from test_stream import _check_stream, make_stream
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+os.environ["UC_TUNING"] = "1"   # the library reads its experiment switches only under UC_TUNING=1
 bad = 0
 for case in range(cases):
     decim = int(rng.choice([4, 8, 16]))

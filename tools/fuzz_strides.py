@@ -11,7 +11,7 @@ sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
 import numpy as np
 import uchirp
 from oracle import uco
-import synth
+from uchirp import synth
 from parity_util import check_history, MARGIN, MAG_TOL
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200

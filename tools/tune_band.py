@@ -26,6 +26,7 @@ for waves in (2, 3, 4):
         configs.append((waves, grid))
 for waves, mult in ((2, 2), (2, 3), (3, 4), (3, 5), (4, 6), (4, 7)):
     configs.append((waves, 256 * mult))
+os.environ["UC_TUNING"] = "1"   # the library reads its experiment switches only under UC_TUNING=1
 engines = []
 for waves, grid in configs:
     os.environ["UC_BAND_WAVES"] = str(waves)

@@ -73,7 +73,13 @@ bool is_device_ptr(const void* p) {
 
 }  // namespace
 
-constexpr unsigned kWorkSlots = 64, kWorkStride = 128;
+// Hand-out counters of the dynamically dealt launches (one 32-bit word each, every word in its own 128-byte line):
+//   slots [0, kWorkSlots)                          a ring for EAGER launches; a slot is reused only after the launch that
+//                                                  last used it has finished (one hipEvent per slot, queried on reuse)
+//   slots [kWorkSlots, kWorkSlots + kGraphSlots)   handed out ONCE each to launches recorded while their stream is being
+//                                                  captured into a hipGraph: the graph owns that slot for the life of the
+//                                                  context, and its zeroing rides in the graph as a memset node
+constexpr unsigned kWorkSlots = 64, kGraphSlots = 960, kWorkStride = 128;
 
 struct uc_ctx {
   uc_config cfg;
@@ -93,11 +99,11 @@ struct uc_ctx {
   DevBuf s_cic_in, s_cic_out;
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
-  int band_blocks_per_cu[3][2] = {{0, 0}, {0, 0}, {0, 0}};  // [mode][dtype]: the instantiations differ in registers
+  int band_blocks_per_cu[2][3][2] = {};  // [wide][mode][dtype]: the instantiations differ in registers
   int full_blocks_per_cu[2] = {0, 0};    // [dtype]: the int32 / f32 instantiations differ in registers
   int iq_blocks_per_cu[2] = {0, 0};
   int stream_blocks_per_cu[2] = {0, 0};
-  DevBuf s_comp, s_peaks;
+  DevBuf s_comp, s_peaks, s_spec;
   DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream: zero-prefixed stream, (up, down) mag_max per frame
   std::vector<float2> h_rx_mag;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID / UC_BAND_GROUP / UC_STATIC_DEAL): not part of the ABI
@@ -120,6 +126,9 @@ struct uc_ctx {
   unsigned int* d_work = nullptr;
   void* h_slot = nullptr;  // uc_process_frame: pinned, device-mapped host memory for one frame and its results
   unsigned work_next = 0;
+  unsigned graph_next = 0;              // graph-owned slots handed out so far (never recycled)
+  hipEvent_t work_ev[kWorkSlots] = {};  // recorded behind the launch that used ring slot i
+  bool work_busy[kWorkSlots] = {};      // slot i has been used and its event not yet seen complete
 };
 
 extern "C" {
@@ -171,96 +180,22 @@ int uc_default_config(int32_t variant, uc_config* cfg) {
   }
 }
 
+// (a table that already lives on the device is overwritten in place: uc_set_table)
 static int upload(void** dst, const void* src, size_t bytes) {
-  hipError_t e = hipMalloc(dst, bytes);
+  hipError_t e = hipSuccess;
+  if (!*dst) e = hipMalloc(dst, bytes);
   if (e != hipSuccess) return hip_fail(e, "hipMalloc(table)");
   e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   if (e != hipSuccess) return hip_fail(e, "hipMemcpy(table)");
   return 0;
 }
 
-int uc_create(const uc_config* cfg, uc_ctx** out) {
-  if (!cfg || !out) return fail(-EINVAL, "uc_create: NULL argument");
-  *out = nullptr;
-  int ndev = 0;
-  hipError_t e = hipGetDeviceCount(&ndev);
-  if (e != hipSuccess || ndev <= 0) {
-    (void)hipGetLastError();
-    return fail(-ENODEV, "uc_create: no HIP device (%s); this library has no CPU path",
-                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
-  }
-  if (cfg->device < 0 || cfg->device >= ndev)
-    return fail(-ENODEV, "uc_create: device %d out of range [0,%d)", (int)cfg->device, ndev);
-  if (cfg->n != (uint32_t)uc::kN && !(cfg->variant == UC_IQ && cfg->n == 1024))
-    return fail(-ENOTSUP, "uc_create: n=%u unsupported (kernels are specialised for n=%d; UC_IQ also takes 1024)",
-                cfg->n, uc::kN);
-
-  uc_ctx* c = new (std::nothrow) uc_ctx();
-  if (!c) return fail(-ENOMEM, "uc_create: out of memory");
-  c->cfg = *cfg;
-  c->device = cfg->device;
-  if (const char* w = getenv("UC_BAND_WAVES")) {
-    const int v = atoi(w);
-    if (v >= 2 && v <= 4) c->band_waves = v;
-  }
-  if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
-  if (const char* g = getenv("UC_BAND_GROUP")) {
-    const int v = atoi(g);
-    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
-  }
-  if (const char* g = getenv("UC_STATIC_DEAL")) c->static_deal = atoi(g) != 0;
-  if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
-  if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
-  if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
-  if (const char* g = getenv("UC_COMPRESS_CHUNK")) {
-    const int v = atoi(g);
-    if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->compress_chunk = v;
-  }
-  if (const char* g = getenv("UC_STREAM_CHUNK")) {
-    const int v = atoi(g);
-    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->stream_chunk = v;
-  }
-  if (const char* g = getenv("UC_IQ_GROUP")) {
-    const int v = atoi(g);
-    if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->iq_group = v;
-  }
-  int rc = uc::build_tables(*cfg, c->tab);
-  if (rc) {
-    delete c;
-    return fail(rc, "uc_create: invalid configuration (rc=%d)", rc);
-  }
-  if (cfg->variant == UC_STREAM) {
-    rc = uc::build_stream_tables(*cfg, c->stab);
-    if (rc) {
-      delete c;
-      return fail(rc, "uc_create: UC_STREAM takes decim 4, 8 or 16 (got %u)", cfg->decim);
-    }
-    c->cfg.decim = c->stab.decim;
-  }
-  if (cfg->variant != UC_IQ && cfg->variant != UC_COMPRESS && cfg->variant != UC_STREAM && c->tab.bandwidth2 > 191) {
-    delete c;
-    return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the 191-bin window the kernel evaluates",
-                c->tab.bandwidth2);
-  }
-  const bool iq_bb = cfg->variant == UC_IQ && (cfg->flags & UC_FLAG_IQ_BASEBAND) != 0;
-  if (cfg->variant == UC_IQ && c->tab.bandwidth4 > (cfg->n == 1024 ? 128u : 256u)) {
-    delete c;
-    return fail(-ENOTSUP, "uc_create: IQ window of %u bins exceeds the 256 the kernel evaluates", c->tab.bandwidth4);
-  }
-  e = hipSetDevice(c->device);
-  if (e != hipSuccess) {
-    delete c;
-    return hip_fail(e, "hipSetDevice");
-  }
-  hipDeviceProp_t prop;
-  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
-    c->num_cu = prop.multiProcessorCount;
-
+// The fused device tables of a context (reference * Hann etc.), from the host tables in c->tab / c->stab.
+// Called by uc_create and again by uc_set_table.
+static int upload_device_tables(uc_ctx* c) {
+  const uc_config* cfg = &c->cfg;
   const uint32_t n = cfg->n;
-  std::vector<float> tw;
-  uc::build_twiddles(n, tw);
-  rc = upload((void**)&c->d_tw, tw.data(), tw.size() * sizeof(float));
-
+  const bool iq_bb = cfg->variant == UC_IQ && (cfg->flags & UC_FLAG_IQ_BASEBAND) != 0;
   std::vector<float> t0(2 * (size_t)n, 0.0f), t1(2 * (size_t)n, 0.0f), t2;
   const uc::Tables& T = c->tab;
   switch (cfg->variant) {
@@ -327,13 +262,108 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     default:
       break;
   }
-  if (!rc) {
-    e = hipMalloc((void**)&c->d_work, (size_t)kWorkSlots * kWorkStride);
-    if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(work counters)");
-  }
-  if (!rc) rc = upload((void**)&c->d_tab0, t0.data(), t0.size() * sizeof(float));
+  int rc = upload((void**)&c->d_tab0, t0.data(), t0.size() * sizeof(float));
   if (!rc) rc = upload((void**)&c->d_tab1, t1.data(), t1.size() * sizeof(float));
   if (!rc && !t2.empty()) rc = upload((void**)&c->d_tab2, t2.data(), t2.size() * sizeof(float));
+  return rc;
+}
+
+int uc_create(const uc_config* cfg, uc_ctx** out) {
+  if (!cfg || !out) return fail(-EINVAL, "uc_create: NULL argument");
+  *out = nullptr;
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev <= 0) {
+    (void)hipGetLastError();
+    return fail(-ENODEV, "uc_create: no HIP device (%s); this library has no CPU path",
+                e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+  }
+  if (cfg->device < 0 || cfg->device >= ndev)
+    return fail(-ENODEV, "uc_create: device %d out of range [0,%d)", (int)cfg->device, ndev);
+  if (cfg->n != (uint32_t)uc::kN && !(cfg->variant == UC_IQ && cfg->n == 1024))
+    return fail(-ENOTSUP, "uc_create: n=%u unsupported (kernels are specialised for n=%d; UC_IQ also takes 1024)",
+                cfg->n, uc::kN);
+
+  uc_ctx* c = new (std::nothrow) uc_ctx();
+  if (!c) return fail(-ENOMEM, "uc_create: out of memory");
+  c->cfg = *cfg;
+  c->device = cfg->device;
+  // Experiment switches (grid size, group sizes, static deal, kernel variants): NOT part of the ABI.  They are read only
+  // when UC_TUNING=1 is set as well, so that a stray variable in a production environment changes nothing.
+  const char* tuning = getenv("UC_TUNING");
+  if (tuning && atoi(tuning) != 0) {
+    if (const char* w = getenv("UC_BAND_WAVES")) {
+      const int v = atoi(w);
+      if (v >= 2 && v <= 4) c->band_waves = v;
+    }
+    if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
+    if (const char* g = getenv("UC_BAND_GROUP")) {
+      const int v = atoi(g);
+      if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
+    }
+    if (const char* g = getenv("UC_STATIC_DEAL")) c->static_deal = atoi(g) != 0;
+    if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
+    if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
+    if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
+    if (const char* g = getenv("UC_COMPRESS_CHUNK")) {
+      const int v = atoi(g);
+      if (v >= 2 && v <= 64 && (v & (v - 1)) == 0) c->compress_chunk = v;
+    }
+    if (const char* g = getenv("UC_STREAM_CHUNK")) {
+      const int v = atoi(g);
+      if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->stream_chunk = v;
+    }
+    if (const char* g = getenv("UC_IQ_GROUP")) {
+      const int v = atoi(g);
+      if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->iq_group = v;
+    }
+  }
+  int rc = uc::build_tables(*cfg, c->tab);
+  if (rc) {
+    delete c;
+    return fail(rc, "uc_create: invalid configuration (rc=%d)", rc);
+  }
+  if (cfg->variant == UC_STREAM) {
+    rc = uc::build_stream_tables(*cfg, c->stab);
+    if (rc) {
+      delete c;
+      return fail(rc, "uc_create: UC_STREAM takes decim 4, 8 or 16 (got %u)", cfg->decim);
+    }
+    c->cfg.decim = c->stab.decim;
+  }
+  if (cfg->variant != UC_IQ && cfg->variant != UC_COMPRESS && cfg->variant != UC_STREAM &&
+      c->tab.bandwidth2 > (uint32_t)uc::kBandWideMax) {
+    delete c;
+    return fail(-ENOTSUP, "uc_create: bandwidth2=%u exceeds the %d-bin window the kernel evaluates",
+                c->tab.bandwidth2, uc::kBandWideMax);
+  }
+  if (cfg->variant == UC_IQ && c->tab.bandwidth4 > (cfg->n == 1024 ? 128u : 256u)) {
+    delete c;
+    return fail(-ENOTSUP, "uc_create: IQ window of %u bins exceeds the 256 the kernel evaluates", c->tab.bandwidth4);
+  }
+  e = hipSetDevice(c->device);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_fail(e, "hipSetDevice");
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, c->device) == hipSuccess && prop.multiProcessorCount > 0)
+    c->num_cu = prop.multiProcessorCount;
+
+  const uint32_t n = cfg->n;
+  std::vector<float> tw;
+  uc::build_twiddles(n, tw);
+  rc = upload((void**)&c->d_tw, tw.data(), tw.size() * sizeof(float));
+
+  if (!rc) {
+    e = hipMalloc((void**)&c->d_work, (size_t)(kWorkSlots + kGraphSlots) * kWorkStride);
+    if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(work counters)");
+    for (unsigned i = 0; !rc && i < kWorkSlots; i++) {
+      e = hipEventCreateWithFlags(&c->work_ev[i], hipEventDisableTiming);
+      if (e != hipSuccess) { c->work_ev[i] = nullptr; rc = hip_fail(e, "hipEventCreate(work counter)"); }
+    }
+  }
+  if (!rc) rc = upload_device_tables(c);
   if (!rc && cfg->variant == UC_IQ) {
     // the taps as the A operand of v_mfma_f32_16x16x4_f32: lane l = (k = l >> 4, i = l & 15) of k-step s holds
     // T[i][4 s + k] = fir[i + 26 - (4 s + k)] (0 outside the taps): output i of a 16-output block sees the
@@ -342,7 +372,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     for (int s = 0; s < 11; s++)
       for (int l = 0; l < 64; l++) {
         const int d = (l & 15) + 26 - (4 * s + (l >> 4));
-        if (d >= 0 && d < uc::kFirTaps) fa[(size_t)s * 64 + l] = T.fir[(size_t)d];
+        if (d >= 0 && d < uc::kFirTaps) fa[(size_t)s * 64 + l] = c->tab.fir[(size_t)d];
       }
     rc = upload((void**)&c->d_aux, fa.data(), fa.size() * sizeof(float));
   }
@@ -362,6 +392,8 @@ void uc_destroy(uc_ctx* c) {
   if (c->d_tab2) (void)hipFree(c->d_tab2);
   if (c->d_tw) (void)hipFree(c->d_tw);
   if (c->d_work) (void)hipFree(c->d_work);
+  for (unsigned i = 0; i < kWorkSlots; i++)
+    if (c->work_ev[i]) (void)hipEventDestroy(c->work_ev[i]);
   if (c->h_slot) (void)hipHostFree(c->h_slot);
   if (c->d_cic_ctr) (void)hipFree(c->d_cic_ctr);
   if (c->d_aux) (void)hipFree(c->d_aux);
@@ -375,6 +407,7 @@ void uc_destroy(uc_ctx* c) {
   c->s_stats.release();
   c->s_comp.release();
   c->s_peaks.release();
+  c->s_spec.release();
   c->s_rx_pad.release();
   c->s_rx_mag.release();
   delete c;
@@ -433,23 +466,54 @@ int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
   return (int32_t)((ifs * (n - idx) / n) * 0xFFFFFFFFu);
 }
 
-// The counter of one dynamically dealt launch: a slot of the context's ring, zeroed on `stream` right before the
-// launch.  nullptr (static deal) while `stream` is being captured into a graph: a replayed graph would keep using the
-// slot it was captured with, next to whatever eager launch the ring hands the same slot to later.
-static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out) {
+// The counter of one dynamically dealt launch, zeroed on `stream` right in front of the launch.
+//   eager launch : the next slot of the context's ring; *slot = its index (pass it to work_counter_launched() behind
+//                  the launch).  If the launch that last used that slot is still running (64 or more launches of ONE
+//                  context in flight on several streams) the counter would be shared: *out = nullptr, the caller deals
+//                  this launch statically.
+//   capture      : a slot the graph owns from now on (kGraphSlots per context, never recycled); the hipMemsetAsync is
+//                  recorded as a memset node in front of the kernel node, so every replay starts from zero and two
+//                  graphs replayed on two streams never share a counter.  *slot = -1.  When the graph slots are used
+//                  up: nullptr (static deal).
+static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, int* slot) {
   *out = nullptr;
+  *slot = -1;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-  if (stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return 0;
-  unsigned int* w = (unsigned int*)((char*)c->d_work + (size_t)(c->work_next++ % kWorkSlots) * kWorkStride);
+  const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  unsigned idx;
+  if (capturing) {
+    if (c->graph_next >= kGraphSlots) return 0;
+    idx = kWorkSlots + c->graph_next++;
+  } else {
+    idx = c->work_next % kWorkSlots;
+    if (c->work_busy[idx]) {
+      const hipError_t q = hipEventQuery(c->work_ev[idx]);
+      if (q == hipErrorNotReady) return 0;  // still in flight: do not advance, deal this launch statically
+      if (q != hipSuccess) return hip_fail(q, "hipEventQuery(work counter)");
+      c->work_busy[idx] = false;
+    }
+    c->work_next++;
+    *slot = (int)idx;
+  }
+  unsigned int* w = (unsigned int*)((char*)c->d_work + (size_t)idx * kWorkStride);
   const hipError_t e = hipMemsetAsync(w, 0, sizeof(unsigned int), stream);
   if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(work counter)");
   *out = w;
   return 0;
 }
 
+// behind the launch that uses ring slot `slot` (no-op for -1: static deal or a graph-owned slot)
+static int work_counter_launched(uc_ctx* c, hipStream_t stream, int slot) {
+  if (slot < 0) return 0;
+  const hipError_t e = hipEventRecord(c->work_ev[slot], stream);
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(work counter)");
+  c->work_busy[slot] = true;
+  return 0;
+}
+
 static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                               const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream,
-                              bool mapped = false);
+                              bool mapped = false, float* d_spectrum = nullptr);
 
 int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                      const float* mag_mean, uint8_t* symbols, uc_stats* stats, void* hip_stream) {
@@ -458,9 +522,10 @@ int uc_process_batch(uc_ctx* c, const void* frames, int dtype, size_t n_frames, 
 
 // d_magmax: device, (up, down) mag_max per frame, nullable (internal: uc_receive_stream)
 // mapped  : every pointer is device-accessible as it stands (internal: the pinned, mapped frame slot of uc_process_frame)
+// d_spectrum: device, the window bins of every frame (internal: uc_window_spectrum; band variants only)
 static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                               const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream,
-                              bool mapped) {
+                              bool mapped, float* d_spectrum) {
   if (!c) return fail(-EINVAL, "uc_process_batch: NULL ctx");
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32)
     return fail(-EINVAL, "uc_process_batch: dtype %d is neither UC_DTYPE_I32 nor UC_DTYPE_F32", dtype);
@@ -559,15 +624,17 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
       if (grid > ngroups) grid = ngroups;
     }
     ip.work_ctr = nullptr;
+    int wslot = -1;
     if (!c->static_deal && ip.group >= 2) {
       const size_t ngroups = (n_frames + ip.group - 1) / ip.group;
       if (ngroups > grid) {  // dynamic hand-out
-        const int wrc = take_work_counter(c, stream, &ip.work_ctr);
+        const int wrc = take_work_counter(c, stream, &ip.work_ctr, &wslot);
         if (wrc) return wrc;
       }
     }
     int lrc = uc::launch_iq(dtype, ip, (int)grid, stream, (int)n);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "iq kernel launch");
+    if (int erc = work_counter_launched(c, stream, wslot)) return erc;
     goto copy_back;
   }
   if (variant == UC_COMPRESS) {
@@ -592,8 +659,9 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     if (grid > npairs) grid = npairs;
     fp.work_ctr = nullptr;
     fp.chunk_log2 = 0;
+    int wslot = -1;
     if (!c->static_deal && c->compress_chunk >= 2 && npairs > (size_t)c->compress_chunk * grid) {  // more chunks than workgroups
-      const int wrc = take_work_counter(c, stream, &fp.work_ctr);  // dynamic hand-out of chunks of consecutive pairs
+      const int wrc = take_work_counter(c, stream, &fp.work_ctr, &wslot);  // dynamic hand-out of chunks of consecutive pairs
       if (wrc) return wrc;
       if (fp.work_ctr) {
         while ((1u << fp.chunk_log2) < (unsigned)c->compress_chunk) fp.chunk_log2++;
@@ -603,6 +671,7 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     }
     int lrc = uc::launch_compress(dtype, fp, (int)grid, stream);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "compress kernel launch");
+    if (int erc = work_counter_launched(c, stream, wslot)) return erc;
     goto copy_back;
   }
   {
@@ -618,6 +687,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   p.symbols = d_sym;
   p.stats = d_stats;
   p.magmax = d_magmax;
+  p.spectrum = d_spectrum;
+  p.wide = (c->tab.bandwidth2 > (uint32_t)uc::kBandNarrowMax || d_spectrum) ? 1u : 0u;
   p.mag_mean_scalar = c->cfg.mag_mean;
   p.snr_threshold = c->cfg.snr_threshold;
   p.bw2 = c->tab.bandwidth2;
@@ -630,8 +701,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
 #endif
   const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
                    : (variant == UC_DECHIRP_DOWN) ? uc::kModePair : uc::kModeRxReal;
-  int& bpc = c->band_blocks_per_cu[mode][dtype == UC_DTYPE_I32 ? 0 : 1];
-  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, c->band_waves);
+  int& bpc = c->band_blocks_per_cu[p.wide][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
+  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, c->band_waves, p.wide != 0);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   // units of work: frames, or frame pairs (DECHIRP_DOWN).  Groups of `band_group` units; smaller ones when the batch
@@ -646,12 +717,14 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   p.group_log2 = 0;
   while ((1u << p.group_log2) < group) p.group_log2++;
   p.work_ctr = nullptr;
+  int wslot = -1;
   if (!c->static_deal && group >= 2 && ngroups > grid) {
-    const int wrc = take_work_counter(c, stream, &p.work_ctr);  // dynamic hand-out
+    const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
     if (wrc) return wrc;
   }
   int lrc = uc::launch_band(mode, dtype, c->band_waves, p, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
+  if (int erc = work_counter_launched(c, stream, wslot)) return erc;
   }
 copy_back:
 
@@ -664,6 +737,67 @@ copy_back:
       e = hipMemcpyAsync(stats, d_stats, n_frames * (size_t)spf * sizeof(uc_stats), hipMemcpyDeviceToHost, stream);
       if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(stats)");
     }
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  }
+  return 0;
+}
+
+int uc_set_table(uc_ctx* c, int table_id, const float* data, size_t count) {
+  if (!c || !data) return fail(-EINVAL, "uc_set_table: NULL argument");
+  const int v = c->cfg.variant;
+  if (v != UC_RX_REAL && v != UC_SYNC_CPLX && v != UC_DECHIRP_DOWN)
+    return fail(-ENOTSUP, "uc_set_table: variant %d derives further tables from its references (RX_REAL, SYNC_CPLX, "
+                          "DECHIRP_DOWN only)", v);
+  std::vector<float>* dst = nullptr;
+  switch (table_id) {
+    case UC_TABLE_UP: dst = &c->tab.up; break;
+    case UC_TABLE_DOWN: dst = &c->tab.down; break;
+    case UC_TABLE_HANN: dst = &c->tab.hann; break;
+    default: return fail(-EINVAL, "uc_set_table: table %d cannot be replaced (UC_TABLE_UP, _DOWN, _HANN)", table_id);
+  }
+  if (dst->empty()) return fail(-ENOENT, "uc_set_table: table %d does not exist for this variant", table_id);
+  if (count != dst->size()) return fail(-EINVAL, "uc_set_table: table %d holds %zu floats, got %zu", table_id, dst->size(), count);
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  e = hipDeviceSynchronize();  // no launch of this context may still be reading the old tables
+  if (e != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
+  memcpy(dst->data(), data, count * sizeof(float));
+  return upload_device_tables(c);
+}
+
+int uc_window_bins(const uc_ctx* c) {
+  if (!c) return fail(-EINVAL, "uc_window_bins: NULL ctx");
+  const int v = c->cfg.variant;
+  if (v != UC_RX_REAL && v != UC_SYNC_CPLX && v != UC_DECHIRP_DOWN)
+    return fail(-ENOTSUP, "uc_window_bins: variant %d has no windows around DC", v);
+  return (int)(2 * c->tab.bandwidth2 + 1);
+}
+
+int uc_window_spectrum(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems, float* mags,
+                       void* hip_stream) {
+  if (!c) return fail(-EINVAL, "uc_window_spectrum: NULL ctx");
+  const int wb = uc_window_bins(c);
+  if (wb < 0) return wb;
+  if (n_frames == 0) return 0;
+  if (!mags) return fail(-EINVAL, "uc_window_spectrum: mags is NULL");
+  const size_t count = n_frames * (size_t)uc_stats_per_frame(c) * (size_t)wb;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  float* d_out = mags;
+  const bool host_out = !is_device_ptr(mags);
+  if (host_out) {
+    const int rc = c->s_spec.ensure(count * sizeof(float));
+    if (rc) return rc;
+    d_out = (float*)c->s_spec.p;
+  }
+  const int rc = process_batch_impl(c, frames, dtype, n_frames, stride_elems, nullptr, nullptr, nullptr, nullptr, hip_stream,
+                                    false, d_out);
+  if (rc) return rc;
+  if (host_out) {
+    e = hipMemcpyAsync(mags, d_out, count * sizeof(float), hipMemcpyDeviceToHost, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(window spectrum)");
     e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
   }
@@ -832,9 +966,10 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
   if (n_blocks >= ((size_t)1 << 32)) return fail(-EINVAL, "uc_process_stream: at most 2^32 - 1 blocks per call");
   sp.work_ctr = nullptr;
   sp.chunk_log2 = 0;
+  int wslot = -1;
   if (!c->static_deal && n_blocks > (size_t)c->stream_chunk * grid) {  // more chunks than workgroups
     // dynamic hand-out of chunks of consecutive blocks
-    const int wrc = take_work_counter(c, stream, &sp.work_ctr);
+    const int wrc = take_work_counter(c, stream, &sp.work_ctr, &wslot);
     if (wrc) return wrc;
     if (sp.work_ctr) {
       while ((1u << sp.chunk_log2) < (unsigned)c->stream_chunk) sp.chunk_log2++;
@@ -844,6 +979,7 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
   }
   int lrc = uc::launch_stream(dtype, D, sp, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "stream kernel launch");
+  if (int erc = work_counter_launched(c, stream, wslot)) return erc;
 
   if (any_host_out) {
     if (compressed && d_comp != compressed) {

@@ -113,6 +113,44 @@ __device__ __forceinline__ Partial window_partial(float vr0, float vl0, int k0, 
   return o;
 }
 
+// WIDE build (bandwidth2 of 192 .. 319 bins: receivers below ~64 kHz for the 16-19 kHz band, receiver/Src/main.c:372-374
+// derives `bandwidth` for any sampling rate): up to NS candidate slots per lane, k[s] = 0x3fffffff where a lane has none.
+template <int NS>
+__device__ __forceinline__ Partial window_partial_n(const float (&vr)[NS], const float (&vl)[NS], const int (&k)[NS],
+                                                    int bw2) {
+  const float ninf = -INFINITY;
+  float r[NS], l[NS];
+  float mr = ninf, ml = ninf;
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    r[s] = (k[s] < bw2) ? vr[s] : ninf;
+    l[s] = (k[s] >= 1 && k[s] <= bw2) ? vl[s] : ninf;
+    mr = max_f32(mr, r[s]);
+    ml = max_f32(ml, l[s]);
+  }
+  Partial o;
+  o.vr = wave_max_f32(mr);
+  o.vl = wave_max_f32(ml);
+  int cr = 0x7fffffff, cl = -1;
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    if (r[s] == o.vr && k[s] < cr) cr = k[s];
+    if (l[s] == o.vl && k[s] > cl) cl = k[s];
+  }
+  o.kr = wave_min_u32(cr);
+  o.kl = wave_max_i32(cl);
+  if (o.kr == 0x7fffffff) o.kr = 0;
+  if (o.kl < 0) o.kl = 0;
+  bool nfr = false, nfl = false;
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    nfr = nfr || (k[s] == 0 && vr[s] != vr[s]);
+    nfl = nfl || (k[s] == bw2 && vl[s] != vl[s]);
+  }
+  o.nan_first = (__ballot(nfr) ? 1u : 0u) | (__ballot(nfl) ? 2u : 0u);
+  return o;
+}
+
 // RX_REAL: both windows of a history look at the SAME magnitudes; they differ only in
 // bin 0 (right window only) and bin bw2 (left window only).  So one maximum over the
 // common bins [1, bw2) with its smallest and its largest attaining bin serves both, and
@@ -269,7 +307,9 @@ __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
 #define UC_STAMP(k) do { } while (0)
 #endif
 
-template <int MODE, int DTYPE, int WAVES>
+// WIDE: windows of up to 319 bins (three pruned-pass rounds, generic window search, 16-bit indices in the ring);
+// built at 2 waves/SIMD only.  The default build (windows of up to 191 bins) is untouched by it.
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false>
 __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #ifdef UC_STAMPS
   unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -363,6 +403,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // pass-3 twiddles: W_2048^j and its square (the pruned pass is evaluated in Horner form)
   const v2f tw3_1 = ld_tw(p.tw, j), tw3_2 = ld_tw(p.tw, 2 * j);
   const v2f K = mkv(kCos8, kSin8), H = mkv(kSqrtHalfF, kSqrtHalfF);  // SGPR pairs
+  // WIDE: W^i and W^2i of the bins i = 128 + j (both waves) and 256 + lane (wave 1) of rounds 1 and 2
+  v2f tw3w[2][2];
+  if (WIDE) {
+    tw3w[0][0] = ld_tw(p.tw, 128 + j);
+    tw3w[0][1] = ld_tw(p.tw, 2 * (128 + j));
+    tw3w[1][0] = ld_tw(p.tw, 256 + lane);
+    tw3w[1][1] = ld_tw(p.tw, 2 * (256 + lane));
+  }
 
   // LDS addresses (complex units)
   // exchange 1: element o = 16 j + t lives at o ^ (((o >> 4) & 7) << 1): bit 0 untouched, so the
@@ -412,8 +460,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       int kr, kl;
       // the ring holds squared magnitudes (x4 for RX_REAL): |X| = mscale * sqrt(q)
       const float mscale = kReal ? 0.5f : 1.0f;
-      unsigned kp0, kp1, fl = 0;
-      if (kReal) {
+      unsigned kp0 = 0, kp1 = 0, fl = 0;
+      if (WIDE) {
+        // per wave: [up right, up left, down right, down left, (kr, kl) of up, (kr, kl) of down], 16 bits per index
+        kp0 = __float_as_uint(e[4]);
+        kp1 = __float_as_uint(e[6 + 4]);
+        merge_window(e[0], kp0 & 0x7fff, e[6 + 0], kp1 & 0x7fff, true, ((kp0 | kp1) >> 15) & 1u, 0, mr, kr);
+        merge_window(e[1], (kp0 >> 16) & 0x7fff, e[6 + 1], (kp1 >> 16) & 0x7fff, false, ((kp0 | kp1) >> 31) & 1u, bw2, ml, kl);
+      } else if (kReal) {
         // per wave: [M_up, M_dn, kpack, edge_up, edge_dn]; wave 0's edge = bin 0, wave 1's = bin bw2
         kp0 = __float_as_uint(e[2]);
         kp1 = __float_as_uint(e[6 + 2]);
@@ -430,7 +484,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       ml = mscale * sqrtf(ml);
       const Hist h0 = make_hist(mr, kr, ml, kl, mm_up, p.ifs, kPair);
       {
-        if (kReal) {
+        if (WIDE) {
+          kp0 = __float_as_uint(e[5]);
+          kp1 = __float_as_uint(e[6 + 5]);
+          merge_window(e[2], kp0 & 0x7fff, e[6 + 2], kp1 & 0x7fff, true, ((kp0 | kp1) >> 15) & 1u, 0, mr, kr);
+          merge_window(e[3], (kp0 >> 16) & 0x7fff, e[6 + 3], (kp1 >> 16) & 0x7fff, false, ((kp0 | kp1) >> 31) & 1u, bw2, ml, kl);
+        } else if (kReal) {
           resolve_windows(e[1], (kp0 >> 16) & 255, (kp0 >> 24) & 255, e[6 + 1], (kp1 >> 16) & 255, (kp1 >> 24) & 255,
                           e[4], e[6 + 4], bw2, mr, kr, ml, kl);
         } else {
@@ -508,6 +567,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     constexpr int kRuns = (MODE == kModeCplx) ? 2 : 1;
     float pv[4] = {0.f, 0.f, 0.f, 0.f};  // this wave's partials: up right/left, down right/left
     unsigned kpack = 0, flags = 0;
+    unsigned kpw[2] = {0, 0};            // WIDE: (kr, kl) of a run as 2 x (15 bits + first-element-NaN flag)
     UC_STAMP(9);
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
@@ -601,6 +661,111 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // owns the finaliser).  A round is latency- not throughput-bound: splitting round 1
       // into one dot product per wave was measured SLOWER (both waves then pay a round).
       // RX_REAL: first = |A[i]| (up), second = |B[i]| (down); CPLX: |Z[i]|, |Z[n-i]|.
+      if constexpr (WIDE) {
+        // Windows of up to 319 bins: three rounds -- bins j and 128 + j on both waves, 256 + lane on wave 1 -- with the
+        // twiddles of rounds 1 and 2 resident, then the generic window search over the lane's three candidates.
+        float qa[3] = {0.f, 0.f, 0.f}, qb[3] = {0.f, 0.f, 0.f};
+        int kb[3];
+        kb[0] = j;
+        kb[1] = 128 + j;
+        kb[2] = (wave == 1) ? 256 + lane : 0x3fffffff;
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const int i = kb[r];
+          if (i <= bw2) {
+            const int ia = i & 255, ib = (256 - i) & 255;
+            v2f av[8], bv[8];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+              av[t] = lds_ld(lds, ia + 256 * t);
+              bv[t] = lds_ld(lds, ib + 256 * t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const v2f w1 = (r == 0) ? t3a : tw3w[r == 1 ? 0 : 1][0];
+            const v2f w2 = (r == 0) ? t3b : tw3w[r == 1 ? 0 : 1][1];
+            v2f el = pk_cfma(av[6], w2, av[4]), ol = pk_cfma(av[7], w2, av[5]);
+            v2f eh = pk_cfmac(bv[6], w2, bv[4]), oh = pk_cfmac(bv[7], w2, bv[5]);
+            el = pk_cfma(el, w2, av[2]); ol = pk_cfma(ol, w2, av[3]);
+            eh = pk_cfmac(eh, w2, bv[2]); oh = pk_cfmac(oh, w2, bv[3]);
+            el = pk_cfma(el, w2, av[0]); ol = pk_cfma(ol, w2, av[1]);
+            eh = pk_cfmac(eh, w2, bv[0]); oh = pk_cfmac(oh, w2, bv[1]);
+            const v2f zn = el - ol;               // bin 0 only: Z[n/2]
+            const v2f zl = pk_cfma(ol, w1, el);   // Z[k]
+            const v2f zh = pk_cfmac(oh, w1, eh);  // Z[n-k]
+            if (kReal) {
+              const v2f sa = pk_add_conj(zl, zh);  // 2 A[k]
+              const v2f sb = pk_sub_conj(zl, zh);  // 2j B[k]
+              float ma = sa.x * sa.x + sa.y * sa.y, mb = sb.x * sb.x + sb.y * sb.y;
+              if (r == 0 && i == 0) {  // Q2, as in the default build below
+                ma = sa.x * sa.x;
+                mb = sb.y * sb.y;
+                if (!p.true_dc) {
+                  ma += 4.0f * (zn.x * zn.x);
+                  mb += 4.0f * (zn.y * zn.y);
+                }
+              }
+              qa[r] = ma;
+              qb[r] = mb;
+            } else {
+              qa[r] = zl.x * zl.x + zl.y * zl.y;
+              qb[r] = zh.x * zh.x + zh.y * zh.y;
+            }
+            if (p.spectrum) {
+              // uc_window_spectrum: the magnitudes pipeline() leaves in signal[] (receiver/Src/main.c:176-179), for the
+              // bins dsp() looks at.  Real reference(s): both sides of DC carry the same value (Hermitian mirror, Q1).
+              const size_t wb = 2 * (size_t)bw2 + 1;
+              const float va = (kReal ? 0.5f : 1.0f) * sqrtf(qa[r]);  // (the finaliser's own expression: bit-equal to the stats)
+              const float vb = (kReal ? 0.5f : 1.0f) * sqrtf(qb[r]);
+              if (MODE == kModeCplx) {
+                float* o = p.spectrum + ((size_t)f * 2 + run) * wb + bw2;
+                o[i] = va;
+                if (i) o[-i] = vb;
+              } else if (kPair) {
+                const size_t fa = (size_t)f << psh;
+                float* oa = p.spectrum + fa * wb + bw2;
+                oa[i] = va;
+                oa[-i] = va;
+                if (psh && fa + 1 < p.n_frames) {
+                  float* ob = oa + wb;
+                  ob[i] = vb;
+                  ob[-i] = vb;
+                }
+              } else {
+                float* o = p.spectrum + (size_t)f * 2 * wb + bw2;
+                o[i] = va;
+                o[-i] = va;
+                o[wb + i] = vb;
+                o[wb - i] = vb;
+              }
+            }
+          }
+        }
+        UC_STAMP(6);
+        auto pack16 = [](const Partial& q) {
+          return ((unsigned)q.kr | ((q.nan_first & 1u) << 15)) | (((unsigned)q.kl | ((q.nan_first & 2u) << 14)) << 16);
+        };
+        float* e = ring + ring_n * kRingStride + wave * 6;
+        if (kReal) {
+          // the up history looks at qa in both windows, the down history at qb
+          const Partial qu = window_partial_n<3>(qa, qa, kb, bw2);
+          const Partial qd = window_partial_n<3>(qb, qb, kb, bw2);
+          if (lane == 0) {
+            e[0] = qu.vr; e[1] = qu.vl; e[2] = qd.vr; e[3] = qd.vl;
+            e[4] = __uint_as_float(pack16(qu));
+            e[5] = __uint_as_float(pack16(qd));
+          }
+        } else {
+          const Partial q = window_partial_n<3>(qa, qb, kb, bw2);
+          pv[2 * run] = q.vr;
+          pv[2 * run + 1] = q.vl;
+          kpw[run] = pack16(q);
+          if (run == kRuns - 1 && lane == 0) {
+            e[0] = pv[0]; e[1] = pv[1]; e[2] = pv[2]; e[3] = pv[3];
+            e[4] = __uint_as_float(kpw[0]);
+            e[5] = __uint_as_float(kpw[1]);
+          }
+        }
+      } else {
       float m_a[2] = {0.f, 0.f}, m_b[2] = {0.f, 0.f};
 #pragma unroll
       for (int r = 0; r < 2; r++) {
@@ -714,6 +879,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           e[5] = __uint_as_float(flags);
         }
       }
+      }
       UC_STAMP(8);
       __builtin_amdgcn_s_setprio(2);
       if (run == kRuns - 1) ring_n++;
@@ -744,16 +910,16 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #endif
 }
 
-template <int MODE, int DTYPE, int WAVES>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false>
 static int launch_one(const BandParams& p, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES, WIDE>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
   return (int)hipGetLastError();
 }
 
-template <int MODE, int DTYPE, int WAVES>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false>
 static int occupancy_one() {
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES>, T, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES, WIDE>, T, 0);
   if (e != hipSuccess || nb <= 0) nb = 2 * WAVES;
   return nb;
 }
@@ -762,6 +928,18 @@ static int occupancy_one() {
 
 #define UC_DISPATCH(FN, ...)                                                              \
   do {                                                                                    \
+    if (wide) { /* windows of 192 .. 319 bins: one build per mode and dtype */             \
+      if (mode == kModePair) {                                                            \
+        if (dtype == UC_DTYPE_I32) return FN<kModePair, UC_DTYPE_I32, 2, true>(__VA_ARGS__);   \
+        return FN<kModePair, UC_DTYPE_F32, 2, true>(__VA_ARGS__);                         \
+      }                                                                                   \
+      if (mode == kModeRxReal) {                                                          \
+        if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 2, true>(__VA_ARGS__); \
+        return FN<kModeRxReal, UC_DTYPE_F32, 2, true>(__VA_ARGS__);                       \
+      }                                                                                   \
+      if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, true>(__VA_ARGS__);     \
+      return FN<kModeCplx, UC_DTYPE_F32, 2, true>(__VA_ARGS__);                           \
+    }                                                                                     \
     if (mode == kModePair) { /* one build: 3 waves/SIMD */                                \
       if (dtype == UC_DTYPE_I32) return FN<kModePair, UC_DTYPE_I32, 3>(__VA_ARGS__);      \
       return FN<kModePair, UC_DTYPE_F32, 3>(__VA_ARGS__);                                 \
@@ -788,10 +966,11 @@ static int occupancy_one() {
 
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream) {
   if (grid <= 0) return (int)hipSuccess;
+  const bool wide = p.wide != 0;
   UC_DISPATCH(launch_one, p, grid, stream);
 }
 
-int band_max_blocks_per_cu(int mode, int dtype, int waves) {
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide) {
   UC_DISPATCH(occupancy_one);
 }
 

@@ -11,6 +11,8 @@ namespace uc {
 
 constexpr int kN = 2048;          // frame length all kernels are specialised for
 constexpr int kBandThreads = 128; // one 16x16x8 frame per 2-wave workgroup
+constexpr int kBandNarrowMax = 191; // largest bandwidth2 of the default band-kernel build (bins 0 .. 191 in two rounds)
+constexpr int kBandWideMax = 319;   // ... of the WIDE build (three rounds), the largest window the library evaluates
 
 // Band pipeline: RX_REAL, SYNC_CPLX, DECHIRP_DOWN (windows around DC only).
 struct BandParams {
@@ -25,9 +27,12 @@ struct BandParams {
   uc_stats* stats;        // device or nullptr
   float2* magmax;         // device or nullptr: (up, down) mag_max of every frame only (uc_receive_stream's replay needs no
                           // more: 8 instead of 64 bytes per frame to bring back); RX_REAL / SYNC_CPLX
+  float* spectrum;        // device or nullptr (WIDE build only): |X| of the window bins -bw2 .. +bw2 of every history,
+                          // [frame][history][2 bw2 + 1], entry bw2 + k = bin k (k < 0: bin n + k) -- uc_window_spectrum
+  uint32_t wide;          // 1 = the WIDE build (bw2 > kBandNarrowMax, or spectrum != nullptr)
   float mag_mean_scalar;
   float snr_threshold;
-  uint32_t bw2;           // window length (<= 255)
+  uint32_t bw2;           // window length (<= kBandWideMax; > kBandNarrowMax selects the WIDE build)
   uint32_t ifs;           // (uint32_t)(int32_t)fs for idx2freq
   uint32_t true_dc;       // UC_FLAG_TRUE_DC
   uint32_t group_log2;    // log2 of the frames (PAIR: frame pairs) per group: 1..6 with work_ctr, 0..6 without
@@ -44,7 +49,7 @@ enum BandMode { kModeRxReal = 0, kModeCplx = 1, kModePair = 2 };
 // returns hipError_t as int
 // `waves` = min waves per SIMD the kernel was compiled for (2, 3 or 4): a tuning knob
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
-int band_max_blocks_per_cu(int mode, int dtype, int waves);
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide);
 
 // Full-spectrum pipeline: UC_COMPRESS (FFT x H x IFFT, two frames per complex transform).
 struct FullParams {

@@ -30,7 +30,8 @@ FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP, FLAG_IQ_BASEBAND, FLAG_NO_FRAME_PA
 EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", "uc_destroy",
            "uc_process_frame", "uc_process_batch", "uc_stats_per_frame", "uc_iq_halo",
            "uc_get_table", "uc_get_windows", "uc_idx2freq", "uc_receive_stream", "uc_receive_stream_isr",
-           "uc_stream_geometry", "uc_process_stream", "uc_dfsdm_sinc5"]
+           "uc_stream_geometry", "uc_process_stream", "uc_dfsdm_sinc5", "uc_set_table", "uc_window_bins",
+           "uc_window_spectrum"]
 
 
 class Config(C.Structure):
@@ -106,6 +107,9 @@ def lib():
     L.uc_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
     L.uc_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.uc_dfsdm_sinc5.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.uc_set_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.uc_window_bins.argtypes = [C.c_void_p]
+    L.uc_window_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
     _lib = L
     return L
 
@@ -165,6 +169,45 @@ class Engine:
 
     def idx2freq(self, idx):
         return lib().uc_idx2freq(self._h, int(idx))
+
+    def set_table(self, tid, data):
+        """uc_set_table: replace TABLE_UP / TABLE_DOWN / TABLE_HANN (synchronous)."""
+        a = np.ascontiguousarray(data, np.float32).reshape(-1)
+        _check(lib().uc_set_table(self._h, tid, a.ctypes.data_as(C.c_void_p), a.size), "uc_set_table")
+
+    def window_spectrum(self, frames, n_frames=None, stride=0):
+        """uc_window_spectrum: |X[k]|, k = -bandwidth2 .. +bandwidth2, of every history of every frame.
+        numpy in -> numpy [n_frames, spf, 2 bandwidth2 + 1] (synchronous); torch device tensor in -> torch tensor."""
+        wb = _check(lib().uc_window_bins(self._h), "uc_window_bins")
+        st = stride or self.n
+        if _is_torch(frames):
+            import torch
+            t = frames
+            if not t.is_contiguous() or t.dtype not in (torch.int32, torch.float32) or t.device.type != "cuda":
+                raise ValueError("frames must be a contiguous int32 / float32 GPU tensor")
+            dt = DTYPE_I32 if t.dtype == torch.int32 else DTYPE_F32
+            if n_frames is None:
+                n_frames = (t.numel() - self.n) // st + 1 if t.numel() >= self.n else 0
+            if n_frames and (n_frames - 1) * st + self.n > t.numel():
+                raise ValueError("frames tensor too small for %d frames" % n_frames)
+            out = torch.empty((n_frames, self.spf, wb), dtype=torch.float32, device=t.device)
+            _check(lib().uc_window_spectrum(self._h, C.c_void_p(t.data_ptr()), dt, n_frames, st, C.c_void_p(out.data_ptr()),
+                                            C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)),
+                   "uc_window_spectrum")
+            return out
+        a = np.ascontiguousarray(frames)
+        if a.dtype not in (np.int32, np.float32):
+            raise TypeError("frames must be int32 or float32")
+        dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
+        flat = a.reshape(-1)
+        if n_frames is None:
+            n_frames = (flat.size - self.n) // st + 1 if flat.size >= self.n else 0
+        if n_frames and (n_frames - 1) * st + self.n > flat.size:
+            raise ValueError("frames buffer too small for %d frames" % n_frames)
+        out = np.zeros((n_frames, self.spf, wb), np.float32)
+        _check(lib().uc_window_spectrum(self._h, flat.ctypes.data_as(C.c_void_p), dt, n_frames, st,
+                                        out.ctypes.data_as(C.c_void_p), None), "uc_window_spectrum")
+        return out
 
     def receive(self, samples, busy=None):
         """uc_receive_stream / uc_receive_stream_isr: the receiver's main loop over a recorded stream.
