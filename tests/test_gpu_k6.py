@@ -82,7 +82,9 @@ def test_rx_real_with_unit_reference_is_the_devices_rfft_magnitude(uchirp):
     checked = 0
     for i, (name, raw, flt, freq, mag_dev) in enumerate(caps):
         g = spec[i, 0, 318:].astype(np.float64)            # bins 0 .. 318
-        assert np.array_equal(spec[i, 0], spec[i, 1])      # up == down reference: the same spectrum twice
+        # up == down reference: the same spectrum twice (one rides in the real, one in the imaginary part of the complex
+        # transform: equal to round-off, not bit for bit)
+        assert np.abs(spec[i, 0] - spec[i, 1]).max() <= 2e-6 * spec[i, 0].max()
         assert np.array_equal(spec[i, 0, :318][::-1], spec[i, 0, 319:])   # Hermitian mirror (Q1)
         live = np.nonzero(freq[:319] >= 1000.0)[0]
         scale = g.max()                                    # (the DC region: this kernel's own largest bin)
@@ -169,7 +171,7 @@ def test_window_spectrum_matches_the_oracle_bin_by_bin(uchirp, name, kw):
     gd = e.window_spectrum(x, stride=256)
     torch.cuda.synchronize()
     gh = e.window_spectrum(frames.reshape(-1)[: 2048 * 9], stride=256)
-    assert gd.shape[0] == 33 and np.array_equal(gd.cpu().numpy().view(np.uint32), gh.view(np.uint32))
+    assert gd.shape[0] == 65 and np.array_equal(gd.cpu().numpy().view(np.uint32), gh.view(np.uint32))
 
 
 @pytest.mark.parametrize("name", ["rx_real", "sync_cplx", "dechirp_down"])

@@ -816,8 +816,8 @@ def test_unsupported_configurations_fail_loudly(uchirp):
 def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch, uc_tuning):
     """uc_process_batch captured ONCE into a hipGraph and replayed over new frames in the same buffers gives the eager
     launch's bytes.  A tiny grid makes every launch -- the captured ones too -- use the dynamic hand-out: a captured launch
-    gets a counter slot that its graph owns (zeroed by a memset node in front of the kernel node), the eager launches of
-    the same context in between draw theirs from the ring.  Two graphs of one context replayed on two streams at the same
+    gets a counter slot that its graph owns (every launch leaves its counter at zero: csrc/uc_dev.hpp handout_leave), the
+    eager launches of the same context in between draw theirs from the ring.  Two graphs of one context replayed on two streams at the same
     time must not share a slot."""
     import torch
     dev = torch.device("cuda:0")

@@ -73,12 +73,13 @@ bool is_device_ptr(const void* p) {
 
 }  // namespace
 
-// Hand-out counters of the dynamically dealt launches (one 32-bit word each, every word in its own 128-byte line):
+// Hand-out counters of the dynamically dealt launches (two 32-bit words each -- next ticket, workgroups gone -- every
+// pair in its own 128-byte line; zeroed once at uc_create, left at zero by every launch's last workgroup):
 //   slots [0, kWorkSlots)                          a ring for EAGER launches; a slot is reused only after the launch that
 //                                                  last used it has finished (one hipEvent per slot, queried on reuse)
 //   slots [kWorkSlots, kWorkSlots + kGraphSlots)   handed out ONCE each to launches recorded while their stream is being
 //                                                  captured into a hipGraph: the graph owns that slot for the life of the
-//                                                  context, and its zeroing rides in the graph as a memset node
+//                                                  context
 constexpr unsigned kWorkSlots = 64, kGraphSlots = 960, kWorkStride = 128;
 
 struct uc_ctx {
@@ -358,6 +359,10 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   if (!rc) {
     e = hipMalloc((void**)&c->d_work, (size_t)(kWorkSlots + kGraphSlots) * kWorkStride);
     if (e != hipSuccess) rc = hip_fail(e, "hipMalloc(work counters)");
+    if (!rc) {
+      e = hipMemset(c->d_work, 0, (size_t)(kWorkSlots + kGraphSlots) * kWorkStride);
+      if (e != hipSuccess) rc = hip_fail(e, "hipMemset(work counters)");
+    }
     for (unsigned i = 0; !rc && i < kWorkSlots; i++) {
       e = hipEventCreateWithFlags(&c->work_ev[i], hipEventDisableTiming);
       if (e != hipSuccess) { c->work_ev[i] = nullptr; rc = hip_fail(e, "hipEventCreate(work counter)"); }
@@ -466,15 +471,15 @@ int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
   return (int32_t)((ifs * (n - idx) / n) * 0xFFFFFFFFu);
 }
 
-// The counter of one dynamically dealt launch, zeroed on `stream` right in front of the launch.
+// The counter of one dynamically dealt launch.  The kernels leave a counter at zero when their last workgroup exits
+// (uc_dev.hpp: handout_leave), so a slot is zero whenever no launch is using it and nothing is written here.
 //   eager launch : the next slot of the context's ring; *slot = its index (pass it to work_counter_launched() behind
 //                  the launch).  If the launch that last used that slot is still running (64 or more launches of ONE
 //                  context in flight on several streams) the counter would be shared: *out = nullptr, the caller deals
 //                  this launch statically.
-//   capture      : a slot the graph owns from now on (kGraphSlots per context, never recycled); the hipMemsetAsync is
-//                  recorded as a memset node in front of the kernel node, so every replay starts from zero and two
-//                  graphs replayed on two streams never share a counter.  *slot = -1.  When the graph slots are used
-//                  up: nullptr (static deal).
+//   capture      : a slot the graph owns from now on (kGraphSlots per context, never recycled): two graphs replayed on
+//                  two streams never share a counter, and a graph's own replays are serialised by the runtime.
+//                  *slot = -1.  When the graph slots are used up: nullptr (static deal).
 static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, int* slot) {
   *out = nullptr;
   *slot = -1;
@@ -495,10 +500,7 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, 
     c->work_next++;
     *slot = (int)idx;
   }
-  unsigned int* w = (unsigned int*)((char*)c->d_work + (size_t)idx * kWorkStride);
-  const hipError_t e = hipMemsetAsync(w, 0, sizeof(unsigned int), stream);
-  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(work counter)");
-  *out = w;
+  *out = (unsigned int*)((char*)c->d_work + (size_t)idx * kWorkStride);
   return 0;
 }
 

@@ -351,9 +351,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   const unsigned gsh = p.group_log2, gmask = (1u << gsh) - 1u;
   const unsigned ngroups = (nfr + gmask) >> gsh;
   unsigned grp = blockIdx.x;
-  if (grp >= ngroups) return;
-  unsigned f = grp << gsh;
   const bool dyn = p.work_ctr != nullptr;
+  if (grp >= ngroups) {  // (the host never launches more workgroups than groups)
+    if (dyn && j == 0) handout_leave(p.work_ctr);
+    return;
+  }
+  unsigned f = grp << gsh;
   unsigned* next_slot = reinterpret_cast<unsigned*>(lds + kNextOff);
   // thread 0: the group id an in-flight atomic returns.  It is parked in LDS in the first frame of every group
   // (the frame after the one that issued it), once that frame's loads -- older than the atomic -- are consumed.
@@ -893,6 +896,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   }
   __syncthreads();
   if (ring_n > 0 && wave == 0) finalise(ring_f0, ring_n);
+  if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
 #ifdef UC_STAMPS
   if (lane == 0 && p.debug) {
     for (int k = 0; k < 10; k++) p.debug[((size_t)blockIdx.x * 2 + wave) * 10 + k] = acc_[k];

@@ -59,6 +59,23 @@ __device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
   *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
 }
 
+// ---- dynamic hand-out counters (uc_api.cpp: take_work_counter) -----------------------------------
+// ctr[0] = the next ticket, ctr[1] = workgroups that have left.  Every workgroup of a dynamically dealt launch calls
+// this ONCE, from one thread, on its way out; the last one to leave puts both words back to zero.  A counter slot is
+// therefore zero whenever no launch is using it: no memset in front of a launch, and none recorded into a captured
+// graph (a memset NODE in front of a replayed kernel node was measured not to be seen by the kernel's device-scope
+// atomics on short launches: profiles/r03_graph_probe.txt).
+__device__ __forceinline__ void handout_leave(unsigned int* ctr) {
+  // a ticket request this thread issued and never read (the ragged end of a batch) must have been performed before
+  // the count below can reach its final value: wait for every outstanding memory operation of the thread
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  const unsigned left = atomicAdd(ctr + 1, 1u);
+  if (left == gridDim.x - 1u) {
+    atomicExch(ctr + 1, 0u);
+    atomicExch(ctr, 0u);
+  }
+}
+
 // ---- wave-wide reductions without LDS ----------------------------------------
 // Six DPP steps (row_ror 1/2/4/8 make every lane of a 16-lane row hold the row
 // result, row_bcast:15 / :31 fold the rows into lane 63) and one v_readlane.

@@ -122,7 +122,10 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   const unsigned nchunks = (npairs + gmask) >> gsh;
   unsigned q, qend;
   if (dyn) {
-    if (blockIdx.x >= nchunks) return;
+    if (blockIdx.x >= nchunks) {  // (the host never launches more workgroups than chunks)
+      if (j == 0) handout_leave(p.work_ctr);
+      return;
+    }
     q = blockIdx.x << gsh;
     qend = q + gmask + 1u < npairs ? q + gmask + 1u : npairs;
   } else {
@@ -275,6 +278,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   }
   __syncthreads();
   if (pending) publish(qprev);
+  if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
 }
 
 }  // namespace

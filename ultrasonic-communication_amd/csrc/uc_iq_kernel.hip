@@ -145,9 +145,12 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   const unsigned gsh = (unsigned)__builtin_ctz(p.group), gmask = (1u << gsh) - 1u;
   const unsigned ngroups = (nfr + gmask) >> gsh;
   unsigned grp = blockIdx.x;
-  if (grp >= ngroups) return;
-  unsigned f = grp << gsh;
   const bool dyn = p.work_ctr != nullptr;
+  if (grp >= ngroups) {  // (the host never launches more workgroups than groups)
+    if (dyn && j == 0) handout_leave(p.work_ctr);
+    return;
+  }
+  unsigned f = grp << gsh;
   unsigned fetched = kNoGroup;  // thread 0: what the atomic in flight returns; kNoGroup = none asked for (the ragged last group)
   unsigned* next_slot = reinterpret_cast<unsigned*>(lds + kNextO);
 
@@ -418,6 +421,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   }
   __syncthreads();
   if (ring_n > 0 && wave == 0) finalise(ring_f0, ring_n);
+  if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
 }
 
 
@@ -478,9 +482,12 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   const unsigned gsh = (unsigned)__builtin_ctz(p.group), gmask = (1u << gsh) - 1u;
   const unsigned ngroups = (nfr + gmask) >> gsh;
   unsigned grp = blockIdx.x;
-  if (grp >= ngroups) return;
-  unsigned f = grp << gsh;
   const bool dyn = p.work_ctr != nullptr;
+  if (grp >= ngroups) {  // (the host never launches more workgroups than groups)
+    if (dyn && j == 0) handout_leave(p.work_ctr);
+    return;
+  }
+  unsigned f = grp << gsh;
   unsigned fetched = kNoGroup;  // lane 0: what the atomic in flight returns; kNoGroup = none asked for (the ragged last group)
 
   const __amdgpu_buffer_rsrc_t rs_car = make_rsrc(p.carrier, kN1 * 8);
@@ -817,6 +824,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   }
   __syncthreads();
   if (ring_n > 0) finalise(ring_f0, ring_n);
+  if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
 }
 
 }  // namespace

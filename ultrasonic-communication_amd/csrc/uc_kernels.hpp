@@ -37,7 +37,7 @@ struct BandParams {
   uint32_t true_dc;       // UC_FLAG_TRUE_DC
   uint32_t group_log2;    // log2 of the frames (PAIR: frame pairs) per group: 1..6 with work_ctr, 0..6 without
   uint32_t unpaired;      // kModePair only: 1 = UC_FLAG_NO_FRAME_PAIRS, one frame per transform
-  unsigned int* work_ctr; // device word, zero at launch: groups beyond the first one of each workgroup are handed out
+  unsigned int* work_ctr; // two device words, zero at launch and left at zero: groups beyond the first one of each workgroup are handed out
                           // by atomic increments (the workgroups run at different speeds); nullptr = static round robin
   unsigned long long* debug;  // diagnostic builds only (UC_STAMPS), else nullptr
 };

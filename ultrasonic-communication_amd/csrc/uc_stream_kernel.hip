@@ -98,7 +98,10 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   const unsigned nchunks = (nblk + gmask) >> gsh;
   unsigned b, bend;
   if (dyn) {
-    if (blockIdx.x >= nchunks) return;
+    if (blockIdx.x >= nchunks) {  // (the host never launches more workgroups than chunks)
+      if (j == 0) handout_leave(p.work_ctr);
+      return;
+    }
     b = blockIdx.x << gsh;
     bend = b + gmask + 1u < nblk ? b + gmask + 1u : nblk;
   } else {
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     b = bn;
     if (hop) bend = b + gmask + 1u < nblk ? b + gmask + 1u : nblk;
   }
+  if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
 }
 
 template <int DTYPE, int D>
