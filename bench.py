@@ -17,6 +17,20 @@ over one batch of synthetic frames already resident in HBM.
 `python bench.py --gpus N` starts its N ranks itself (one process per GPU, before anything touches
 the GPU); under `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` it is
 one of the ranks.  --gpus must equal the world size.  Prints ONE JSON line on rank 0.
+
+Beside the contract line's own fields the N = 1 line carries (after the timed region, which they do not touch):
+  configs        BASELINE configs[2] (base-band I/Q, n = 1024, on the fs = 100 kHz pass-band stream; the firmware-window
+                 mode beside it) and configs[3] (UC_STREAM, D = 8, replayed from a captured hipGraph; the eager rate
+                 beside it), each with ms_per_step, kernel time by HIP events and both rooflines
+  hello_world1   the N > 1 leg (configs[4]: K7 framing, RCCL all-gather every step, decode) at world size 1: the
+                 like-for-like anchor of the driver's 1 -> N scaling efficiency
+  roofline.valu  VALU issue fraction from the committed counter passes (profiles/r*_valu_insts.json); `bound` names the
+                 larger of the HBM and the VALU fraction
+Exit status: 3 if a correctness gate fails (symbols differ from the oracle on clear frames, a transmission does not
+decode, the gathered stream is inconsistent) -- the JSON line is still printed.
+
+Never run `--gpus N > 1` under rocprofv3: the profiler initialises the GPU in this parent, which then starts N children.
+Profile one rank instead (RANK=0 WORLD_SIZE=1 ... rocprofv3 ... -- python3 bench.py), see tools/profile_round.sh.
 """
 import argparse
 import json
@@ -93,7 +107,7 @@ def cpu_baseline(frames_host, mag_mean):
                 break
     except OSError:
         pass
-    rs, _ = o.process(frames_host[:4096], precision=uco.F64, threads=cores)
+    rs, rst = o.process(frames_host[:4096], precision=uco.F64, threads=cores)
     # SURVEY.md section 8d's optional NumPy line: the same decision with numpy.fft.rfft (pocketfft), one process
     up, down, hann = o.table(uco.TABLE_UP), o.table(uco.TABLE_DOWN), o.table(uco.TABLE_HANN)
     bw2 = o.bandwidth2
@@ -108,12 +122,85 @@ def cpu_baseline(frames_host, mag_mean):
     sym_np = np.where((np.maximum(mu, md) - mag_mean) / mag_mean >= 2.0, (md <= mu).astype(np.uint8), 255)
     numpy_rate = xs.shape[0] / (time.perf_counter() - t2)
     numpy_agree = float((sym_np[:4096] == rs).mean())
-    return {"symbols_f64_oracle_head": rs, "value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+    return {"symbols_f64_oracle_head": rs, "clear_head": clear_frames(rst), "value": n / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "one_thread_value": one_thread, "cpu_model": model,
             "numpy_rfft_value": numpy_rate, "numpy_rfft_agrees_with_oracle": numpy_agree,
             "sample": "%d passes over the first %d frames of the same batch, oracle/uc_oracle.c "
                       "(float32 butterflies), OpenMP %d threads = this box's CPU share (%d hardware threads visible), "
                       "%.1f s" % (passes, n // passes, cores, os.cpu_count() or 1, dt)}
+
+
+def clear_frames(stats, thr=2.0, margin=1e-3):
+    """Frames whose float64-oracle decision is not a near-tie (tests/parity_util.py: clear_symbols)."""
+    su, sd = stats["snr"][:, 0].astype(np.float64), stats["snr"][:, 1].astype(np.float64)
+    m = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30)
+    near = (np.abs(su - thr) < 1e-3 * thr) | (np.abs(sd - thr) < 1e-3 * thr)
+    return (m >= margin) & ~near
+
+
+def clock_ramp(launch, torch, ramp_ms):
+    """Untimed launches until `ramp_ms` have passed (an idle MI355X needs ~20 launches / ~40 ms of these kernels
+    before its launch time settles: tools/ramp_probe.py, profiles/r02_v5_ramp.txt).  Returns the launch count."""
+    n = 0
+    if ramp_ms <= 0:
+        return 0
+    t_r = time.perf_counter()
+    while (time.perf_counter() - t_r) * 1e3 < ramp_ms:
+        for _ in range(4):
+            launch()
+        torch.cuda.synchronize()
+        n += 4
+    return n
+
+
+def timed_launches(launch, stream, torch, steps, warmup):
+    """W untimed + K timed launches: (wall ms per step, mean HIP-event ms per launch on `stream`)."""
+    for _ in range(warmup):
+        launch()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    t0 = time.perf_counter()
+    for a, b in ev:
+        a.record(stream)
+        launch()
+        b.record(stream)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    return wall, float(np.mean([a.elapsed_time(b) for a, b in ev]))
+
+
+_VALU = None
+
+
+def valu_table():
+    """profiles/r*_valu_insts.json (the newest): VALU wave-instructions per unit of work and the in-kernel shader clock
+    of every kernel, from rocprofv3 --pmc passes and the clock-stamp build (tools/pmc_round.sh, tools/valu_table.py)."""
+    global _VALU
+    if _VALU is None:
+        import glob
+        fs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_valu_insts.json")))
+        _VALU = (json.load(open(fs[-1])), os.path.relpath(fs[-1], ROOT)) if fs else ({}, None)
+    return _VALU
+
+
+def roofline(kernel_key, kernel_name, units, bytes_per_unit, kern_ms, num_cu=256):
+    """Both roofs of one launch: HBM (algorithmic bytes / kernel time / 8 TB/s) and VALU issue (wave-instructions x 4
+    cycles / (4 SIMDs x CUs x in-kernel clock x kernel time)); `bound` = the larger fraction."""
+    achieved = units * bytes_per_unit / (kern_ms * 1e-3) / 1e9
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+         "kernel": kernel_name, "kernel_ms": kern_ms, "bytes_per_unit": bytes_per_unit}
+    tab, src = valu_table()
+    v = tab.get(kernel_key)
+    if v:
+        cyc = v["valu_insts_per_unit"] * 4.0 / 4.0                       # issue cycles per unit and CU: 4 SIMDs share it
+        frac = v["valu_insts_per_unit"] * units * 4.0 / (4.0 * num_cu * v["clock_GHz"] * 1e9 * kern_ms * 1e-3)
+        r["valu"] = {"insts_per_unit": v["valu_insts_per_unit"], "issue_cycles_per_unit": cyc,
+                     "clock_GHz": v["clock_GHz"], "frac": frac, "source": src + ": " + v.get("source", "")}
+        if "lds_insts_per_unit" in v:
+            r["valu"]["lds_insts_per_unit"] = v["lds_insts_per_unit"]
+        if frac > r["frac"]:
+            r["bound"] = "valu"
+    return r
 
 
 def achievable_hbm(frames, stream, torch):
@@ -155,33 +242,225 @@ def achievable_hbm(frames, stream, torch):
                       "(read + write bytes); HIP events, median of 10" % (nbytes >> 20, half >> 20)}
 
 
+def config2_iq(args, device, stream, torch, mag_mean):
+    """BASELINE configs[2] on its stated workload: a continuous real pass-band stream at
+    fs = 100 kHz, carrier 18 kHz, base-band chirps of +-1.5 kHz, n = 1024 samples per symbol, 26 samples of FIR
+    history in front, generated on the device; UC_IQ with UC_FLAG_IQ_BASEBAND (the experiment's intended maths,
+    simulation/IQ_modulation.ipynb cells 16-31: mix, 27-tap low-pass, two dechirp runs, up/down symbol) and, beside
+    it, the firmware-window mode (experiments/iq_modulation/Src/main.c:283-285: one history, no symbol)."""
+    import uchirp
+    from uchirp import synth
+    n = 1024
+    nf = 2 * args.frames                                  # the same sample count as configs[1]
+    x, bits = synth.device_iq_stream(nf, n, device, seed=4321, snr_db=args.snr)
+    steps, warm = min(args.steps, 10), min(args.warmup, 3)
+    cfg = dict(n=n, fs=100000.0, carrier=18000.0, f0=16500.0, f1=19500.0, time_frame=n / 100000.0, mag_mean=mag_mean)
+    out = {"workload": "configs[2]: %d x %d-sample symbols of a continuous real pass-band stream, fs 100 kHz, carrier 18 kHz, "
+                       "base-band chirp +-1.5 kHz, SNR %.0f dB, 26 samples of FIR history, generated on the device" % (nf, n, args.snr),
+           "frames": nf, "frame_len": n, "steps": steps, "warmup": warm}
+    # --- base-band mode: symbols out
+    eng = uchirp.Engine(uchirp.IQ, device=device.index, flags=uchirp.FLAG_IQ_BASEBAND, **cfg)
+    sym = torch.empty(nf, dtype=torch.uint8, device=device)
+
+    def launch_bb():
+        eng.process(x, n_frames=nf, want_stats=False, symbols_out=sym, stream=stream.cuda_stream)
+
+    ramp = clock_ramp(launch_bb, torch, args.ramp_ms)
+    wall, kern = timed_launches(launch_bb, stream, torch, steps, warm)
+    bb = {"mode": "UC_FLAG_IQ_BASEBAND: mix, 27-tap FIR, dechirp by conj(up) and conj(down), 2 x CFFT-1024, windows around DC, symbol",
+          "value": nf / (wall * 1e-3), "unit": "frames/s", "ms_per_step": wall, "ramp_launches": ramp,
+          "roofline": roofline("iq1024_bb_f32", "iq1024_kernel<f32,baseband>", nf, 4096 + 1, kern),
+          "bytes_note": "4096 B in + 1 B symbol out per frame (+ 104 B of FIR history once per launch)",
+          "bit_error_rate_vs_transmitted": float((sym != bits).float().mean().item())}
+    if not args.no_cpu_baseline:
+        from oracle import uco
+        o = uco.Oracle(uco.IQ, flags=uco.FLAG_IQ_BASEBAND, **cfg)
+        head = x[: 26 + 4096 * n].cpu().numpy()
+        rs, rst = o.process(head, halo=26, n_frames=4096)
+        clear = clear_frames(rst)
+        bb["symbols_equal_oracle_head4096_clear"] = float((sym[:4096].cpu().numpy()[clear] == rs[clear]).mean())
+        bb["oracle_head_near_ties_excluded"] = int((~clear).sum())
+        bb["oracle_head_bit_error_rate"] = float((rs != bits[:4096].cpu().numpy()).mean())
+    out["baseband"] = bb
+    eng.close()
+    # --- firmware-window mode: one history record out, no symbol
+    eng = uchirp.Engine(uchirp.IQ, device=device.index, n=n, mag_mean=mag_mean)
+    st = torch.empty((nf, eng.spf, 8), dtype=torch.float32, device=device)
+
+    def launch_fw():
+        eng.process(x, n_frames=nf, want_symbols=False, stats_out=st, stream=stream.cuda_stream)
+
+    clock_ramp(launch_fw, torch, args.ramp_ms / 3)
+    wall, kern = timed_launches(launch_fw, stream, torch, steps, warm)
+    out["firmware_windows"] = {
+        "mode": "the committed firmware's windows at bin (F1+F2) n / fs (iq_modulation/Src/main.c:215-219,283-285): one dechirp run, one history",
+        "value": nf / (wall * 1e-3), "unit": "frames/s", "ms_per_step": wall,
+        "roofline": roofline("iq1024_fw_f32", "iq1024_kernel<f32,firmware windows>", nf, 4096 + 32, kern),
+        "bytes_note": "4096 B in + 32 B history record out per frame"}
+    out["baseband_over_firmware_windows"] = bb["value"] / out["firmware_windows"]["value"]
+    eng.close()
+    del x, sym, st
+    return out
+
+
+def config3_stream(args, frames, device, torch):
+    """BASELINE configs[3]: the configs[1] batch read as ONE continuous stream through UC_STREAM (27-tap FIR low-pass,
+    decimation by 8, overlap-save FFT x H x IFFT compression, include/uchirp.h), captured ONCE into a hipGraph and
+    replayed; the eager launches beside it.  The captured launch deals its blocks dynamically like the eager one
+    (a counter slot the graph owns)."""
+    import uchirp
+    eng = uchirp.Engine(uchirp.STREAM, device=device.index)
+    x = frames.reshape(-1)
+    halo, n_out, n_blocks, hop = eng.stream_geometry(x.numel())
+    steps, warm = min(args.steps, 10), min(args.warmup, 3)
+    comp = torch.empty(n_out, dtype=torch.float32, device=device)
+    pk = torch.empty((n_blocks, 2), dtype=torch.int32, device=device)
+    comp_g, pk_g = torch.empty_like(comp), torch.empty_like(pk)
+    byts = (x.numel() * 4 + n_out * 4 + n_blocks * 8) / x.numel()
+    out = {"workload": "configs[3]: %d samples (2^%.2f, the configs[1] batch as one continuous stream), decimation 8, FFT 2048, "
+                       "hop %d, |y| for every decimated sample + one peak record per block" % (x.numel(), np.log2(x.numel()), hop),
+           "samples": x.numel(), "blocks": n_blocks, "decim": int(eng.cfg.decim), "steps": steps, "warmup": warm,
+           "bytes_per_sample": byts}
+    s1 = torch.cuda.current_stream(device)
+
+    def launch():
+        eng.process_stream(x, compressed_out=comp, peaks_out=pk, stream=s1.cuda_stream)
+
+    clock_ramp(launch, torch, args.ramp_ms)
+    wall, kern = timed_launches(launch, s1, torch, steps, warm)
+    out["eager"] = {"value": x.numel() / (wall * 1e-3), "unit": "samples/s", "ms_per_step": wall,
+                    "roofline": roofline("stream_d8_f32", "stream_kernel<f32,8>", x.numel(), byts, kern)}
+    s2 = torch.cuda.Stream(device)
+    g = torch.cuda.CUDAGraph()
+    s2.wait_stream(s1)
+    with torch.cuda.stream(s2):
+        with torch.cuda.graph(g, stream=s2):
+            eng.process_stream(x, compressed_out=comp_g, peaks_out=pk_g, stream=s2.cuda_stream)
+        wall, kern = timed_launches(g.replay, s2, torch, steps, warm)
+    torch.cuda.synchronize()
+    out["graph_replay"] = {"value": x.numel() / (wall * 1e-3), "unit": "samples/s", "ms_per_step": wall,
+                           "roofline": roofline("stream_d8_f32", "stream_kernel<f32,8> (captured hipGraph, replayed)",
+                                                x.numel(), byts, kern)}
+    out["graph_equals_eager"] = bool(torch.equal(comp, comp_g) and torch.equal(pk, pk_g))
+    out["graph_over_eager"] = out["graph_replay"]["value"] / out["eager"]["value"]
+    if not args.no_cpu_baseline:
+        from oracle import uco
+        o = uco.Oracle(uco.STREAM)
+        nb = 6
+        head = x[: halo + 8 * nb * hop].cpu().numpy()
+        cr, pr = o.process_stream(head)
+        got = comp_g[: cr.size].cpu().numpy()
+        out["head_rel_err_vs_oracle"] = float(np.abs(got - cr).max() / cr.max())
+        out["head_peak_offsets_equal_oracle"] = bool(np.array_equal(pk_g[:nb, 1].cpu().numpy().astype(np.uint32),
+                                                                    pr["offset"][:nb]))
+    eng.close()
+    return out
+
+
+def hello_world1(args, device, torch, mag_mean):
+    """The N > 1 leg at world size 1, inside the N = 1 run: configs[4] framing, matched sweep, an RCCL process group of one
+    rank, the asynchronous all-gather of the symbol stream every step (double-buffered as in the N > 1 run), decode.
+    Gives the driver's 1 -> N efficiency a like-for-like anchor (the N = 1 contract line runs configs[1] without a gather)."""
+    import torch.distributed as dist
+    import uchirp
+    from uchirp import synth
+    own = not dist.is_initialized()
+    if own:
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=device)
+    try:
+        nf = args.frames
+        eng = uchirp.Engine(uchirp.RX_REAL, device=device.index, mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
+        frames, sent = synth.device_hello_frames(0, nf, device, seed=1234, snr_db=args.snr, msg=MSG)
+        stream = torch.cuda.current_stream(device)
+        sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
+        gat2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
+        works = [None, None]
+
+        def step(k, e0=None, e1=None):
+            b = k & 1
+            if works[b] is not None:
+                works[b].wait()
+            if e0 is not None:
+                e0.record(stream)
+            eng.process(frames, want_stats=False, symbols_out=sym2[b], stream=stream.cuda_stream)
+            if e1 is not None:
+                e1.record(stream)
+            works[b] = dist.all_gather_into_tensor(gat2[b], sym2[b], async_op=True)
+
+        def drain():
+            for b in range(2):
+                if works[b] is not None:
+                    works[b].wait()
+                    works[b] = None
+
+        clock_ramp(lambda: eng.process(frames, want_stats=False, symbols_out=sym2[0], stream=stream.cuda_stream), torch,
+                   args.ramp_ms)
+        for k in range(args.warmup):
+            step(k)
+        drain()
+        torch.cuda.synchronize()
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+        t0 = time.perf_counter()
+        for k in range(args.steps):
+            step(k, ev[k][0], ev[k][1])
+        drain()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        kern = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        g = gat2[(args.steps - 1) & 1]
+        ok = bool(torch.equal(g, sym2[(args.steps - 1) & 1]))
+        texts = synth.decode_hello(g.cpu().numpy(), len(MSG))
+        good = sum(1 for t in texts if t == MSG)
+        ms = elapsed / args.steps * 1e3
+        out = {"workload": "configs[4] at world size 1: %d x 2048-sample frames, K7 'Hello World!' framing, SNR %.0f dB, matched "
+                           "sweep, RCCL all-gather of the symbol stream every step" % (nf, args.snr),
+               "value": nf * args.steps / elapsed, "unit": "frames/s", "ms_per_step": ms, "steps": args.steps,
+               "kernel_ms": kern, "gather_ms_exposed": ms - kern, "gathered_equals_decoded": ok,
+               "transmissions": len(texts), "transmissions_decoded_exactly": good}
+        eng.close()
+        del frames, sym2, gat2
+        return out
+    finally:
+        if own:
+            dist.destroy_process_group()
+
+
 def stream_measurement(args, eng, frames, rank, torch):
-    """BASELINE config 4 (side measurement): the batch read as ONE continuous stream through UC_STREAM."""
+    """BASELINE config 4 (side measurement, eager launches): the batch read as ONE continuous stream through UC_STREAM."""
     x = frames.reshape(-1)
     halo, n_out, n_blocks, hop = eng.stream_geometry(x.numel())
     comp = torch.empty(n_out, dtype=torch.float32, device=x.device)
     pk = torch.empty((n_blocks, 2), dtype=torch.int32, device=x.device)
-    t_r = time.perf_counter()
-    while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:      # clock ramp: see main()
-        eng.process_stream(x, compressed_out=comp, peaks_out=pk)
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        eng.process_stream(x, compressed_out=comp, peaks_out=pk)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.process_stream(x, compressed_out=comp, peaks_out=pk)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / args.steps
-    byts = x.numel() * 4 + n_out * 4 + n_blocks * 8
+    stream = torch.cuda.current_stream(x.device)
+
+    def launch():
+        eng.process_stream(x, compressed_out=comp, peaks_out=pk, stream=stream.cuda_stream)
+
+    clock_ramp(launch, torch, args.ramp_ms)
+    wall, kern = timed_launches(launch, stream, torch, args.steps, args.warmup)
+    byts = (x.numel() * 4 + n_out * 4 + n_blocks * 8) / x.numel()
     if rank == 0:
         print(json.dumps({"metric": "input samples/s (stream: FIR decimate + overlap-save compression, side measurement)",
-                          "value": x.numel() / dt, "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
-                          "warmup": args.warmup, "ms_per_step": dt * 1e3, "decim": int(eng.cfg.decim),
-                          "blocks": n_blocks, "blocks_per_s": n_blocks / dt,
-                          "roofline": {"bound": "hbm", "achieved": byts / dt / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": byts / dt / 1e9 / HBM_PEAK_GBS,
-                                       "bytes_per_sample": byts / x.numel()}}), flush=True)
+                          "value": x.numel() / (wall * 1e-3), "unit": "samples/s", "n_gpus": 1, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": wall, "decim": int(eng.cfg.decim),
+                          "blocks": n_blocks, "blocks_per_s": n_blocks / (wall * 1e-3),
+                          "roofline": roofline("stream_d%d_f32" % int(eng.cfg.decim), "stream_kernel<f32,%d>" % int(eng.cfg.decim),
+                                               x.numel(), byts, kern)}), flush=True)
+
+
+SIDE = {  # variant -> (algorithmic bytes per frame, key of profiles/r*_valu_insts.json, kernel)
+    "sync_cplx": (8193, "band_sync_cplx_f32", "band_kernel<sync_cplx,f32>"),
+    "compress": (8192 + 32, "compress_f32", "compress_kernel<f32>"),
+    "dechirp_down": (8192 + 32, "band_dechirp_down_f32", "band_kernel<dechirp_down,f32>"),
+    "iq": (8192 + 104 + 32, "iq2048_fw_f32", "iq_kernel<f32,firmware windows>"),
+    "iq1024": (4096 + 104 + 32, "iq1024_fw_f32", "iq1024_kernel<f32,firmware windows>"),
+    "iq_bb": (8192 + 104 + 1, "iq2048_bb_f32", "iq_kernel<f32,baseband>"),
+    "iq1024_bb": (4096 + 104 + 1, "iq1024_bb_f32", "iq1024_kernel<f32,baseband>"),
+}
 
 
 def side_measurement(args, eng, frames, world, rank, torch):
@@ -189,31 +468,24 @@ def side_measurement(args, eng, frames, world, rank, torch):
     if args.variant == "stream":
         return stream_measurement(args, eng, frames, rank, torch)
     n = eng.n
-    per_frame = {"sync_cplx": 8193, "compress": 8192 + 32, "dechirp_down": 8192 + 32, "iq": 8192 + 104 + 32,
-                 "iq1024": 4096 + 104 + 32}[args.variant]
+    per_frame, key, kname = SIDE[args.variant]
     nfr = (frames.numel() - eng.halo - n) // n + 1
-    want_sym = args.variant == "sync_cplx"
+    want_sym = args.variant in ("sync_cplx", "iq_bb", "iq1024_bb")
     stats = None if want_sym else torch.empty((nfr, eng.spf, 8), dtype=torch.float32, device=frames.device)
     sym = torch.empty(nfr, dtype=torch.uint8, device=frames.device) if want_sym else None
-    t_r = time.perf_counter()
-    while (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:      # clock ramp: see main()
-        eng.process(frames, n_frames=nfr, want_symbols=want_sym, want_stats=not want_sym, symbols_out=sym, stats_out=stats)
-        torch.cuda.synchronize()
-    for _ in range(args.warmup):
-        eng.process(frames, n_frames=nfr, want_symbols=want_sym, want_stats=not want_sym, symbols_out=sym, stats_out=stats)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        eng.process(frames, n_frames=nfr, want_symbols=want_sym, want_stats=not want_sym, symbols_out=sym, stats_out=stats)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    stream = torch.cuda.current_stream(frames.device)
+
+    def launch():
+        eng.process(frames, n_frames=nfr, want_symbols=want_sym, want_stats=not want_sym, symbols_out=sym, stats_out=stats,
+                    stream=stream.cuda_stream)
+
+    clock_ramp(launch, torch, args.ramp_ms)
+    wall, kern = timed_launches(launch, stream, torch, args.steps, args.warmup)
     if rank == 0:
-        v = nfr * args.steps / dt
-        print(json.dumps({"metric": "chirp frames/s (%s, side measurement)" % args.variant, "value": v, "unit": "frames/s",
-                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+        print(json.dumps({"metric": "chirp frames/s (%s, side measurement)" % args.variant, "value": nfr / (wall * 1e-3),
+                          "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall,
                           "frame_len": n, "frames": nfr,
-                          "roofline": {"bound": "hbm", "achieved": v * per_frame / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                       "frac": v * per_frame / 1e9 / HBM_PEAK_GBS, "bytes_per_frame": per_frame}}), flush=True)
+                          "roofline": roofline(key, kname, nfr, per_frame, kern)}), flush=True)
 
 
 def parse_args(argv=None):
@@ -227,8 +499,10 @@ def parse_args(argv=None):
     ap.add_argument("--ramp-ms", type=float, default=150.0,
                     help="untimed kernel launches before the warm-up steps until the GPU's clocks have settled (0 = none)")
     ap.add_argument("--variant", default="rx_real",
-                    choices=["rx_real", "sync_cplx", "compress", "dechirp_down", "iq", "iq1024", "stream"],
+                    choices=["rx_real", "sync_cplx", "compress", "dechirp_down", "iq", "iq1024", "iq_bb", "iq1024_bb", "stream"],
                     help="default rx_real = BASELINE configs[1]; the others are side measurements")
+    ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs[2] / configs[3] block")
+    ap.add_argument("--no-hello1", action="store_true", help="N = 1: skip the configs[4] leg at world size 1")
     return ap.parse_args(argv)
 
 
@@ -246,6 +520,9 @@ def launch_ranks(args):
     for r in range(args.gpus):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        # This pool's host driver only supports dmabuf IPC: without HSA_ENABLE_IPC_MODE_LEGACY=0 RCCL's intra-node setup
+        # (hipIpcGetMemHandle) fails with "invalid argument".  The image exports it already; keep it if a caller's
+        # environment dropped it.  (setdefault: an explicit value from the caller wins.)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else sys.stderr))
@@ -264,13 +541,13 @@ def launch_ranks(args):
             p.wait()
     out0.seek(0)
     text = out0.read().decode()
-    if rc:
-        sys.stderr.write(text)
-        raise SystemExit("bench.py: a rank failed (exit %s)" % rc)
-    # stdout carries the JSON line(s) only; anything a library printed on rank 0's stdout goes to stderr
+    # stdout carries the JSON line(s) only; anything a library printed on rank 0's stdout goes to stderr.  Exit status 3
+    # = a correctness gate failed on rank 0: its JSON line (with `gates_failed`) is still relayed.
     for ln in text.splitlines():
-        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
+        (sys.stdout if ln.startswith("{") and rc in (0, 3) else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
+    if rc:
+        raise SystemExit("bench.py: a rank failed (exit %s)" % rc if rc != 3 else 3)
 
 
 def main():
@@ -304,16 +581,20 @@ def main():
     # UC_BENCH_HELLO=1: run the N > 1 leg -- configs[4] framing, RCCL process group, async all-gather, digest check,
     # text decode -- with whatever world size there is, 1 included (what a one-GPU box can exercise of it on RCCL).
     multi = world > 1 or os.environ.get("UC_BENCH_HELLO") == "1"
-    json_out = sys.stdout
+    # RCCL prints its version banner on file descriptor 1 (the N = 1 run starts it too, for `hello_world1`); stdout must
+    # carry the JSON line and nothing else: keep a private copy of the real stdout for that line and point descriptor 1
+    # at stderr for everyone else
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if multi:
-        # RCCL prints its version banner on file descriptor 1; stdout must carry the JSON line and nothing else:
-        # keep a private copy of the real stdout for that line and point descriptor 1 at stderr for everyone else
-        sys.stdout.flush()
-        json_out = os.fdopen(os.dup(1), "w")
-        os.dup2(2, 1)
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29517")
+        if "MASTER_PORT" not in os.environ:      # (UC_BENCH_HELLO=1 outside a launcher: one process, any free port)
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
+            sk.close()
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -330,6 +611,10 @@ def main():
         vmap = {"rx_real": (uchirp.RX_REAL, {}), "sync_cplx": (uchirp.SYNC_CPLX, {}), "compress": (uchirp.COMPRESS, {}),
                 "dechirp_down": (uchirp.DECHIRP_DOWN, {}), "iq": (uchirp.IQ, {}), "iq1024": (uchirp.IQ, {"n": 1024}),
                 "stream": (uchirp.STREAM, {})}
+        for nn in (2048, 1024):   # base-band I/Q, configs[2]'s constants (the batch is not its workload: timing only)
+            vmap["iq_bb" if nn == 2048 else "iq1024_bb"] = (uchirp.IQ, dict(
+                n=nn, fs=100000.0, carrier=18000.0, f0=16500.0, f1=19500.0, time_frame=nn / 100000.0,
+                flags=uchirp.FLAG_IQ_BASEBAND))
         vid, vkw = vmap[args.variant]
         if hello:
             vkw = dict(vkw, time_frame=MATCHED_TIME_FRAME)
@@ -340,6 +625,7 @@ def main():
     else:
         frames, sent = synth.device_frames(nf, device, seed=1234 + rank, snr_db=args.snr)
     if args.variant != "rx_real":
+        sys.stdout = json_out                  # (the side measurements print their line themselves)
         return side_measurement(args, eng, frames, world, rank, torch)
     # Two symbol buffers: the gather of step k (RCCL's own stream) overlaps the kernel of step k + 1;
     # a buffer is rewritten only after the gather that read it has finished (work.wait() orders the
@@ -415,6 +701,7 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    elapsed_local = elapsed
     if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -438,7 +725,18 @@ def main():
             digs = [d.cpu() for d in dd]
         assert all(torch.equal(d, digs[0]) for d in digs), "ranks hold different gathered symbol streams"
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if have_gpu else None
+    local_ms = elapsed_local / args.steps * 1e3
+    per_rank = None
+    if multi:
+        # every rank's own kernel time and step time (not only rank 0's, not only the maximum): lets a reader of the
+        # N > 1 line tell the gather's cost from a straggling rank
+        mine = torch.tensor([kern_ms if kern_ms is not None else 0.0, local_ms], dtype=torch.float64,
+                            device="cpu" if rehearse else device)
+        alls = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(alls, mine)
+        per_rank = np.array([a.cpu().numpy() for a in alls])       # [world, (kernel_ms, ms_per_step)]
 
+    gate_failures = []
     if rank == 0:
         total_frames = world * nf * args.steps
         value = total_frames / elapsed
@@ -467,7 +765,7 @@ def main():
             # HBM bytes per launch from the committed PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE,
             # collected with rocprofv3 --pmc in their own runs: profiles/*_hbm_traffic.json), scaled to
             # this launch's frame count; null if no profile is committed.
-            traffic = None
+            traffic, traffic_source = None, None
             try:
                 import glob
                 import re
@@ -475,12 +773,15 @@ def main():
                 tf = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic.json"))
                             if re.fullmatch(r"r\d+_v\d+_hbm_traffic\.json", os.path.basename(f)))[-1]
                 traffic = json.load(open(tf))["hbm_bytes_per_frame"] * nf
+                traffic_source = ("NOT measured in this run: FETCH_SIZE x 2 + WRITE_SIZE per frame of the committed "
+                                  "rocprofv3 --pmc passes in %s, scaled to this launch's %d frames"
+                                  % (os.path.relpath(tf, ROOT), nf))
             except Exception:
                 traffic = None
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                               "kernel": "band_kernel<rx_real,f32>", "kernel_ms": kern_ms,
-                               "bytes_per_frame": BYTES_PER_FRAME}
+            out["roofline"] = roofline("band_rx_real_f32", "band_kernel<rx_real,f32>", nf, BYTES_PER_FRAME, kern_ms)
+            out["roofline"]["bytes_per_frame"] = BYTES_PER_FRAME
+            out["roofline"]["traffic"] = traffic
+            out["roofline"]["traffic_source"] = traffic_source
             if not multi:
                 ach = achievable_hbm(frames, stream, torch)
                 if ach:
@@ -500,19 +801,72 @@ def main():
                 out["rehearsal"] = "plumbing only: no GPU, no kernel ran, value is null"
             elif rehearse:
                 out["rehearsal"] = "every rank on device 0, gloo: not a measurement"
+            if good != len(texts):
+                gate_failures.append("hello: %d of %d transmissions decode" % (good, len(texts)))
+            out["value_per_gpu"] = value / world if have_gpu else None
+            km, sm = per_rank[:, 0], per_rank[:, 1]
+            out["per_rank"] = {"kernel_ms": {"min": float(km.min()), "median": float(np.median(km)), "max": float(km.max())},
+                               "ms_per_step": {"min": float(sm.min()), "median": float(np.median(sm)), "max": float(sm.max())},
+                               "kernel_ms_by_rank": [float(v) for v in km]}
+            # what a step costs beyond the kernel on the slowest rank: the gather that the next kernel does not hide,
+            # launch gaps, and (N > 1) waiting for the slowest rank inside the collective
+            out["gather_ms_exposed"] = float((sm - km).max()) if have_gpu else None
         else:
-            # correctness gate on the measured run: decoded symbols vs transmitted bits
+            # correctness figure of the measured run: decoded symbols vs transmitted bits.  ~23 % is EXPECTED here:
+            # configs[1] runs the firmware's literal TIME_FRAME = 0.0205 s reference tables against frames that
+            # sweep over the whole 26.2 ms frame; GPU == oracle is the gate (below), the matched sweep is configs[4]
             out["bit_error_rate_vs_transmitted"] = float((symbols != sent).float().mean().item())
+            out["bit_error_rate_note"] = ("expected ~0.23: literal TIME_FRAME reference (SURVEY Q4) vs full-frame sweeps; "
+                                          "the oracle has the same errors (symbols_equal_oracle_head4096_clear)")
+        if not multi and have_gpu and not args.no_configs:
+            cfgs = {}
+            for name, fn in (("configs[2]", lambda: config2_iq(args, device, stream, torch, mag_mean)),
+                             ("configs[3]", lambda: config3_stream(args, frames, device, torch))):
+                t_c = time.perf_counter()
+                try:
+                    cfgs[name] = fn()
+                except Exception as ex:                      # the contract line must not die with a side leg
+                    cfgs[name] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+                    gate_failures.append("%s failed: %s" % (name, type(ex).__name__))
+                cfgs[name]["wall_s"] = time.perf_counter() - t_c
+            out["configs"] = cfgs
+            c2, c3 = cfgs["configs[2]"], cfgs["configs[3]"]
+            if c2.get("baseband", {}).get("symbols_equal_oracle_head4096_clear", 1.0) < 1.0:
+                gate_failures.append("configs[2]: base-band symbols differ from the oracle on clear frames")
+            if c3.get("graph_equals_eager") is False:
+                gate_failures.append("configs[3]: graph replay differs from the eager launch")
+            if c3.get("head_rel_err_vs_oracle", 0.0) > 2e-5 or c3.get("head_peak_offsets_equal_oracle") is False:
+                gate_failures.append("configs[3]: stream head differs from the oracle")
+        if not multi and have_gpu and not args.no_hello1:
+            t_c = time.perf_counter()
+            try:
+                h1 = hello_world1(args, device, torch, mag_mean)
+                if h1["transmissions_decoded_exactly"] != h1["transmissions"] or not h1["gathered_equals_decoded"]:
+                    gate_failures.append("hello_world1: %d of %d transmissions decode"
+                                         % (h1["transmissions_decoded_exactly"], h1["transmissions"]))
+                h1["over_configs1_value"] = h1["value"] / value
+            except Exception as ex:
+                h1 = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+            h1["wall_s"] = time.perf_counter() - t_c
+            out["hello_world1"] = h1
         if not multi and have_gpu and not args.no_cpu_baseline:
             cb = cpu_baseline(frames[: 1 << 19].cpu().numpy(), mag_mean)
             # the oracle as the checker: GPU symbols of the measured run vs float64 oracle
-            head = cb.pop("symbols_f64_oracle_head")
-            out["symbols_equal_oracle_head4096"] = float((symbols[:4096].cpu().numpy() == head).mean())
+            head, clear = cb.pop("symbols_f64_oracle_head"), cb.pop("clear_head")
+            got = symbols[:4096].cpu().numpy()
+            out["symbols_equal_oracle_head4096"] = float((got == head).mean())
+            out["symbols_equal_oracle_head4096_clear"] = float((got[clear] == head[clear]).mean())
+            if not np.array_equal(got[clear], head[clear]):
+                gate_failures.append("configs[1]: symbols differ from the float64 oracle on clear frames")
             out["cpu_baseline"] = cb
+        out["gates_failed"] = gate_failures
         print(json.dumps(out), file=json_out, flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()
+    if gate_failures:
+        sys.stderr.write("bench.py: correctness gate(s) failed: %s\n" % "; ".join(gate_failures))
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

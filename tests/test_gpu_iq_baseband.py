@@ -31,21 +31,7 @@ def uchirp():
     return m
 
 
-def iq_stream(n_frames, n, fs=100000.0, carrier=18000.0, bw=3000.0, amp=1000.0, sigma=0.0, seed=5, inverted=True):
-    """A continuous pass-band stream of n-sample symbols behind 26 zeros of FIR history.
-    inverted: the notebook's modulator, x = A cos(2 pi (carrier - f_b(t)) t) (IQ_modulation.ipynb cell 4), f_b the
-    base-band chirp -bw/2 .. +bw/2 (up, bit 1) or back (down, bit 0); else a plain pass-band chirp around the carrier."""
-    rng = np.random.default_rng(seed)
-    t = np.arange(n) / fs
-    k = bw / (n / fs)
-    bits = rng.integers(0, 2, n_frames).astype(np.uint8)
-    out = [np.zeros(26)]
-    for b in bits:
-        fb = (-bw / 2 + k * t / 2.0) if b else (bw / 2 - k * t / 2.0)
-        out.append(amp * np.cos(2 * np.pi * ((carrier - fb) if inverted else (carrier + fb)) * t))
-    x = np.concatenate(out)
-    x[26:] += sigma * rng.standard_normal(x.size - 26)
-    return x.astype(np.float32), bits
+from uchirp.synth import iq_stream  # noqa: E402  (the pass-band stream of BASELINE configs[2]; shared with bench.py)
 
 
 BB = dict(fs=100000.0, carrier=18000.0, f0=16500.0, f1=19500.0)   # BASELINE configs[2]: +-1.5 kHz around 18 kHz

@@ -8,6 +8,12 @@ sigma = A * 10^(-SNR/20).
 
   chirp_pair / make_frames        numpy, host (tests, small cases)
   device_frames                   BASELINE configs[1]: random bits, generated on the device
+  iq_symbol_pair / iq_stream / device_iq_stream
+                                  BASELINE configs[2]: a continuous real pass-band stream at
+                                  fs = 100 kHz, one n-sample symbol after the other, x = A cos(2 pi (carrier - f_b(t)) t)
+                                  with the base-band chirp f_b = -+1.5 kHz -> +-1.5 kHz (the notebook's modulator,
+                                  simulation/IQ_modulation.ipynb cell 4; generator/ChirpGeneratorIQmodulation.ipynb cell 5),
+                                  behind 26 zeros of FIR history
   hello_kinds / device_hello_frames / decode_hello
                                   BASELINE configs[4]: the K7 wire format (G, 7 x H, L, 96 data bits of
                                   "Hello World!", 12 x G: generator/ChirpGenerator.ipynb cells 1-3) repeated to
@@ -72,6 +78,50 @@ def device_frames(n_frames, device, seed, snr_db=-10.0, amp=1000.0, n=N):
     g.manual_seed(seed)
     bits = torch.randint(0, 2, (n_frames,), generator=g, device=device, dtype=torch.int64)
     return _fill_device(bits, device, g, snr_db, amp, n), bits.to(torch.uint8)
+
+
+def iq_symbol_pair(n, fs=100000.0, carrier=18000.0, bw=3000.0, amp=1000.0, inverted=True):
+    """(up, down) float64 pass-band symbols of n samples.  inverted: the notebook's modulator
+    x = A cos(2 pi (carrier - f_b(t)) t), f_b the base-band chirp -bw/2 .. +bw/2 (up, bit 1) or back (down, bit 0);
+    else a plain pass-band chirp around the carrier."""
+    t = np.arange(n, dtype=np.float64) / fs
+    k = bw / (n / fs)
+    out = []
+    for up in (True, False):
+        fb = (-bw / 2 + k * t / 2.0) if up else (bw / 2 - k * t / 2.0)
+        out.append(amp * np.cos(2 * np.pi * ((carrier - fb) if inverted else (carrier + fb)) * t))
+    return out[0], out[1]
+
+
+def iq_stream(n_frames, n, fs=100000.0, carrier=18000.0, bw=3000.0, amp=1000.0, sigma=0.0, seed=5, inverted=True):
+    """Host version: (stream float32 [26 + n_frames * n], bits uint8); the first 26 samples are zeros (FIR history)."""
+    rng = np.random.default_rng(seed)
+    up, down = iq_symbol_pair(n, fs, carrier, bw, amp, inverted)
+    bits = rng.integers(0, 2, n_frames).astype(np.uint8)
+    x = np.concatenate([np.zeros(26)] + [up if b else down for b in bits])
+    x[26:] += sigma * rng.standard_normal(x.size - 26)
+    return x.astype(np.float32), bits
+
+
+def device_iq_stream(n_frames, n, device, seed, snr_db=-10.0, amp=1000.0, fs=100000.0, carrier=18000.0, bw=3000.0):
+    """configs[2] on the device: (stream float32 [26 + n_frames * n], bits uint8).  Noise as configs[1]:
+    sigma = A 10^(-SNR/20)."""
+    import torch
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    bits = torch.randint(0, 2, (n_frames,), generator=g, device=device, dtype=torch.int64)
+    up, down = iq_symbol_pair(n, fs, carrier, bw, amp)
+    tab = torch.tensor(np.stack([down, up]), dtype=torch.float32, device=device)
+    x = torch.empty(26 + n_frames * n, dtype=torch.float32, device=device)
+    x[:26] = 0.0
+    body = x[26:].view(n_frames, n)
+    sigma = amp * 10.0 ** (-snr_db / 20.0)
+    chunk = 1 << 16
+    for s0 in range(0, n_frames, chunk):
+        e0 = min(n_frames, s0 + chunk)
+        body[s0:e0] = tab[bits[s0:e0]]
+        body[s0:e0] += sigma * torch.randn((e0 - s0, n), generator=g, device=device)
+    return x, bits.to(torch.uint8)
 
 
 def hello_kinds(msg="Hello World!"):
