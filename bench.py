@@ -336,6 +336,9 @@ def config3_stream(args, frames, device, torch):
     with torch.cuda.stream(s2):
         with torch.cuda.graph(g, stream=s2):
             eng.process_stream(x, compressed_out=comp_g, peaks_out=pk_g, stream=s2.cuda_stream)
+        # (capture + instantiation leave the GPU idle for a while: the same clock ramp as in front of every timed loop --
+        # without it the first replays run ~9 % slow, and so do eager launches at that moment: profiles/r03_graph_rate_probe.txt)
+        clock_ramp(g.replay, torch, args.ramp_ms)
         wall, kern = timed_launches(g.replay, s2, torch, steps, warm)
     torch.cuda.synchronize()
     out["graph_replay"] = {"value": x.numel() / (wall * 1e-3), "unit": "samples/s", "ms_per_step": wall,

@@ -6,6 +6,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -29,6 +31,8 @@ def test_gpus_2_starts_two_ranks_and_decodes_hello_world():
     assert d["decoded_text_first"] == "Hello World!"
     assert d["transmissions"] == 2 * 1170 // 117 and d["transmissions_decoded_exactly"] == d["transmissions"]
     assert d["value"] is None and "rehearsal" in d      # no GPU here: never a measurement
+    # every rank's own kernel and step time ride in the N > 1 line
+    assert len(d["per_rank"]["kernel_ms_by_rank"]) == 2 and d["per_rank"]["ms_per_step"]["max"] > 0 and d["gates_failed"] == []
 
 
 def test_gpus_must_equal_world_size():
@@ -55,10 +59,58 @@ def test_stdout_is_exactly_one_json_line_for_n_ranks():
 
 def test_hello_leg_runs_at_world_size_one():
     p = _run(["--frames", "1170", "--steps", "2", "--warmup", "1"],
-             {"UC_BENCH_REHEARSE": "1", "UC_BENCH_HELLO": "1", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": "",
-              "MASTER_PORT": "29541"})
+             {"UC_BENCH_REHEARSE": "1", "UC_BENCH_HELLO": "1", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.strip()]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("configs[4]") and d["decoded_text_first"] == "Hello World!"
+
+
+# ---- on the GPU box: the legs of bench.py the driver's 8-GPU run depends on, as fresh child processes -----------------
+
+def _one_line(p):
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_gpu_two_rank_rehearsal_runs_the_real_kernel_and_decodes():
+    """`--gpus 2` as the driver's launcher would run it, both ranks on device 0 (one-GPU box), gloo gather: spawn,
+    rendezvous, the real kernel on every rank, gather every step, digest agreement, decode, per-rank statistics."""
+    d = _one_line(_run(["--gpus", "2", "--frames", "65536", "--steps", "3", "--warmup", "1"], {"UC_BENCH_REHEARSE": "1"}))
+    assert d["n_gpus"] == 2 and d["config"]["workload"].startswith("configs[4]")
+    assert d["transmissions"] == 2 * 65536 // 117 and d["transmissions_decoded_exactly"] == d["transmissions"]
+    assert d["value"] > 0 and abs(d["value_per_gpu"] * 2 - d["value"]) < 1e-6 * d["value"]
+    assert len(d["per_rank"]["kernel_ms_by_rank"]) == 2 and min(d["per_rank"]["kernel_ms_by_rank"]) > 0
+    assert d["gather_ms_exposed"] is not None and d["gates_failed"] == []
+    assert d["roofline"]["kernel"] == "band_kernel<rx_real,f32>" and "valu" in d["roofline"]
+
+
+@pytest.mark.gpu
+def test_gpu_hello_leg_on_rccl_at_world_size_one():
+    """The N > 1 leg on RCCL itself (process group with device_id, asynchronous all_gather_into_tensor, digest check,
+    decode) with the world a one-GPU box has."""
+    d = _one_line(_run(["--frames", "65536", "--steps", "3", "--warmup", "1"], {"UC_BENCH_HELLO": "1"}))
+    assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("configs[4]")
+    assert d["transmissions_decoded_exactly"] == d["transmissions"] == 65536 // 117
+    assert d["decoded_text_first"] == "Hello World!" and "rehearsal" not in d and d["gates_failed"] == []
+
+
+@pytest.mark.gpu
+def test_gpu_default_line_carries_every_single_gpu_config():
+    """The N = 1 contract line (small batch): configs[1] headline + configs[2] (base-band I/Q and firmware windows) +
+    configs[3] (eager and graph replay) + hello_world1 + cpu_baseline, all gates green."""
+    d = _one_line(_run(["--frames", "65536", "--steps", "3", "--warmup", "1", "--ramp-ms", "20"], {}))
+    assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("configs[1]") and d["gates_failed"] == []
+    assert d["roofline"]["bound"] in ("hbm", "valu") and d["roofline"]["traffic_source"].startswith("NOT measured in this run")
+    c2, c3 = d["configs"]["configs[2]"], d["configs"]["configs[3]"]
+    assert c2["baseband"]["symbols_equal_oracle_head4096_clear"] == 1.0 and c2["baseband"]["bit_error_rate_vs_transmitted"] < 0.03
+    assert c2["baseband"]["roofline"]["kernel"].startswith("iq1024_kernel") and c2["firmware_windows"]["value"] > 0
+    assert c3["graph_equals_eager"] is True and c3["head_rel_err_vs_oracle"] < 2e-5 and c3["head_peak_offsets_equal_oracle"]
+    assert c3["graph_replay"]["value"] > 0 and c3["eager"]["value"] > 0 and c3["samples"] == 65536 * 2048
+    h = d["hello_world1"]
+    assert h["transmissions_decoded_exactly"] == h["transmissions"] == 65536 // 117 and h["gathered_equals_decoded"]
+    assert d["symbols_equal_oracle_head4096_clear"] == 1.0 and d["cpu_baseline"]["kind"] == "port"

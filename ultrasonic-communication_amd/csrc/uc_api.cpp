@@ -609,6 +609,9 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
       ip.ifs = (uint32_t)(int32_t)c->cfg.fs;
       ip.snr_threshold = c->cfg.snr_threshold;
     }
+#if defined(UC_CLOCKSTAMP)
+    if (const char* d = getenv("UC_DEBUG_PTR")) ip.debug = (unsigned long long*)strtoull(d, nullptr, 0);
+#endif
     ip.fir_mfma = (n == 1024 && c->iq_fir_mfma) ? c->d_aux : nullptr;
     ip.stagger = c->iq_stagger;
     int& iq_bpc = c->iq_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
@@ -652,6 +655,9 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     fp.symbols = d_sym;
     fp.stats = d_stats;
     fp.mag_mean_scalar = c->cfg.mag_mean;
+#if defined(UC_CLOCKSTAMP)
+    if (const char* d = getenv("UC_DEBUG_PTR")) fp.debug = (unsigned long long*)strtoull(d, nullptr, 0);
+#endif
     int& full_bpc = c->full_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
     if (full_bpc == 0) full_bpc = uc::compress_max_blocks_per_cu(dtype);
     size_t grid = (size_t)c->num_cu * (size_t)full_bpc;
@@ -954,6 +960,9 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
   sp.tw = c->d_tw;
   sp.compressed = d_comp;
   sp.peaks = d_peaks;
+#if defined(UC_CLOCKSTAMP)
+  if (const char* d = getenv("UC_DEBUG_PTR")) sp.debug = (unsigned long long*)strtoull(d, nullptr, 0);
+#endif
   for (int k = 0; k < 2 * uc::kFirTapsDev; k++) sp.ctap[k] = c->stab.ctap[k];
   const int D = (int)c->stab.decim;
   for (int sub = 0; sub < D / 2; sub++) {

@@ -315,12 +315,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_readcyclecounter();
 #endif
-#ifdef UC_CLOCKSTAMP
-  // Diagnostic build only (-DUC_CLOCKSTAMP, libuchirp_clock.so): ONE stamp pair around the whole
-  // persistent loop; shader clock = d(s_memtime) / d(s_memrealtime) x 100 MHz (tools/clock_probe.py).
-  const unsigned long long clk0_ = __builtin_readcyclecounter();
-  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
-#endif
+  UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
   constexpr bool kTw2Lds = WAVES >= 4;
   constexpr int kNextOff = next_off(WAVES);
   __shared__ __attribute__((aligned(16))) float lds[lds_floats(WAVES)];
@@ -902,16 +897,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     for (int k = 0; k < 10; k++) p.debug[((size_t)blockIdx.x * 2 + wave) * 10 + k] = acc_[k];
   }
 #endif
-#ifdef UC_CLOCKSTAMP
-  if (lane == 0 && p.debug) {
-    const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();
-    unsigned long long* d_ = p.debug + ((size_t)blockIdx.x * 2 + wave) * 4;
-    d_[0] = __builtin_readcyclecounter() - clk0_;
-    d_[1] = rt1_ - rt0_;
-    d_[2] = rt0_;  // absolute 100 MHz stamps: start / end skew across the grid
-    d_[3] = rt1_;
-  }
-#endif
+  UC_CLOCK_END(p.debug, 2);
 }
 
 template <int MODE, int DTYPE, int WAVES, bool WIDE = false>

@@ -59,6 +59,30 @@ __device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
   *reinterpret_cast<v2f*>(lds + 2 * cidx) = v;
 }
 
+// ---- diagnostic build only (-DUC_CLOCKSTAMP, libuchirp_clock.so; tools/clock_probe.py) -----------------------------------
+// ONE s_memtime / s_memrealtime stamp pair around a kernel's whole persistent loop: shader clock under this kernel =
+// d(s_memtime) / d(s_memrealtime) x 100 MHz.  Four words per wave go to `dbg` (never read by a kernel, never part of
+// an output): cycles, 100 MHz ticks, absolute start and end ticks (start / end skew across the grid).
+#ifdef UC_CLOCKSTAMP
+#define UC_CLOCK_BEGIN()                                              \
+  const unsigned long long clk0_ = __builtin_readcyclecounter();     \
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime()
+#define UC_CLOCK_END(dbg, waves_per_wg)                                                                          \
+  do {                                                                                                           \
+    if ((threadIdx.x & 63) == 0 && (dbg)) {                                                                      \
+      const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();                                          \
+      unsigned long long* d_ = (dbg) + ((size_t)blockIdx.x * (waves_per_wg) + (threadIdx.x >> 6)) * 4;            \
+      d_[0] = __builtin_readcyclecounter() - clk0_;                                                              \
+      d_[1] = rt1_ - rt0_;                                                                                       \
+      d_[2] = rt0_;                                                                                              \
+      d_[3] = rt1_;                                                                                              \
+    }                                                                                                            \
+  } while (0)
+#else
+#define UC_CLOCK_BEGIN() do { } while (0)
+#define UC_CLOCK_END(dbg, waves_per_wg) do { } while (0)
+#endif
+
 // ---- dynamic hand-out counters (uc_api.cpp: take_work_counter) -----------------------------------
 // ctr[0] = the next ticket, ctr[1] = workgroups that have left.  Every workgroup of a dynamically dealt launch calls
 // this ONCE, from one thread, on its way out; the last one to leave puts both words back to zero.  A counter slot is

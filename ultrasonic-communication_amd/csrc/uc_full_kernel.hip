@@ -108,6 +108,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   const int j = threadIdx.x;
   const int lane = j & 63;
   const int wave = j >> 6;
+  UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
 
   // Static: a balanced contiguous partition of the frame pairs.  Dynamic (p.work_ctr): chunks of G = 2^chunk_log2
   // consecutive pairs; a workgroup starts with chunk blockIdx.x and takes every further one from an atomic counter
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
   __syncthreads();
   if (pending) publish(qprev);
   if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
+  UC_CLOCK_END(p.debug, 2);
 }
 
 }  // namespace

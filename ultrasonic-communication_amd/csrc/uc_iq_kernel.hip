@@ -127,6 +127,7 @@ static_assert(kRingFrBb * kRingStBb <= kRingFr * kRingSt, "the base-band ring fi
 
 template <int DTYPE, bool BB>
 __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
+  UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
   __shared__ __attribute__((aligned(16))) float lds[kLdsAll];
   float* img = lds;
   float* tile = lds + kTileOff;
@@ -422,6 +423,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   __syncthreads();
   if (ring_n > 0 && wave == 0) finalise(ring_f0, ring_n);
   if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
+  UC_CLOCK_END(p.debug, 2);
 }
 
 
@@ -466,6 +468,7 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 // S the mixed samples.  11 k-steps x (I, Q) x 4 tile pairs = 88 MFMAs per frame instead of 432 packed FMAs per lane.
 template <int DTYPE, bool BB, int FIRM>
 __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
+  UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
   constexpr int kGrow = FIRM ? kImgGrow1 : 0;
   __shared__ __attribute__((aligned(16))) float lds[(BB ? kLdsFloats1Bb : kLdsFloats1) + kGrow];
   float* ring = lds + kRingOff1 + kGrow;
@@ -825,6 +828,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   __syncthreads();
   if (ring_n > 0) finalise(ring_f0, ring_n);
   if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
+  UC_CLOCK_END(p.debug, 1);
 }
 
 }  // namespace

@@ -67,6 +67,7 @@ struct FullParams {
   unsigned int* work_ctr;  // device word, zero at launch: chunks of 2^chunk_log2 consecutive frame pairs, the ones after a
   uint32_t chunk_log2;     // workgroup's first handed out by atomic increments (chunk_log2 >= 1); nullptr = a balanced
                            // contiguous partition of the pairs
+  unsigned long long* debug;  // diagnostic builds only (UC_CLOCKSTAMP), else nullptr
 };
 int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream);
 int compress_max_blocks_per_cu(int dtype);
@@ -99,6 +100,7 @@ struct IqParams {
   float snr_threshold;
   unsigned int* work_ctr;     // device word, zero at launch: groups beyond a workgroup's first are handed out
                               // dynamically, group id = gridDim.x + the value an atomic increment returns; nullptr = static deal
+  unsigned long long* debug;  // diagnostic builds only (UC_CLOCKSTAMP), else nullptr
 };
 // n = 2048 (the committed firmware) or 1024 (one wave per frame)
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
@@ -120,6 +122,7 @@ struct StreamParams {
   unsigned int* work_ctr;       // device word, zero at launch: chunks of 2^chunk_log2 consecutive blocks, the ones after a
   uint32_t chunk_log2;          // workgroup's first handed out by atomic increments; nullptr = a
                                 // balanced contiguous partition of the blocks
+  unsigned long long* debug;    // diagnostic builds only (UC_CLOCKSTAMP), else nullptr
 };
 int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream);
 int stream_max_blocks_per_cu(int dtype, int decim);

@@ -81,6 +81,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
 
   const int j = threadIdx.x;
   const int wave = j >> 6;
+  UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
 
   // Static: a balanced contiguous partition of the blocks, workgroup w takes base (+1 for the first `rem`) blocks.
   // Dynamic (p.work_ctr): chunks of G = 2^chunk_log2 consecutive blocks; a workgroup starts with chunk blockIdx.x and
@@ -312,6 +313,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     if (hop) bend = b + gmask + 1u < nblk ? b + gmask + 1u : nblk;
   }
   if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
+  UC_CLOCK_END(p.debug, 2);
 }
 
 template <int DTYPE, int D>
