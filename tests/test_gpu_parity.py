@@ -899,6 +899,30 @@ def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch, uc_tuni
             assert np.array_equal(stt.cpu().numpy().view(np.uint32), want[-1][1].view(np.uint32)), rep
 
 
+def test_many_launches_in_flight_on_several_streams(uchirp, monkeypatch, uc_tuning):
+    """One context, 300 launches queued on three streams without a wait in between (a ring of 64 hand-out counters):
+    a counter is never shared by two launches in flight -- a launch whose slot is still in use deals statically -- so
+    every launch produces the eager reference's bytes.  The first launches all go to ONE stream (no events), then the
+    context is used from the others (the switch event + per-slot events)."""
+    import torch
+    dev = torch.device("cuda:0")
+    monkeypatch.setenv("UC_GRID", "5")
+    e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+    monkeypatch.delenv("UC_GRID")
+    n_frames = 2000
+    frames = torch.from_numpy(synth.make_frames(n_frames, seed=123, snr_db=-5.0)[0]).to(dev)
+    want, _ = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0).process(frames, want_stats=False)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [torch.zeros(n_frames, dtype=torch.uint8, device=dev) for _ in range(300)]
+    for k, o in enumerate(outs):
+        st = streams[0] if k < 100 else streams[k % 3]
+        e.process(frames, want_stats=False, symbols_out=o, stream=st.cuda_stream)
+    torch.cuda.synchronize()
+    bad = [k for k, o in enumerate(outs) if not torch.equal(o, want)]
+    assert not bad, bad[:10]
+
+
 def test_compress_pair_chunks_dynamic_hand_out(uchirp, monkeypatch, uc_tuning):
     """The compress kernel deals frame PAIRS in chunks of consecutive pairs; a workgroup's first chunk is fixed, every
     further one comes from an atomic counter asked one pair ahead (csrc/uc_full_kernel.hip).  Tiny grids (UC_GRID),

@@ -57,7 +57,9 @@ launch()
 b.record(stream)
 torch.cuda.synchronize()
 d = dbg.cpu().numpy().reshape(-1, 4)
-d = d[d[:, 1] > 0].astype(np.float64)
+d = d[d[:, 1] > 0]
+d[:, 0] &= (1 << 40) - 1                      # (bits 40..51 of the cycle word name the CU: tools/run_target.py)
+d = d.astype(np.float64)
 t_first, t_last = d[:, 2].min(), d[:, 3].max()
 start_us, end_us, life_us = (d[:, 2] - t_first) / 100.0, (d[:, 3] - t_first) / 100.0, d[:, 1] / 100.0
 pct = lambda v: [float(np.percentile(v, q)) for q in (0, 10, 50, 90, 100)]

@@ -135,9 +135,16 @@ a.record(stream)
 launch()
 b.record(stream)
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(-1, 4)
-d = d[d[:, 1] > 0].astype(np.float64)
+raw = dbg.cpu().numpy().reshape(-1, 4)
+raw = raw[raw[:, 1] > 0]
+cu_key = (raw[:, 0] >> 40) & 0xfff            # XCC_ID << 8 | HW_ID[15:8]: the CU that ran the wave
+d = raw.astype(np.float64)
+d[:, 0] = (raw[:, 0] & ((1 << 40) - 1)).astype(np.float64)
 t_first, t_last = d[:, 2].min(), d[:, 3].max()
+# per CU: when its LAST wave ended (the CU is out of work from then on) and when its first one started
+cus = np.unique(cu_key)
+cu_last = np.array([d[cu_key == c, 3].max() for c in cus])
+cu_idle_us = (t_last - cu_last) / 100.0        # idle tail of each CU inside the grid span
 start_us, end_us, life_us = (d[:, 2] - t_first) / 100.0, (d[:, 3] - t_first) / 100.0, d[:, 1] / 100.0
 
 
@@ -155,4 +162,6 @@ print(json.dumps({
     "loop_us_median": float(np.median(d[:, 1]) / 100.0), "units_per_s": units / wall,
     "grid_span_us_first_start_to_last_end": float((t_last - t_first) / 100.0),
     "wave_start_us_p0_10_50_90_100": pct(start_us), "wave_end_us_p0_10_50_90_100": pct(end_us),
-    "wave_life_us_p0_10_50_90_100": pct(life_us)}))
+    "wave_life_us_p0_10_50_90_100": pct(life_us),
+    "cus_seen": int(cus.size), "cu_idle_tail_us_p0_10_50_90_100": pct(cu_idle_us), "cu_idle_tail_us_mean": float(cu_idle_us.mean()),
+    "wave_idle_tail_us_mean": float(((t_last - d[:, 3]) / 100.0).mean())}))

@@ -128,8 +128,17 @@ struct uc_ctx {
   void* h_slot = nullptr;  // uc_process_frame: pinned, device-mapped host memory for one frame and its results
   unsigned work_next = 0;
   unsigned graph_next = 0;              // graph-owned slots handed out so far (never recycled)
-  hipEvent_t work_ev[kWorkSlots] = {};  // recorded behind the launch that used ring slot i
+  hipEvent_t work_ev[kWorkSlots] = {};  // recorded behind the launch that used ring slot i (several streams only)
   bool work_busy[kWorkSlots] = {};      // slot i has been used and its event not yet seen complete
+  // As long as every eager launch of the context goes to ONE stream, stream order alone keeps a slot from being
+  // shared (its previous user finished 64 launches earlier on the same stream) and no event is recorded at all.
+  // The first launch on a second stream records `switch_ev` on the first one -- it covers every slot used so far --
+  // and from then on every launch records its slot's event.
+  hipStream_t ring_stream = nullptr;
+  bool ring_stream_set = false, multi_stream = false;
+  hipEvent_t switch_ev = nullptr;
+  bool wait_switch[kWorkSlots] = {};    // slot i was last used before the switch: free once switch_ev has completed
+  bool slot_used[kWorkSlots] = {};
 };
 
 extern "C" {
@@ -303,6 +312,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
       if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
     }
     if (const char* g = getenv("UC_STATIC_DEAL")) c->static_deal = atoi(g) != 0;
+    if (const char* g = getenv("UC_SLOT_EVENTS")) c->multi_stream = atoi(g) != 0;  // record an event behind every launch
     if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
     if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
     if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
@@ -367,6 +377,10 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
       e = hipEventCreateWithFlags(&c->work_ev[i], hipEventDisableTiming);
       if (e != hipSuccess) { c->work_ev[i] = nullptr; rc = hip_fail(e, "hipEventCreate(work counter)"); }
     }
+    if (!rc) {
+      e = hipEventCreateWithFlags(&c->switch_ev, hipEventDisableTiming);
+      if (e != hipSuccess) { c->switch_ev = nullptr; rc = hip_fail(e, "hipEventCreate(work counter)"); }
+    }
   }
   if (!rc) rc = upload_device_tables(c);
   if (!rc && cfg->variant == UC_IQ) {
@@ -399,6 +413,7 @@ void uc_destroy(uc_ctx* c) {
   if (c->d_work) (void)hipFree(c->d_work);
   for (unsigned i = 0; i < kWorkSlots; i++)
     if (c->work_ev[i]) (void)hipEventDestroy(c->work_ev[i]);
+  if (c->switch_ev) (void)hipEventDestroy(c->switch_ev);
   if (c->h_slot) (void)hipHostFree(c->h_slot);
   if (c->d_cic_ctr) (void)hipFree(c->d_cic_ctr);
   if (c->d_aux) (void)hipFree(c->d_aux);
@@ -476,7 +491,8 @@ int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
 //   eager launch : the next slot of the context's ring; *slot = its index (pass it to work_counter_launched() behind
 //                  the launch).  If the launch that last used that slot is still running (64 or more launches of ONE
 //                  context in flight on several streams) the counter would be shared: *out = nullptr, the caller deals
-//                  this launch statically.
+//                  this launch statically.  While the context has only ever launched on one stream, stream order is
+//                  the guard and no event is recorded or queried.
 //   capture      : a slot the graph owns from now on (kGraphSlots per context, never recycled): two graphs replayed on
 //                  two streams never share a counter, and a graph's own replays are serialised by the runtime.
 //                  *slot = -1.  When the graph slots are used up: nullptr (static deal).
@@ -490,12 +506,31 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, 
     if (c->graph_next >= kGraphSlots) return 0;
     idx = kWorkSlots + c->graph_next++;
   } else {
+    if (!c->multi_stream) {
+      if (!c->ring_stream_set) {
+        c->ring_stream = stream;
+        c->ring_stream_set = true;
+      } else if (stream != c->ring_stream) {
+        const hipError_t e = hipEventRecord(c->switch_ev, c->ring_stream);
+        if (e != hipSuccess) return hip_fail(e, "hipEventRecord(stream switch)");
+        for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = c->slot_used[i];
+        c->multi_stream = true;
+      }
+    }
     idx = c->work_next % kWorkSlots;
-    if (c->work_busy[idx]) {
-      const hipError_t q = hipEventQuery(c->work_ev[idx]);
-      if (q == hipErrorNotReady) return 0;  // still in flight: do not advance, deal this launch statically
-      if (q != hipSuccess) return hip_fail(q, "hipEventQuery(work counter)");
-      c->work_busy[idx] = false;
+    if (c->multi_stream) {
+      if (c->wait_switch[idx]) {
+        const hipError_t q = hipEventQuery(c->switch_ev);
+        if (q == hipErrorNotReady) return 0;  // launches from before the switch still run: deal this one statically
+        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(stream switch)");
+        for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = false;
+      }
+      if (c->work_busy[idx]) {
+        const hipError_t q = hipEventQuery(c->work_ev[idx]);
+        if (q == hipErrorNotReady) return 0;  // still in flight: do not advance, deal this launch statically
+        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(work counter)");
+        c->work_busy[idx] = false;
+      }
     }
     c->work_next++;
     *slot = (int)idx;
@@ -507,6 +542,8 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, 
 // behind the launch that uses ring slot `slot` (no-op for -1: static deal or a graph-owned slot)
 static int work_counter_launched(uc_ctx* c, hipStream_t stream, int slot) {
   if (slot < 0) return 0;
+  c->slot_used[slot] = true;
+  if (!c->multi_stream) return 0;  // one stream so far: stream order is the guard
   const hipError_t e = hipEventRecord(c->work_ev[slot], stream);
   if (e != hipSuccess) return hip_fail(e, "hipEventRecord(work counter)");
   c->work_busy[slot] = true;
@@ -615,7 +652,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     ip.fir_mfma = (n == 1024 && c->iq_fir_mfma) ? c->d_aux : nullptr;
     ip.stagger = c->iq_stagger;
     int& iq_bpc = c->iq_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
-    if (iq_bpc == 0) iq_bpc = uc::iq_max_blocks_per_cu(dtype, (int)n, bb ? 1 : 0, ip.fir_mfma ? 1 : 0);
+    if (iq_bpc == 0) iq_bpc = uc::iq_max_blocks_per_cu(dtype, (int)n, bb ? 1 : 0, ip.fir_mfma ? 1 : 0,
+                                                      ip.bw2 <= (n == 1024 ? 32u : 64u) ? 1 : 0);
     size_t grid = (size_t)c->num_cu * (size_t)iq_bpc;
     if (c->grid_override > 0) grid = (size_t)c->grid_override;
     if (grid > n_frames) grid = n_frames;

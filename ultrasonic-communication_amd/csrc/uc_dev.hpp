@@ -62,7 +62,8 @@ __device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
 // ---- diagnostic build only (-DUC_CLOCKSTAMP, libuchirp_clock.so; tools/clock_probe.py) -----------------------------------
 // ONE s_memtime / s_memrealtime stamp pair around a kernel's whole persistent loop: shader clock under this kernel =
 // d(s_memtime) / d(s_memrealtime) x 100 MHz.  Four words per wave go to `dbg` (never read by a kernel, never part of
-// an output): cycles, 100 MHz ticks, absolute start and end ticks (start / end skew across the grid).
+// an output): cycles (low 40 bits; bits 40..51 name the CU), 100 MHz ticks, absolute start and end ticks (start / end
+// skew across the grid and, grouped by CU, when each CU ran out of work).
 #ifdef UC_CLOCKSTAMP
 #define UC_CLOCK_BEGIN()                                              \
   const unsigned long long clk0_ = __builtin_readcyclecounter();     \
@@ -72,7 +73,10 @@ __device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
     if ((threadIdx.x & 63) == 0 && (dbg)) {                                                                      \
       const unsigned long long rt1_ = __builtin_amdgcn_s_memrealtime();                                          \
       unsigned long long* d_ = (dbg) + ((size_t)blockIdx.x * (waves_per_wg) + (threadIdx.x >> 6)) * 4;            \
-      d_[0] = __builtin_readcyclecounter() - clk0_;                                                              \
+      /* bits 40..51: which CU ran the wave -- XCC_ID[3:0] (hwreg 20) and HW_ID's cu / sh / se fields [15:8] */   \
+      const unsigned long long cu_ = ((unsigned long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15u) << 8) | \
+                                     ((__builtin_amdgcn_s_getreg(4 | (8 << 6) | (7 << 11))) & 255u);              \
+      d_[0] = ((__builtin_readcyclecounter() - clk0_) & 0xffffffffffull) | (cu_ << 40);                          \
       d_[1] = rt1_ - rt0_;                                                                                       \
       d_[2] = rt0_;                                                                                              \
       d_[3] = rt1_;                                                                                              \

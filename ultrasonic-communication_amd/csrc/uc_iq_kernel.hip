@@ -125,7 +125,10 @@ static_assert((kTw2O & 1) == 0, "complex alignment");
 static_assert(kImg >= kN, "exchange 1 lives in the image area");
 static_assert(kRingFrBb * kRingStBb <= kRingFr * kRingSt, "the base-band ring fits the same LDS");
 
-template <int DTYPE, bool BB>
+// BB: 0 = the firmware's windows, 1 = UC_FLAG_IQ_BASEBAND, 2 = base band with windows of at most 64 bins each (61 at
+// BASELINE configs[2]'s constants): wave 0 owns the left window's bins, wave 1 the right window's -- ONE pruned round,
+// one wave reduction per dechirp run and wave.
+template <int DTYPE, int BB>
 __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
   __shared__ __attribute__((aligned(16))) float lds[kLdsAll];
@@ -183,10 +186,12 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   for (int e = j; e < 256; e += T) lds_st(tw2l, e, buf_ld64(rs_tw, ((8 * (e >> 4) * (e & 15)) & (kN - 1)) * 8, 0));
   const int tw2o = j & 15;  // + 16 t
   // pass-3 twiddles of bins k = lo + j and lo + 128 + j: W^k and W^2k (Horner form)
+  // (BB == 2: one bin per thread -- lo + lane on wave 0, center + lane on wave 1)
+  const int kk2 = (wave == 0) ? lo + lane : center + lane;
   v2f t3w1[2], t3w2[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
-    const int k = lo + T * r + j;
+    const int k = (BB == 2) ? kk2 : lo + T * r + j;
     t3w1[r] = buf_ld64(rs_tw, (k & (kN - 1)) * 8, 0);
     t3w2[r] = buf_ld64(rs_tw, ((2 * k) & (kN - 1)) * 8, 0);
   }
@@ -337,42 +342,70 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is read)
 
     // ---- stage 2: (I + jQ) * down_chirp * hann, FFT pass 1 -------------------------------
-    // Base band: two dechirp runs (conj(up), conj(down)) over the SAME filtered frame.  Run 0 keeps the
-    // filtered frame in `tile` intact: its pass 2 goes back into the image area (one more barrier), and its
-    // pruned pass reads from there.
+    // Base band: two dechirp runs (conj(up), conj(down)) over the SAME filtered frame, which is read from the tile
+    // ONCE and stays in vr[]: the tile is free again behind B3.
     constexpr int kRuns = BB ? 2 : 1;
+    v2f vr[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) vr[t] = lds_ld(tile, ((t & 1) ? rd1o : rd1e) + 128 * t);
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
     v2f v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(tile, ((t & 1) ? rd1o : rd1e) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
     if (run == 0) {
 #pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(vr[t], ch[t]);
     } else {
 #pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], buf_ld64(rs_ch2, voff8, T * 8 * t));
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(vr[t], buf_ld64(rs_ch2, voff8, T * 8 * t));
     }
     pk_dft16(v, K, H);
-    if (run) __syncthreads();  // run 0's pruned pass has read the image area
+    // (run 1: every pass-2 read of the image area by run 0 sits in front of run 0's B4)
 #pragma unroll
     for (int t = 0; t < 16; t++) lds_st(img, wr1 + (t ^ s1v), v[pk_slot16(t)]);
-    __syncthreads();  // B3
+    __syncthreads();  // B3: every read of the tile (vr; run 0's pruned pass) is done
 
     // ---- FFT pass 2 -----------------------------------------------------------------------
-    float* dst2 = (BB && run == 0) ? img : tile;
+    float* dst2 = tile;
 #pragma unroll
     for (int t = 0; t < 16; t++) v[t] = lds_ld(img, ((t & 1) ? rd1o : rd1e) + 128 * t);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2l, tw2o + 16 * t));
     pk_dft16(v, K, H);
-    if (BB && run == 0) __syncthreads();  // every pass-2 read of the image area is done
 #pragma unroll
     for (int t = 0; t < 16; t++) lds_st(dst2, wr2 + 16 * t, v[pk_slot16(t)]);
     __syncthreads();  // B4
 
+    if (BB == 2) {
+      // ---- FFT pass 3, pruned to ONE bin per thread; this wave's window maximum and its first attaining bin --------
+      v2f a[8];
+      const int b = kk2 & 255;
+#pragma unroll
+      for (int t = 0; t < 8; t++) a[t] = lds_ld(dst2, b + 256 * t);
+      __builtin_amdgcn_sched_barrier(0);
+      const v2f w1 = t3w1[0], w2 = t3w2[0];
+      v2f e_ = pk_cfma(a[6], w2, a[4]), o_ = pk_cfma(a[7], w2, a[5]);
+      e_ = pk_cfma(e_, w2, a[2]); o_ = pk_cfma(o_, w2, a[3]);
+      e_ = pk_cfma(e_, w2, a[0]); o_ = pk_cfma(o_, w2, a[1]);
+      const v2f z = pk_cfma(o_, w1, e_);
+      const float q = z.x * z.x + z.y * z.y;
+      const bool valid = lane < bw2;
+      const float c = valid ? q : -INFINITY;
+      const float m = wave_max_f32(c);
+      const unsigned long long hit = __ballot(valid && c == m);
+      const unsigned long long nan = __ballot(q != q);
+      if (lane == 0) {
+        const int k = kk2 + (hit ? __ffsll((long long)hit) - 1 : 0);
+        float* e = ring + ring_n * kRingStBb + 5 * wave + 10 * run;
+        // wave 0 reports the left window, wave 1 the right one; the other half of the entry loses every merge
+        e[0] = wave == 0 ? m : -INFINITY;
+        e[1] = __int_as_float(wave == 0 ? k : 0x7fffffff);
+        e[2] = wave == 0 ? -INFINITY : m;
+        e[3] = __int_as_float(wave == 0 ? 0x7fffffff : k);
+        e[4] = __int_as_float((int)(nan & 1ull) << wave);  // first element of this wave's window is NaN
+      }
+    } else {
     // ---- FFT pass 3, pruned: bins k = lo + j and k = lo + 128 + j (< lo + bw4) ------------
     float q[2] = {0.f, 0.f};
     {
@@ -414,6 +447,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
         e[3] = __int_as_float(kr);
         e[4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
       }
+    }
     }
     }  // run
     ring_n++;
@@ -466,7 +500,10 @@ typedef float v4acc __attribute__((ext_vector_type(4)));
 // the transform's packed-VALU work of the SIMD's other waves: outputs 16 b + i of 16 blocks b = T^ x S, T the
 // 16 x 44 Toeplitz matrix of the taps (rows i, columns = the 42 samples the 16 outputs see, zero padded to 44),
 // S the mixed samples.  11 k-steps x (I, Q) x 4 tile pairs = 88 MFMAs per frame instead of 432 packed FMAs per lane.
-template <int DTYPE, bool BB, int FIRM>
+// BB: 0 = the firmware's windows, 1 = UC_FLAG_IQ_BASEBAND, 2 = base band with windows of at most 32 bins each (BASELINE
+// configs[2]: 30): lanes 0-31 own the left window's bins, lanes 32-63 the right window's, so ONE pruned round serves
+// both windows and one half-wave DPP reduction per dechirp run finds both maxima.
+template <int DTYPE, int BB, int FIRM>
 __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
   UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
   constexpr int kGrow = FIRM ? kImgGrow1 : 0;
@@ -526,10 +563,12 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
 #pragma unroll
   for (int t = 1; t < 8; t++) tw2[t] = buf_ld64(rs_tw, ((8 * t * (j & 15)) & (kN1 - 1)) * 8, 0);
   // pass-3 twiddles of bins k = lo + j and lo + 64 + j: W^k and W^2k (Horner form)
+  // (BB == 2: one bin per lane -- lo + j on lanes 0-31, center + j - 32 on lanes 32-63)
+  const int kk2 = (j < 32) ? lo + j : center + (j - 32);
   v2f t3w1[2], t3w2[2];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
-    const int k = lo + T1 * r + j;
+    const int k = (BB == 2) ? kk2 : lo + T1 * r + j;
     t3w1[r] = buf_ld64(rs_tw, (k & (kN1 - 1)) * 8, 0);
     t3w2[r] = buf_ld64(rs_tw, ((2 * k) & (kN1 - 1)) * 8, 0);
   }
@@ -713,10 +752,8 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
       ring_f0 = f;
       ring_n = 0;
     }
-    // Base band: two dechirp runs (conj(up), conj(down)) over the same filtered frame, which stays in accA / accB.
-    constexpr int kRuns = BB ? 2 : 1;
-#pragma unroll
-    for (int run = 0; run < kRuns; run++) {
+    // Exchange 1 (FIR order -> stride-64 order), ONCE per frame: both dechirp runs of the base-band mode start from the
+    // same filtered samples, which stay in vr[] (the FIR's accumulators are dead from here on).
     if (FIRM) {
       // point u = 4 T + r of this lane is output o = 16 b + 4 (j >> 4) + r of block b = 16 T + (j & 15); the
       // exchange-1 layout puts o at (o & ~15) + ((o & 15) ^ (b & 15))
@@ -729,22 +766,27 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
       for (int u = 0; u < 16; u++) lds_st(lds, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
     }
     __syncthreads();
-
+    v2f vr[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) vr[t] = lds_ld(lds, rdn[t & 3] + 64 * t);
+    // Base band: two dechirp runs (conj(up), conj(down)) over the same filtered frame.
+    constexpr int kRuns = BB ? 2 : 1;
+    float qn[2] = {0.f, 0.f};  // BB == 2: |Z|^2 of this lane's bin in run 0 / run 1
+#pragma unroll
+    for (int run = 0; run < kRuns; run++) {
     // ---- pass 1: x chirp*hann, radix-16 (Ns = 1) -------------------------------------------
     v2f v[16];
-#pragma unroll
-    for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rdn[t & 3] + 64 * t);
     if (run == 0) {
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], ch[t]);
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(vr[t], ch[t]);
     } else {
       v2f c2[16];
 #pragma unroll
       for (int t = 0; t < 16; t++) c2[t] = lds_ld(tab1l, j + T1 * t);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = pk_cmul(v[t], c2[t]);
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(vr[t], c2[t]);
     }
     pk_dft16(v, K, H);
     __syncthreads();
@@ -766,17 +808,35 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
     for (int h = 0; h < 2; h++) {
 #pragma unroll
       for (int t = 1; t < 8; t++) g[h][t] = pk_cmul(g[h][t], tw2[t]);
-      pk_dft8(g[h], H);
+      // BB == 2: the pruned pass only reads columns 0 .. 31 and 96 .. 127 (bins within 32 of DC): outputs 0, 1, 6, 7
+      if (BB == 2) pk_dft8_0167(g[h], H);
+      else pk_dft8(g[h], H);
     }
     __syncthreads();
 #pragma unroll
     for (int h = 0; h < 2; h++) {
       const int b = j + T1 * h;
 #pragma unroll
-      for (int t = 0; t < 8; t++) lds_st(lds, (b >> 4) * 128 + (b & 15) + 16 * t, g[h][pk_slot8(t)]);
+      for (int t = 0; t < 8; t++)
+        if (BB != 2 || t < 2 || t >= 6) lds_st(lds, (b >> 4) * 128 + (b & 15) + 16 * t, g[h][pk_slot8(t)]);
     }
     __syncthreads();
 
+    if (BB == 2) {
+      // ---- pass 3 (radix-8, Ns = 128), pruned to ONE bin per lane: lanes 0-31 the left window, 32-63 the right ------
+      v2f a[8];
+      const int b = kk2 & 127;
+#pragma unroll
+      for (int t = 0; t < 8; t++) a[t] = lds_ld(lds, b + 128 * t);
+      __builtin_amdgcn_sched_barrier(0);
+      const v2f w1 = t3w1[0], w2 = t3w2[0];
+      v2f e = pk_cfma(a[6], w2, a[4]), o = pk_cfma(a[7], w2, a[5]);
+      e = pk_cfma(e, w2, a[2]); o = pk_cfma(o, w2, a[3]);
+      e = pk_cfma(e, w2, a[0]); o = pk_cfma(o, w2, a[1]);
+      const v2f z = pk_cfma(o, w1, e);
+      qn[run] = z.x * z.x + z.y * z.y;
+      __syncthreads();  // tile free for the next run / frame
+    } else {
     // ---- pass 3 (radix-8, Ns = 128), pruned: bins k = lo + j, lo + 64 + j ---------------------
     float q[2] = {0.f, 0.f};
     {
@@ -820,7 +880,44 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
         e[4] = __int_as_float((nl ? 1 : 0) | (nr ? 2 : 0));
       }
     }
+    }
     }  // run
+    if (BB == 2) {
+      // ---- windows of both runs: each half-wave holds one window's bins in ascending order.  Four row rotations and
+      // one row broadcast leave the left maximum in lane 31 and the right one in lane 63 (as common_partial2 of
+      // uc_band_kernel.hip); the first attaining bin of each comes from one ballot and a scalar bit scan.
+      const bool valid = (j & 31) < bw2;
+      float* e = ring + ring_n * kRingStride1Bb;
+#pragma unroll
+      for (int run = 0; run < 2; run++) {
+        const float q = qn[run];
+        const float c = valid ? q : -INFINITY;
+        float m = c;
+        asm("s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_ror:1 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_ror:2 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+            "s_nop 1\n\t"
+            "v_max_f32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf"
+            : "+v"(m));
+        const float ml = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 31));
+        const float mr = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m), 63));
+        const unsigned long long hit = __ballot(valid && c == ((j < 32) ? ml : mr));
+        const unsigned long long nan = __ballot(q != q);
+        const unsigned hl = (unsigned)hit, hr = (unsigned)(hit >> 32);
+        if (j == 0) {
+          e[5 * run + 0] = ml;
+          e[5 * run + 1] = __int_as_float(lo + (hl ? __ffs((int)hl) - 1 : 0));
+          e[5 * run + 2] = mr;
+          e[5 * run + 3] = __int_as_float(center + (hr ? __ffs((int)hr) - 1 : 0));
+          e[5 * run + 4] = __int_as_float((int)((nan & 1ull) | ((nan >> 31) & 2ull)));  // first elements: lanes 0 and 32
+        }
+      }
+    }
     ring_n++;
     if (!has_next) break;
     f = fnext;
@@ -848,20 +945,24 @@ int occ(F kernel, int threads, int fallback) {
   do {                                                                      \
     const bool i32 = dtype == UC_DTYPE_I32;                                 \
     if (n == kN1 && mfma) {                                                 \
-      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, true, 1); } else { CALL1024(UC_DTYPE_F32, true, 1); } }     \
-      else    { if (i32) { CALL1024(UC_DTYPE_I32, false, 1); } else { CALL1024(UC_DTYPE_F32, false, 1); } }   \
+      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, 1, 1); } else { CALL1024(UC_DTYPE_F32, 1, 1); } }     \
+      else    { if (i32) { CALL1024(UC_DTYPE_I32, 0, 1); } else { CALL1024(UC_DTYPE_F32, 0, 1); } }     \
+    } else if (n == kN1 && bb && narrow) {                                  \
+      if (i32) { CALL1024(UC_DTYPE_I32, 2, 0); } else { CALL1024(UC_DTYPE_F32, 2, 0); }                 \
     } else if (n == kN1) {                                                  \
-      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, true, 0); } else { CALL1024(UC_DTYPE_F32, true, 0); } }     \
-      else    { if (i32) { CALL1024(UC_DTYPE_I32, false, 0); } else { CALL1024(UC_DTYPE_F32, false, 0); } }   \
+      if (bb) { if (i32) { CALL1024(UC_DTYPE_I32, 1, 0); } else { CALL1024(UC_DTYPE_F32, 1, 0); } }     \
+      else    { if (i32) { CALL1024(UC_DTYPE_I32, 0, 0); } else { CALL1024(UC_DTYPE_F32, 0, 0); } }     \
+    } else if (bb && narrow2) {                                             \
+      if (i32) { CALL2048(UC_DTYPE_I32, 2); } else { CALL2048(UC_DTYPE_F32, 2); }                       \
     } else {                                                                \
-      if (bb) { if (i32) { CALL2048(UC_DTYPE_I32, true); } else { CALL2048(UC_DTYPE_F32, true); } }     \
-      else    { if (i32) { CALL2048(UC_DTYPE_I32, false); } else { CALL2048(UC_DTYPE_F32, false); } }   \
+      if (bb) { if (i32) { CALL2048(UC_DTYPE_I32, 1); } else { CALL2048(UC_DTYPE_F32, 1); } }           \
+      else    { if (i32) { CALL2048(UC_DTYPE_I32, 0); } else { CALL2048(UC_DTYPE_F32, 0); } }           \
     }                                                                       \
   } while (0)
 
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n) {
   if (grid <= 0) return (int)hipSuccess;
-  const bool bb = p.baseband != 0, mfma = p.fir_mfma != nullptr;
+  const bool bb = p.baseband != 0, mfma = p.fir_mfma != nullptr, narrow = p.bw2 <= 32, narrow2 = p.bw2 <= 64;
 #define UC_L1024(D, B, M) hipLaunchKernelGGL((iq1024_kernel<D, B, M>), dim3((unsigned)grid), dim3((unsigned)T1), 0, stream, p)
 #define UC_L2048(D, B) hipLaunchKernelGGL((iq_kernel<D, B>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p)
   UC_IQ_DISPATCH(UC_L1024, UC_L2048);
@@ -870,8 +971,8 @@ int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n)
   return (int)hipGetLastError();
 }
 
-int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma) {
-  const bool bb = baseband != 0, mfma = fir_mfma != 0;
+int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma, int narrow_) {
+  const bool bb = baseband != 0, mfma = fir_mfma != 0, narrow = narrow_ != 0, narrow2 = narrow_ != 0;
   int nb = 0;
 #define UC_O1024(D, B, M) nb = occ(iq1024_kernel<D, B, M>, T1, 8)
 #define UC_O2048(D, B) nb = occ(iq_kernel<D, B>, T, 4)

@@ -104,7 +104,8 @@ struct IqParams {
 };
 // n = 2048 (the committed firmware) or 1024 (one wave per frame)
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
-int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma);
+// narrow: base band with windows of at most 32 bins (n = 1024: one pruned round, half-wave reductions)
+int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma, int narrow);
 
 // UC_STREAM: FIR-LPF decimating front-end + overlap-save chirp compression (include/uchirp.h).
 struct StreamParams {

@@ -278,6 +278,32 @@ __device__ __forceinline__ void pk_dft8(v2f (&v)[8], v2f H) {
   pk_dft4(v[0], v[1], v[2], v[3]);
   pk_dft4(v[4], v[5], v[6], v[7]);
 }
+// The same 8-point DFT evaluated for the outputs X[0], X[1], X[6], X[7] only (the slots of the others hold garbage):
+// a pass whose successor looks at the bins next to DC only needs the two lowest frequencies either side
+// (25 instead of 29 packed instructions, and half the stores).
+__device__ __forceinline__ void pk_dft4_03(v2f& x0, v2f& x1, v2f& x2, v2f& x3) {
+  v2f a1, d;
+  asm("v_pk_add_f32 %4, %0, %2 neg_lo:[0,1] neg_hi:[0,1]\n\t"   // a1 = x0 - x2
+      "v_pk_add_f32 %0, %0, %2\n\t"                              // a0 = x0 + x2   (in x0)
+      "v_pk_add_f32 %5, %1, %3 neg_lo:[0,1] neg_hi:[0,1]\n\t"   // d  = x1 - x3
+      "v_pk_add_f32 %1, %1, %3\n\t"                              // a2 = x1 + x3   (in x1)
+      "v_pk_add_f32 %0, %0, %1\n\t"                              // X0 = a0 + a2
+      "v_pk_add_f32 %3, %4, %5 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]"        // X3 = a1 - (-j) d
+      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "=&v"(a1), "=&v"(d));
+}
+__device__ __forceinline__ void pk_dft8_0167(v2f (&v)[8], v2f H) {
+#pragma unroll
+  for (int n2 = 0; n2 < 4; n2++) {
+    const v2f a = v[n2], b = v[4 + n2];
+    v[n2] = a + b;
+    v[4 + n2] = a - b;
+  }
+  v[5] = pk_mul_w2(v[5], H);  // W8^1
+  v[6] = pk_mul_mj(v[6]);     // W8^2 = -j
+  v[7] = pk_mul_w6(v[7], H);  // W8^3
+  pk_dft4_03(v[0], v[1], v[2], v[3]);  // X[0] -> v[0], X[6] -> v[3]
+  pk_dft4_03(v[4], v[5], v[6], v[7]);  // X[1] -> v[4], X[7] -> v[7]
+}
 __device__ __forceinline__ constexpr int pk_slot8(int t) { return 4 * (t & 1) + (t >> 1); }
 __device__ __forceinline__ constexpr int pk_slot16(int t) { return 4 * (t & 3) + (t >> 2); }
 
