@@ -95,6 +95,33 @@ def test_sinc5_kernel_is_bit_exact(uchirp):
 
 
 @pytest.mark.gpu
+def test_sinc5_ragged_tails_on_the_device_never_write_past_the_end(uchirp):
+    """The kernel's stores are 16-byte buffer stores through a resource that covers exactly the tile's outputs: a lane
+    whose four words straddle the end of the stream is clipped PER DWORD by the resource, lane 0 (whose outputs belong
+    to the previous tile) sits at offset -16 = 0xFFFFFFF0 and is dropped whole.  Output counts with n_out % 4 in
+    {1, 2, 3}, at and around wave-tile (252 outputs) and workgroup-tile boundaries, into a device buffer with guard
+    words behind it: every output equals the oracle's, no guard word is touched."""
+    import torch
+    dev = torch.device("cuda:0")
+    e = uchirp.Engine(uchirp.RX_REAL)
+    tile = 252
+    wg = tile * 16                                     # outputs per workgroup tile (16 waves)
+    rng = np.random.default_rng(9)
+    GUARD = -1234567
+    for n_out in (1, 2, 3, 5, 6, 7, tile - 3, tile - 2, tile - 1, tile + 1, tile + 2, tile + 3, 2 * tile + 1, 3 * tile - 1,
+                  wg - 1, wg + 1, wg + 2, wg + 3, 5 * wg + tile + 2, 70001, 70002, 70003):
+        w = rng.integers(0, 1 << 32, size=n_out + 4, dtype=np.uint64).astype(np.uint32)
+        ref = uco.dfsdm_sinc5(w)
+        wd = torch.from_numpy(w.view(np.int32)).to(dev)
+        buf = torch.full((n_out + 64,), GUARD, dtype=torch.int32, device=dev)
+        e.dfsdm(wd, out=buf[:n_out])
+        torch.cuda.synchronize()
+        got = buf.cpu().numpy()
+        assert np.array_equal(got[:n_out], ref), n_out
+        assert (got[n_out:] == GUARD).all(), "n_out=%d: stored past the end" % n_out
+
+
+@pytest.mark.gpu
 def test_sinc5_device_path_at_scale_and_chunked(uchirp):
     import torch
     dev = torch.device("cuda:0")

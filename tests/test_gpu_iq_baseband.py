@@ -107,7 +107,7 @@ def test_baseband_noisy_stream_matches_oracle_and_decodes(uchirp, n, dtype):
         rs, rst = o.process(x, halo=26, n_frames=n_frames, mag_mean=mag_mean)
         gs, gst = e.process(x, n_frames=n_frames, mag_mean=mag_mean)
         clear = clear_symbols(rst)
-        assert clear.mean() > 0.98
+        assert clear.mean() >= 0.995      # (measured near-ties at -10 dB: 0.3 % of the frames)
         assert np.array_equal(gs[clear], rs[clear])
         if mag_mean is None:
             # (with a per-frame floor the up and down histories are normalised differently: no decode claim there;

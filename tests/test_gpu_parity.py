@@ -43,7 +43,7 @@ def test_symbol_decision_matches_oracle(uchirp, variant, snr_db):
     margin = np.abs(su - sd) / np.maximum(np.maximum(np.abs(su), np.abs(sd)), 1e-30)
     thr_close = (np.abs(su - 2.0) < 1e-3 * np.abs(su)) | (np.abs(sd - 2.0) < 1e-3 * np.abs(sd))
     clear = (margin >= MARGIN) & ~thr_close
-    assert clear.sum() >= 0.98 * n_frames, "too many near-ties: %d" % (~clear).sum()
+    assert clear.sum() >= 0.995 * n_frames, "too many near-ties: %d" % (~clear).sum()   # (measured: <= 0.3 %)
     assert np.array_equal(gs[clear], rs[clear])
     if snr_db is None or snr_db >= 0.0:
         # the decoded bits are the transmitted bits at these SNRs; at -10 dB the

@@ -154,7 +154,11 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     };
     // outputs base + 4 (lane - 1) .. + 3 through a buffer resource over this tile's outputs: lane 0 (its outputs
     // belong to the previous tile), lanes past the end of the stream and tiles past the last one fall outside the
-    // resource and are dropped by the range check -- no branch, no 64-bit address registers
+    // resource and are dropped by the range check -- no branch, no 64-bit address registers.
+    // The hardware contract this rests on (raw buffer, num_records in bytes): the range check of a b128 store is made
+    // PER DWORD, so a lane whose four words straddle the end of a ragged stream (n_out % 4 != 0) stores the words
+    // inside and drops the rest; lane 0's offset (lane - 1) * 16 = 0xFFFFFFF0 is out of range on purpose.
+    // Pinned by tests/test_dfsdm.py::test_sinc5_ragged_tails_on_the_device_never_write_past_the_end (guard words).
     const size_t left = tile < tiles ? n_out - base : 0;
     const int recs = left < (size_t)kTileOut ? (int)left : kTileOut;
     const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + (tile < tiles ? base : 0), recs * 4);
