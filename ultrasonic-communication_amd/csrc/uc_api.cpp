@@ -108,6 +108,7 @@ struct uc_ctx {
   DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream: zero-prefixed stream, (up, down) mag_max per frame
   std::vector<float2> h_rx_mag;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID / UC_BAND_GROUP / UC_STATIC_DEAL): not part of the ABI
+  bool band_waves_set = false;  // UC_BAND_WAVES given: use it for every mode (default: 3, SYNC_CPLX 2 -- see process_batch_impl)
   int grid_override = 0;
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
@@ -304,7 +305,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
   if (tuning && atoi(tuning) != 0) {
     if (const char* w = getenv("UC_BAND_WAVES")) {
       const int v = atoi(w);
-      if (v >= 2 && v <= 4) c->band_waves = v;
+      if (v >= 2 && v <= 4) { c->band_waves = v; c->band_waves_set = true; }
     }
     if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
     if (const char* g = getenv("UC_BAND_GROUP")) {
@@ -747,8 +748,12 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
 #endif
   const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
                    : (variant == UC_DECHIRP_DOWN) ? uc::kModePair : uc::kModeRxReal;
+  // SYNC_CPLX runs two transforms per frame off two complex tables: at 2 waves/SIMD both tables stay in registers (at 3
+  // the second one is loaded inside the loop, behind the frame prefetch in the in-order vector-memory queue):
+  // 2.59e8 against 2.45e8 frames/s (profiles/r03_sync_cplx_waves.txt)
+  const int waves = (mode == uc::kModeCplx && !c->band_waves_set) ? 2 : c->band_waves;
   int& bpc = c->band_blocks_per_cu[p.wide][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
-  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, c->band_waves, p.wide != 0);
+  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   // units of work: frames, or frame pairs (DECHIRP_DOWN).  Groups of `band_group` units; smaller ones when the batch
@@ -756,7 +761,7 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   p.unpaired = (mode == uc::kModePair && (c->cfg.flags & UC_FLAG_NO_FRAME_PAIRS)) ? 1u : 0u;
   const size_t units = (mode == uc::kModePair && !p.unpaired) ? (n_frames + 1) / 2 : n_frames;
   uint32_t group = (uint32_t)c->band_group;
-  if (c->band_waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
+  if (waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
   while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;
   const size_t ngroups = (units + group - 1) / group;
   if (grid > ngroups) grid = ngroups;
@@ -768,7 +773,7 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
     if (wrc) return wrc;
   }
-  int lrc = uc::launch_band(mode, dtype, c->band_waves, p, (int)grid, stream);
+  int lrc = uc::launch_band(mode, dtype, waves, p, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
   if (int erc = work_counter_launched(c, stream, wslot)) return erc;
   }

@@ -423,7 +423,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // frame 2u in the low and of frame 2u+1 in the high half of pair t
   constexpr int NX = kPair ? 16 : 8;
   v2f xp[NX];
-  auto load_unit = [&](size_t u) {
+  // SYNC_CPLX at 2 waves/SIMD: both runs of a frame read xp, so the next frame is prefetched into a second register set
+  // at the START of the frame (run 0) instead of behind run 1's first pass: a whole frame time of latency hiding, as the
+  // single-run modes have; the set is copied over at the end of the frame (8 packed moves).
+  constexpr bool kDblX = (MODE == kModeCplx) && WAVES <= 2;
+  v2f xq[kDblX ? NX : 1];
+  auto load_unit = [&](size_t u, v2f (&xp)[NX]) {
     if (kPair) {
       const size_t fa = u << psh;
       const bool has_b = psh && fa + 1 < p.n_frames;  // a ragged last pair (or no pairing): frame b reads as zeros
@@ -439,7 +444,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         xp[m] = mkv(buf_ld32_stream(rx, voff4, T * 4 * (2 * m)), buf_ld32_stream(rx, voff4, T * 4 * (2 * m + 1)));
     }
   };
-  load_unit(f);
+  load_unit(f, xp);
 
   // Finaliser, vectorised over frames: lane L turns ring slot L into history[0],
   // history[1] and the symbol of frame f0 + L (receiver/Src/main.c:209-229, 518-531).
@@ -608,7 +613,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         if (j == 0) *next_slot = fetched;
       }
 #ifndef UC_KNOCK_NOLOAD  // (knock-out build: every frame re-uses the first frame's samples -- what the loop costs without HBM)
-      if (run == kRuns - 1 && has_next) load_unit(fnext);
+      if constexpr (kDblX) {
+        if (run == 0 && has_next) load_unit(fnext, xq);
+      } else {
+        if (run == kRuns - 1 && has_next) load_unit(fnext, xp);
+      }
 #endif
       if (MODE == kModeRxReal) pk_dft16_finish(v, K, H);
       else pk_dft16(v, K, H);
@@ -886,6 +895,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     if (dyn && (fnext & gmask) == 0 && j == 0) {
       // a new group was taken: ask for the one after it.  Issued here, where few registers are live.
       fetched = atomicAdd(p.work_ctr, 1u);
+    }
+    if constexpr (kDblX) {
+#pragma unroll
+      for (int m = 0; m < NX; m++) xp[m] = xq[m];
     }
     f = fnext;
   }
