@@ -320,11 +320,13 @@ def test_dechirp_down_frame_pairs_ragged_strided_per_frame_floor(uchirp, n_frame
             assert (np.abs(back[fld].astype(np.float64) - g[fld]) / scale).max() <= MAG_TOL
 
 
-def _random_configs(n, seed):
+def _random_configs(n, seed, wide=False):
+    """wide: windows of 192 .. 319 bins (the three-round build of the band kernel) at the lower DFSDM rates."""
     rng = np.random.default_rng(seed)
     out = []
     while len(out) < n:
-        fs = float(rng.choice([62500.0, 78125.0, 100000.0, 125000.0]))
+        fs = float(rng.choice([38600.0, 125000.0 / 3.0, 44100.0, 48000.0, 62500.0, 100000.0] if wide else
+                              [62500.0, 78125.0, 100000.0, 125000.0]))
         f0 = float(rng.integers(8000, 20000))
         bwid = float(rng.integers(300, 4200))
         f1 = f0 + bwid
@@ -333,7 +335,7 @@ def _random_configs(n, seed):
         variant = int(rng.choice([uco.RX_REAL, uco.SYNC_CPLX, uco.DECHIRP_DOWN]))
         bw = int(bwid * 2048 / fs)
         bw2 = bw * (8 if variant == uco.DECHIRP_DOWN else 2)
-        if bw2 < 2 or bw2 > 191:
+        if (bw2 < 192 or bw2 > 319) if wide else (bw2 < 2 or bw2 > 191):
             continue
         cfg = dict(fs=fs, f0=f0, f1=f1, phase_deg=float(rng.choice([-90.0, 0.0, 37.5])),
                    time_frame=float(rng.choice([0.0205, 2048 / fs, 0.018])),
@@ -345,12 +347,16 @@ def _random_configs(n, seed):
     return out
 
 
-@pytest.mark.parametrize("case", range(16))
+@pytest.mark.parametrize("case", list(range(16)) + ["w%d" % k for k in range(8)])
 def test_randomised_configurations(uchirp, case):
     """The reference's compile-time constants (fs, F0, F1, TIME_FRAME, phase, threshold) as run-time
     configuration: for random draws the product's tables equal the oracle's bit for bit and the
-    per-frame results agree to the usual bars."""
-    variant, cfg = _random_configs(16, seed=2024)[case]
+    per-frame results agree to the usual bars.  Cases w0 .. w7: windows of 192 .. 319 bins."""
+    if isinstance(case, str):
+        variant, cfg = _random_configs(8, seed=2025, wide=True)[int(case[1:])]
+        case = 100 + int(case[1:])
+    else:
+        variant, cfg = _random_configs(16, seed=2024)[case]
     o = uco.Oracle(variant, **cfg)
     e = uchirp.Engine(variant, **cfg)
     assert (e.bandwidth, e.bandwidth2, e.idx_left_zero) == (o.bandwidth, o.bandwidth2, o.idx_left_zero)

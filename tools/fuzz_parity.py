@@ -17,7 +17,9 @@ from parity_util import check_history, MARGIN
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 bad = 0
-for case, (variant, cfg) in enumerate(T._random_configs(cases, seed=seed)):
+# two thirds of the draws with windows of at most 191 bins (the default build), one third with 192 .. 319 (the WIDE build)
+draws = T._random_configs(cases - cases // 3, seed=seed) + T._random_configs(cases // 3, seed=seed + 1, wide=True)
+for case, (variant, cfg) in enumerate(draws):
     try:
         o = uco.Oracle(variant, **cfg)
         e = uchirp.Engine(variant, **cfg)
