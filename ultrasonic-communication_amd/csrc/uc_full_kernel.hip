@@ -234,7 +234,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
         v[2 * m] = pk_scale_lo(cvt_pair<DTYPE>(xp[2 * m]), hw[m]);
         v[2 * m + 1] = pk_scale_hi(cvt_pair<DTYPE>(xp[2 * m + 1]), hw[m]);
       }
-      if (!dyn && more) load_pair(qn);  // a whole pair time ahead
+      if ((!dyn || !hop) && more) load_pair(qn);  // a whole pair time ahead (inside a chunk the next pair is known here)
       pk_dft16(v, K, H);
       xf_store1(ta, xa, s1v, v);
     }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
       }
       // one pair before a chunk's last pair: ask for the next chunk, ahead of the prefetch issued below
       if (((q + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is read)
-      if (more) load_pair(qn);
+      if (hop && more) load_pair(qn);  // chunk boundary: the next pair was only known behind the barrier
     }
     if (pending) publish(qprev);
 
