@@ -513,8 +513,14 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, 
         c->ring_stream_set = true;
       } else if (stream != c->ring_stream) {
         const hipError_t e = hipEventRecord(c->switch_ev, c->ring_stream);
-        if (e != hipSuccess) return hip_fail(e, "hipEventRecord(stream switch)");
-        for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = c->slot_used[i];
+        if (e == hipSuccess) {
+          for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = c->slot_used[i];
+        } else {
+          // (the first stream no longer exists: nothing to record on -- wait once for whatever it left behind)
+          (void)hipGetLastError();
+          const hipError_t e2 = hipDeviceSynchronize();
+          if (e2 != hipSuccess) return hip_fail(e2, "hipDeviceSynchronize(stream switch)");
+        }
         c->multi_stream = true;
       }
     }
