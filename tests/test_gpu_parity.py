@@ -907,6 +907,23 @@ def test_process_batch_in_a_captured_graph(uchirp, variant, monkeypatch, uc_tuni
             assert np.array_equal(stt.cpu().numpy().view(np.uint32), want[-1][1].view(np.uint32)), rep
 
 
+def test_tuning_knobs_need_the_master_switch(uchirp, monkeypatch):
+    """The experiment switches are read only under UC_TUNING=1: a stray UC_BAND_WAVES / UC_STATIC_DEAL / UC_GRID in a
+    production environment changes nothing.  Observable through the 4-waves-per-SIMD build, whose magnitudes differ from
+    the default build's in the last bits (it squares a twiddle where the default reads it from the table)."""
+    frames, _ = synth.make_frames(512, seed=5, snr_db=-5.0)
+    _, ref = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0).process(frames)
+    for k, v in (("UC_BAND_WAVES", "4"), ("UC_STATIC_DEAL", "1"), ("UC_GRID", "1")):
+        monkeypatch.setenv(k, v)
+    monkeypatch.delenv("UC_TUNING", raising=False)
+    _, got = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0).process(frames)
+    assert np.array_equal(got.view(np.uint32), ref.view(np.uint32))
+    monkeypatch.setenv("UC_TUNING", "1")
+    _, tuned = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0).process(frames)
+    assert not np.array_equal(tuned.view(np.uint32), ref.view(np.uint32))     # the switch does switch
+    assert np.allclose(tuned["mag_max"], ref["mag_max"], rtol=2e-6, atol=0.0)
+
+
 def test_many_launches_in_flight_on_several_streams(uchirp, monkeypatch, uc_tuning):
     """One context, 300 launches queued on three streams without a wait in between (a ring of 64 hand-out counters):
     a counter is never shared by two launches in flight -- a launch whose slot is still in use deals statically -- so
