@@ -51,6 +51,11 @@ BYTES_PER_FRAME = 8192 + 1          # fp32 frame in + 1 sy
 HBM_PEAK_GBS = 8000.0               # MI355X_MICROARCH.md: 8.0 TB/s spec
 MATCHED_TIME_FRAME = N / 78125.0    # one symbol = one frame (generator: T = 0.0262 s)
 MSG = "Hello World!"
+# Symbol / gather buffers in rotation.  THREE, not two: the band kernel is persistent and fills every CU, so RCCL's gather
+# kernel of step k only gets CUs when the kernel of step k + 1 drains; with two buffers the kernel of step k + 2 (which
+# rewrites the buffer that gather reads) had to wait for it with the chip idle (20 us per step at world size 1, measured);
+# with three it is the kernel of step k + 3 that depends on gather k, a whole kernel time later.
+NBUF = 3
 
 
 def make_device_frames(n_frames, device, seed, snr_db=-10.0, amp=1000.0):
@@ -379,12 +384,12 @@ def hello_world1(args, device, torch, mag_mean):
         eng = uchirp.Engine(uchirp.RX_REAL, device=device.index, mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
         frames, sent = synth.device_hello_frames(0, nf, device, seed=1234, snr_db=args.snr, msg=MSG)
         stream = torch.cuda.current_stream(device)
-        sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
-        gat2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
-        works = [None, None]
+        sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(NBUF)]
+        gat2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(NBUF)]
+        works = [None] * NBUF
 
         def step(k, e0=None, e1=None):
-            b = k & 1
+            b = k % NBUF
             if works[b] is not None:
                 works[b].wait()
             if e0 is not None:
@@ -395,7 +400,7 @@ def hello_world1(args, device, torch, mag_mean):
             works[b] = dist.all_gather_into_tensor(gat2[b], sym2[b], async_op=True)
 
         def drain():
-            for b in range(2):
+            for b in range(NBUF):
                 if works[b] is not None:
                     works[b].wait()
                     works[b] = None
@@ -414,8 +419,8 @@ def hello_world1(args, device, torch, mag_mean):
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         kern = float(np.mean([a.elapsed_time(b) for a, b in ev]))
-        g = gat2[(args.steps - 1) & 1]
-        ok = bool(torch.equal(g, sym2[(args.steps - 1) & 1]))
+        g = gat2[(args.steps - 1) % NBUF]
+        ok = bool(torch.equal(g, sym2[(args.steps - 1) % NBUF]))
         texts = synth.decode_hello(g.cpu().numpy(), len(MSG))
         good = sum(1 for t in texts if t == MSG)
         ms = elapsed / args.steps * 1e3
@@ -630,12 +635,12 @@ def main():
     if args.variant != "rx_real":
         sys.stdout = json_out                  # (the side measurements print their line themselves)
         return side_measurement(args, eng, frames, world, rank, torch)
-    # Two symbol buffers: the gather of step k (RCCL's own stream) overlaps the kernel of step k + 1;
+    # NBUF symbol buffers in rotation: the gather of step k (RCCL's own stream) overlaps the kernels of the steps behind it;
     # a buffer is rewritten only after the gather that read it has finished (work.wait() orders the
     # launch stream behind it without blocking the host).
-    sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(2)]
-    gathered2 = [torch.empty(world * nf, dtype=torch.uint8, device=device) for _ in range(2)] if multi else None
-    works = [None, None]
+    sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(NBUF)]
+    gathered2 = [torch.empty(world * nf, dtype=torch.uint8, device=device) for _ in range(NBUF)] if multi else None
+    works = [None] * NBUF
     stream = torch.cuda.current_stream(device) if have_gpu else None
 
     def gather(b):
@@ -647,7 +652,7 @@ def main():
         return dist.all_gather_into_tensor(gathered2[b], sym2[b], async_op=True)
 
     def step(k, e0=None, e1=None):
-        b = k & 1
+        b = k % NBUF
         if works[b] is not None:
             works[b].wait()
             works[b] = None
@@ -663,7 +668,7 @@ def main():
             works[b] = gather(b)
 
     def drain():
-        for b in range(2):
+        for b in range(NBUF):
             if works[b] is not None:
                 works[b].wait()
                 works[b] = None
@@ -709,13 +714,13 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    symbols = sym2[(args.steps - 1) & 1]
+    symbols = sym2[(args.steps - 1) % NBUF]
     gathered_host = None
     if multi:
         # Every rank holds the concatenation of all ranks' symbols, rank order: its own slice equals what it
         # decoded, and every rank's gathered buffer has the same digest (so the other slices are the owners').
         import hashlib
-        g = gathered2[(args.steps - 1) & 1]
+        g = gathered2[(args.steps - 1) % NBUF]
         assert torch.equal(g[rank * nf:(rank + 1) * nf], symbols), "gathered symbol stream differs from this rank's symbols"
         gathered_host = g.cpu().numpy()
         dig = torch.frombuffer(bytearray(hashlib.sha256(gathered_host.tobytes()).digest()), dtype=torch.uint8).clone()
