@@ -61,6 +61,32 @@ def test_64ki_frames_two_history_variants(uchirp, variant, dtype):
                                                                                      int((~clear).sum()), ties))
 
 
+@pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX])
+def test_64ki_frames_wide_windows_at_41_7_khz(uchirp, variant):
+    """The WIDE build of the band kernel (windows of 294 bins: the DFSDM rate of the reference's vacuum-cleaner captures)
+    at the same scale and bars, matched sweep."""
+    import torch
+    fs = 125000.0 / 3.0
+    frames, bits = _frames(51 + variant, fs=fs)
+    kw = dict(fs=fs, time_frame=2048.0 / fs, mag_mean=1000.0)
+    o = uco.Oracle(variant, **kw)
+    e = uchirp.Engine(variant, **kw)
+    assert e.bandwidth2 == 294
+    gs, gst = e.process(torch.from_numpy(frames).to("cuda:0"))
+    torch.cuda.synchronize()
+    gs, gst = gs.cpu().numpy(), uchirp.stats_from_tensor(gst)
+    rs, rst = o.process(frames, precision=uco.F64, threads=_threads())
+    clear = clear_symbols(rst)
+    assert clear.mean() >= 0.995
+    assert np.array_equal(gs[clear], rs[clear])
+    assert (gs == bits).mean() > 0.99
+    ties = 0
+    for h in (0, 1):
+        ties += check_history(o, lambda f: frames[f], gst[:, h], rst[:, h], h, "wide variant %d hist%d" % (variant, h))
+    assert ties <= 0.01 * N_FRAMES
+    print("wide variant %d: %d frames, %d unclear symbols, %d proven index near-ties" % (variant, N_FRAMES, int((~clear).sum()), ties))
+
+
 def test_64ki_frames_dechirp_down(uchirp):
     import torch
     frames, _ = _frames(31, fs=100000.0, f0=17000.0, f1=18000.0)
