@@ -185,8 +185,9 @@ int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
  * launches take that counter from a ring of 64 per context; a slot is reused only once the launch that last used it
  * has finished (otherwise the launch falls back to the static round-robin deal: same results, a few percent slower),
  * so any number of launches of one context may be in flight on any number of streams.  (A context that launches on
- * one stream only pays nothing for this; from the first launch on a second stream on, every launch records an event.)  A launch recorded during
- * stream capture gets a counter that its graph owns for the life of the context (960 per context, then static deal).
+ * one stream only pays nothing for this; from the first launch on a second stream on, every launch records an event.)
+ * A launch recorded during stream capture gets a counter that its graph owns for the life of the context (960 per
+ * context, then static deal).
  * Every launch leaves its counter at zero (its last workgroup resets it), so nothing but the kernel node is recorded.
  */
 int uc_process_batch(uc_ctx* ctx, const void* frames, int dtype,
