@@ -919,6 +919,8 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   if (grid > need) grid = need;
   if (c->cic_tickets) {
     // (opt-in, env UC_CIC_TICKETS=1: measured no faster than the static deal, profiles/r02_sinc5_notes.txt)
+    // EXPERIMENT ONLY (needs UC_TUNING=1): the ring below is not guarded by events as take_work_counter's is -- at most
+    // four sinc5 launches of one context may overlap in this mode.  The default (static deal) has no such limit.
     // ticket counters of this launch (one per workgroup), zeroed on the stream right before it
     const size_t bytes = grid * sizeof(unsigned int);
     if (bytes > c->cic_ctr_cap) {
