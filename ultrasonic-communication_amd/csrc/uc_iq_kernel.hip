@@ -348,6 +348,15 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     v2f vr[16];
 #pragma unroll
     for (int t = 0; t < 16; t++) vr[t] = lds_ld(tile, ((t & 1) ? rd1o : rd1e) + 128 * t);
+    // Base band: the second run's chirp*hann entries (16 KiB per workgroup, out of L2) are requested HERE, a whole run
+    // ahead of their use -- issued where run 1 needs them they cost their full cache latency on both waves of the
+    // workgroup at once (measured: the second run took 3.6 x its own issue time).  They queue behind the frame
+    // prefetch of stage 0, which is half a frame old by now.
+    v2f c2[BB ? 16 : 1];
+    if (BB) {
+#pragma unroll
+      for (int t = 0; t < 16; t++) c2[t] = buf_ld64(rs_ch2, voff8, T * 8 * t);
+    }
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
     v2f v[16];
@@ -357,7 +366,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
       for (int t = 0; t < 16; t++) v[t] = pk_cmul(vr[t], ch[t]);
     } else {
 #pragma unroll
-      for (int t = 0; t < 16; t++) v[t] = pk_cmul(vr[t], buf_ld64(rs_ch2, voff8, T * 8 * t));
+      for (int t = 0; t < 16; t++) v[t] = pk_cmul(vr[t], c2[BB ? t : 0]);
     }
     pk_dft16(v, K, H);
     // (run 1: every pass-2 read of the image area by run 0 sits in front of run 0's B4)
