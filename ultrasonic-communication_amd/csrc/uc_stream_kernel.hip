@@ -29,6 +29,12 @@
 #include "uc_kernels.hpp"
 #include "uc_xform.hpp"
 
+#ifndef UC_STREAM_KNOCK
+#define UC_STREAM_KNOCK 0  // diagnostic builds only: 1 no loads in the loop, 2 no FIR arithmetic, 4 no transforms, 8 no stores,
+                           // 16 / 32 the round-2 nt mix / every load nt, 64 a whole block of loads in flight,
+                           // 128 loads on the cache-line grid
+#endif
+
 namespace uc {
 
 namespace {
@@ -148,15 +154,19 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   // (that sample is 26 taps behind the first output of the sub-tile); loads past the end of the
   // buffer, and the tail load of threads >= 7, fall outside the resource and return 0.
   // Two register sets: the loads run TWO sub-tiles ahead of the FIR (and through the transforms).
-  v4u stg[2][9];
+  constexpr int kDepth = (UC_STREAM_KNOCK & 64) ? NSUB : 2;  // (64: a whole block of input in flight -- diagnostic, with 2 + 4)
+  v4u stg[kDepth][9];
   auto issue_loads = [&](unsigned blk, int sub, v4u (&dst)[9]) {
-    const size_t first = (size_t)blk * (size_t)(HOP * D) + (size_t)sub * kSubIn;
+    size_t first = (size_t)blk * (size_t)(HOP * D) + (size_t)sub * kSubIn;
+    if (UC_STREAM_KNOCK & 128) first &= ~(size_t)31;  // (128: loads on the 128-byte grid -- WRONG samples, timing only)
     const size_t left = p.n_samples > first ? p.n_samples - first : 0;
     const int recs = left < (size_t)(kSubIn + 28) ? (int)left : kSubIn + 28;
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.samples) + first * 4, recs * 4);
-    // The last sub-tile of a block holds the (L - 1) D samples the NEXT block reads again (overlap-save): those loads keep
-    // the default cache policy so that the re-read can hit; everything else is read once and streams past the caches.
-    if (sub == NSUB - 1) {
+    // Every load keeps the DEFAULT cache policy (round 3).  Rounds 1-2 streamed all but a block's last sub-tile past
+    // the caches (nt): the last sub-tile holds the (L - 1) D samples the next block reads again.  Measured on two boxes
+    // with the dynamic hand-out: default everywhere 1.833 / 1.836-1.858 ms per 2^31 samples, the nt mix 1.904 /
+    // 1.847-1.917, nt everywhere 1.944 (profiles/r03_stream_knock.txt).
+    if (!(UC_STREAM_KNOCK & 32) && (!(UC_STREAM_KNOCK & 16) || sub == NSUB - 1)) {  // (16: the nt mix of round 2, 32: every load nt)
 #pragma unroll
       for (int r = 0; r < 8; r++) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, T * 16 * r, 0);
       dst[8] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, kSubIn * 4, 0);
@@ -167,8 +177,8 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     }
   };
 
-  issue_loads(b, 0, stg[0]);
-  issue_loads(b, 1, stg[1]);
+#pragma unroll
+  for (int s = 0; s < kDepth; s++) issue_loads(b, s, stg[s]);
 
   float* tb = lds;  // second transform tile: the image area is free once the last window is read
 
@@ -186,7 +196,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     // ---- front end: FIR + decimation, sub-tile by sub-tile, into the FFT tile ----------------
 #pragma unroll
     for (int s = 0; s < NSUB; s++) {
-      v4u (&cur)[9] = stg[s & 1];
+      v4u (&cur)[9] = stg[s % kDepth];
       __syncthreads();  // the windows of the previous sub-tile (and the previous block's transforms) are read
       if (s == 0) {
         if (hop) {
@@ -206,8 +216,10 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
         const int q = kSubIn / 4 + j;
         img[q + (q >> 3)] = cvt4<DTYPE>(cur[8]);
       }
-      if (s + 2 < NSUB) issue_loads(b, s + 2, cur);
-      else if (more) issue_loads(bn, s + 2 - NSUB, cur);
+#if !(UC_STREAM_KNOCK & 1)  // (knock-out builds, tools/stream_knock.sh: what each stage costs; never shipped)
+      if (s + kDepth < NSUB) issue_loads(b, s + kDepth, cur);
+      else if (more) issue_loads(bn, s + kDepth - NSUB, cur);
+#endif
       __syncthreads();
 
       // window: samples 32 j .. 32 j + WIN of the sub-tile image; output u sits on sample 26 + D u
@@ -222,8 +234,12 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
       v2f acc[OPT];
 #pragma unroll
       for (int u = 0; u < OPT; u++) acc[u] = mkv(0.f, 0.f);
+#if UC_STREAM_KNOCK & 2
 #pragma unroll
-      for (int w = 0; w < WIN; w++) {
+      for (int u = 0; u < OPT; u++) acc[u] = xs[u] + xs[WIN4 + u];
+#endif
+#pragma unroll
+      for (int w = 0; w < ((UC_STREAM_KNOCK & 2) ? 0 : WIN); w++) {
 #pragma unroll
         for (int u = 0; u < OPT; u++) {
           const int k = (kFirTapsDev - 1) + D * u - w;  // tap that multiplies sample w for output u
@@ -250,6 +266,11 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
 
     // The transforms (uc_xform.hpp) ping-pong between the two tiles (tile -> tb -> tile -> tb -> tile):
     // every exchange is write, ONE barrier, read.
+#if UC_STREAM_KNOCK & 4
+    v2f y16[16];
+#pragma unroll
+    for (int t = 0; t < 16; t++) y16[t] = lds_ld(tile, j + T * t);
+#else
     {
       v2f v[16];  // forward pass 1
 #pragma unroll
@@ -267,6 +288,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     __syncthreads();
     v2f y16[16];                                                // inverse pass C: y16[t] = output j + 128 t
     xf_invC<false>(tile, y16, xa, y16, t3a, t3b, t3c, K, H);
+#endif
 
     // ---- |y[i]|, i = j + 128 t; outputs i >= L-1 are free of circular wrap-around ---------------------
     const size_t q0 = (size_t)b * (size_t)HOP;               // first output of this block
@@ -284,7 +306,9 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
       const v2f y = y16[t];
       const float m2 = y.x * y.x + y.y * y.y;
       const int o = j + T * t - (L - 1);  // offset inside the block's hop
+#if !(UC_STREAM_KNOCK & 8)
       __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_sqrtf(m2)), ro, o * 4, 0, UC_STREAM_CPOL);
+#endif
       const bool take = (unsigned)o < (unsigned)valid && m2 > best;  // ascending offset: first maximum
       best = take ? m2 : best;
       best_i = take ? o : best_i;
