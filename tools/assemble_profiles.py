@@ -35,8 +35,11 @@ with open("%s/%s_variants_bench.jsonl" % (dst, tag), "w") as f:
 if len(sys.argv) > 2:
     pm = "gpurun_out/pmcall_%s" % sys.argv[2]
     for name in ("%s_pmc_all.json" % sys.argv[2], "%s_valu_insts.json" % sys.argv[2]):
-        if os.path.exists(os.path.join(pm, name)):
-            open(os.path.join(dst, name), "w").write(open(os.path.join(pm, name)).read())
+        if os.path.exists(os.path.join(pm, name)):   # per target: a partial counter run updates, never drops entries
+            new = json.load(open(os.path.join(pm, name)))
+            old = json.load(open(os.path.join(dst, name))) if os.path.exists(os.path.join(dst, name)) else {}
+            old.update(new)
+            json.dump(old, open(os.path.join(dst, name), "w"), indent=1)
     # the band kernel's own traffic record, in the form bench.py reads (rNN_vM_hbm_traffic.json)
     allp = os.path.join(dst, "%s_pmc_all.json" % sys.argv[2])
     if os.path.exists(allp):

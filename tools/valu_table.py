@@ -2,7 +2,8 @@
 """Summaries of tools/pmc_all.sh: per kernel the SQ counters per dispatch and per unit of work, HBM traffic per unit
 (FETCH_SIZE x 2 on gfx950 + WRITE_SIZE, MI355X_MICROARCH.md section HBM), the in-kernel clock, and the VALU issue bound
 bench.py prints (wave-instructions x 4 cycles / (4 SIMDs x 256 CUs x clock)).
-usage: python tools/valu_table.py <gpurun_out/pmcall_tag> <tag>  -> <dir>/<tag>_pmc_all.json, <dir>/<tag>_valu_insts.json"""
+usage: python tools/valu_table.py <gpurun_out/pmcall_tag> <tag>  -> <dir>/<tag>_pmc_all.json, <dir>/<tag>_valu_insts.json
+(entries of targets measured in this run replace their old ones; every other entry of an existing summary is kept)"""
 import collections
 import csv
 import glob
@@ -70,8 +71,12 @@ for info_f in sorted(glob.glob(os.path.join(src, "*.info.json"))):
                     "source": "%s_pmc_all.json (tools/pmc_all.sh: SQ_INSTS_VALU per launch / units; in-kernel clock of the clock-stamp build)" % tag}
         if g("SQ_INSTS_LDS") is not None:
             table[t]["lds_insts_per_unit"] = g("SQ_INSTS_LDS") / units
-json.dump(res, open(os.path.join(src, tag + "_pmc_all.json"), "w"), indent=1)
-json.dump(table, open(os.path.join(src, tag + "_valu_insts.json"), "w"), indent=1)
+# a run over a subset of the targets (or a directory whose raw CSVs are gone) UPDATES the summaries, it never empties them
+for name, new in ((tag + "_pmc_all.json", res), (tag + "_valu_insts.json", table)):
+    path = os.path.join(src, name)
+    merged = json.load(open(path)) if os.path.exists(path) and os.path.getsize(path) > 2 else {}
+    merged.update(new)
+    json.dump(merged, open(path, "w"), indent=1)
 for t, d in res.items():
     e = d["derived"]
     print("%-24s VALU/unit %8.1f  LDS/unit %7.1f  hbm/alg %s  clock %s  valu frac %s  hbm frac %s" % (
