@@ -20,7 +20,10 @@ bad = 0
 for name, variant, kw in (("rx_real", uchirp.RX_REAL, {}), ("sync_cplx", uchirp.SYNC_CPLX, {}), ("dechirp_down", uchirp.DECHIRP_DOWN, {}),
                           ("compress", uchirp.COMPRESS, {}), ("iq", uchirp.IQ, {}), ("iq1024", uchirp.IQ, {"n": 1024}),
                           ("iq1024 base band", uchirp.IQ, {"n": 1024, "flags": uchirp.FLAG_IQ_BASEBAND, "fs": 100000.0,
-                                                           "carrier": 18000.0, "f0": 16500.0, "f1": 19500.0, "time_frame": 1024 / 100000.0})):
+                                                           "carrier": 18000.0, "f0": 16500.0, "f1": 19500.0, "time_frame": 1024 / 100000.0}),
+                          ("iq base band", uchirp.IQ, {"flags": uchirp.FLAG_IQ_BASEBAND, "fs": 100000.0,
+                                                       "carrier": 18000.0, "f0": 16500.0, "f1": 19500.0, "time_frame": 2048 / 100000.0}),
+                          ("rx_real 41.7 kHz", uchirp.RX_REAL, {"fs": 125000.0 / 3.0, "time_frame": 2048 * 3.0 / 125000.0})):
     e = uchirp.Engine(variant, mag_mean=1000.0, **kw)
     n = e.n
     n_frames = (flat.numel() - e.halo - n) // n + 1
