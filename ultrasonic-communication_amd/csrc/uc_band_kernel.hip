@@ -24,6 +24,12 @@
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 
+#ifndef UC_BAND_KNOCK
+// diagnostic builds only (tools/band_knock.sh; results WRONG by construction, timing only), default build of RX_REAL:
+// 2 no pass-1 arithmetic, 4 no pass-2 arithmetic, 8 no pruned-pass arithmetic, 16 no exchange 1 (stores + reads),
+// 32 no exchange-2 stores, 64 no pruned-pass reads, 128 no window search
+#define UC_BAND_KNOCK 0
+#endif
 #ifndef UC_CPLX_RES3
 #define UC_CPLX_RES3 1  // SYNC_CPLX at 3 waves/SIMD: tables kept resident (0, 1)
 #endif
@@ -576,7 +582,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     for (int run = 0; run < kRuns; run++) {
       v2f v[16];
       // ---- pass 1: window*chirp multiply, radix-16, Ns = 1 ------------------
-      if (MODE == kModeRxReal) {
+      if (MODE == kModeRxReal && (UC_BAND_KNOCK & 2)) {
+#pragma unroll
+        for (int t = 0; t < 16; t++) v[t] = cvt_pair<DTYPE>(xp[t >> 1]);
+      } else if (MODE == kModeRxReal) {
         // sample t of this thread = half (t & 1) of pair t >> 1; the table products ride in the first
         // butterfly additions (pk_dft4_scaled), so the pass starts at the second half of the DFT
         v2f xc[8];
@@ -619,7 +628,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         if (run == kRuns - 1 && has_next) load_unit(fnext, xp);
       }
 #endif
-      if (MODE == kModeRxReal) pk_dft16_finish(v, K, H);
+      if (MODE == kModeRxReal && (UC_BAND_KNOCK & 2)) { }
+      else if (MODE == kModeRxReal) pk_dft16_finish(v, K, H);
       else pk_dft16(v, K, H);
       UC_STAMP(0);
       // B4, placed AFTER the register-only part of pass 1: the wave that finished the previous
@@ -635,9 +645,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // (wave priority: low while it issues a burst of LDS stores, raised otherwise -- the SIMD's other waves get their
       // arithmetic issued ahead of the store burst; measured +0.5-0.7 %, the opposite assignment -1.5 %)
       __builtin_amdgcn_s_setprio(0);
+#if !(UC_BAND_KNOCK & 16)
 #pragma unroll
       for (int t = 0; t < 16; t += 2)
         lds_st2(lds, wr1 + (t ^ s1v), v[4 * (t & 3) + (t >> 2)], v[4 * ((t + 1) & 3) + ((t + 1) >> 2)]);
+#endif
       __builtin_amdgcn_s_setprio(2);
       UC_STAMP(1);
       __syncthreads();  // B1
@@ -646,18 +658,24 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // ---- pass 2: radix-16, Ns = 16 ----------------------------------------
       // all 16 reads are issued back to back (the fence keeps hipcc from sinking them
       // next to their uses, which serialises four load->wait round trips)
+#if !(UC_BAND_KNOCK & 16)
 #pragma unroll
       for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rd1 + 128 * t);
+#endif
       __builtin_amdgcn_sched_barrier(0);
+#if !(UC_BAND_KNOCK & 4)
 #pragma unroll
       for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], kTw2Lds ? lds_ld(tw2l, tw2o + 16 * t) : tw2[t]);
       pk_dft16(v, K, H);
+#endif
       UC_STAMP(3);
       __syncthreads();  // B2: every pass-2 read is done before the tile is overwritten
       UC_STAMP(4);
       __builtin_amdgcn_s_setprio(0);
+#if !(UC_BAND_KNOCK & 32)
 #pragma unroll
       for (int t = 0; t < 16; t++) lds_st(lds, wr2 + 16 * t, v[4 * (t & 3) + (t >> 2)]);
+#endif
       __builtin_amdgcn_s_setprio(2);
 
       __syncthreads();  // B3
@@ -785,10 +803,26 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           v2f av[8], bv[8];
 #pragma unroll
           for (int t = 0; t < 8; t++) {
+#if UC_BAND_KNOCK & 64
+            av[t] = v[t];
+            bv[t] = v[8 + t];
+            (void)ib;
+#else
             av[t] = lds_ld(lds, i + 256 * t);
             bv[t] = lds_ld(lds, ib + 256 * t);
+#endif
           }
           __builtin_amdgcn_sched_barrier(0);
+#if UC_BAND_KNOCK & 8
+          if (kReal) {
+            v2f sa = av[0], sb = bv[0];
+#pragma unroll
+            for (int t = 1; t < 8; t++) { sa = sa + av[t]; sb = sb + bv[t]; }   // (keeps the 16 values live: 14 packed adds)
+            m_a[r] = sa.x + sa.y;
+            m_b[r] = sb.x + sb.y;
+            continue;
+          }
+#endif
           // Z = sum_t a_t w^t evaluated as E(w^2) + w O(w^2), E and O by Horner in w^2: seven fused
           // multiply-adds with only w and w^2 (no per-frame derivation of w^3..w^7)
           v2f w1, w2;
@@ -858,8 +892,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         // up history looks at m_a, down history at m_b; wave 1 also holds slot 1
         Common up, dn;
         // (base0 = the bin of the wave's lane 0 in slot 0: 64 * wave, a scalar)
+#if UC_BAND_KNOCK & 128
+        up.m = m_a[0] + m_a[1]; dn.m = m_b[0] + m_b[1]; up.ks = up.kl = dn.ks = dn.kl = j;
+#else
         if (wave == 0) common_partial2<false>(m_a[0], m_b[0], j, 0, 0.f, 0.f, k1, bw2, up, dn);
         else common_partial2<true>(m_a[0], m_b[0], j, 64, m_a[1], m_b[1], k1, bw2, up, dn);
+#endif
         if (lane == 0) {
           e[0] = up.m;
           e[1] = dn.m;
