@@ -761,6 +761,10 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   int& bpc = c->band_blocks_per_cu[p.wide][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
   if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;
+  // DECHIRP_DOWN (frame pairs, the HBM-bound one) runs at the loads-only floor of this kernel structure, and that floor is
+  // lower with fewer concurrent streams: 5 workgroups per CU instead of the 6 that fit: 7.69 against 7.54e8 frames/s,
+  // 4 per CU 7.57, 3 per CU 6.86 (profiles/r03_band_knock.txt)
+  if (mode == uc::kModePair && !p.wide && bpc > 5) grid = (size_t)c->num_cu * 5;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   // units of work: frames, or frame pairs (DECHIRP_DOWN).  Groups of `band_group` units; smaller ones when the batch
   // would not give every workgroup a few (a small batch then still spreads over the whole chip)
