@@ -149,3 +149,59 @@ def test_64ki_frames_iq_baseband(uchirp, n):
                               spectrum_kw={"halo": 26})
     assert ties <= 0.01 * nf
     print("iq base band n=%d: %d frames, BER %.4f, %d proven index near-ties" % (n, nf, float((gs != bits).mean()), ties))
+
+
+_LIN = [("rx_real", uco.RX_REAL, {}), ("sync_cplx", uco.SYNC_CPLX, {}), ("dechirp_down", uco.DECHIRP_DOWN, {}),
+        ("compress", uco.COMPRESS, {}), ("iq", uco.IQ, {}), ("iq1024", uco.IQ, {"n": 1024}),
+        ("iq1024_bb", uco.IQ, dict(n=1024, fs=100000.0, carrier=18000.0, f0=16500.0, f1=19500.0, time_frame=1024 / 100000.0,
+                                   flags=uco.FLAG_IQ_BASEBAND)),
+        ("iq_bb", uco.IQ, dict(fs=100000.0, carrier=18000.0, f0=16500.0, f1=19500.0, time_frame=2048 / 100000.0,
+                               flags=uco.FLAG_IQ_BASEBAND)),
+        ("rx_real_41_7_khz", uco.RX_REAL, dict(fs=125000.0 / 3.0, time_frame=2048 * 3.0 / 125000.0))]
+
+
+@pytest.mark.parametrize("name,variant,kw", _LIN, ids=[c[0] for c in _LIN])
+def test_exact_x2_linearity_and_shard_invariance_of_every_frame_kernel(uchirp, name, variant, kw):
+    """Oracle-free properties of every frame kernel on 128 Ki frames at -10 dB: doubling the input AND the noise floor
+    doubles every magnitude exactly (a power of two commutes with every rounding of the pipeline), leaves every index,
+    snr and symbol bit-identical; a batch cut in two (what a second GPU would get) gives the records of the whole."""
+    import torch
+    dev = torch.device("cuda:0")
+    nf = 1 << 17
+    frames, _ = synth.device_frames(nf, dev, seed=808, snr_db=-10.0)
+    flat = frames.reshape(-1)
+    e1 = uchirp.Engine(variant, mag_mean=1000.0, **kw)
+    e2 = uchirp.Engine(variant, mag_mean=2000.0, **kw)
+    n, halo = e1.n, e1.halo
+    n_frames = (flat.numel() - halo - n) // n + 1
+    s1, t1 = e1.process(flat, n_frames=n_frames)
+    s2, t2 = e2.process(flat * 2.0, n_frames=n_frames)
+    torch.cuda.synchronize()
+    a, b = uchirp.stats_from_tensor(t1), uchirp.stats_from_tensor(t2)
+    for fld in ("mag_max", "mag_max_left", "mag_max_right", "mag_mean"):
+        np.testing.assert_array_equal(b[fld], 2.0 * a[fld], err_msg="%s %s" % (name, fld))
+    for fld in ("max_freq", "max_freq_left", "max_freq_right"):
+        np.testing.assert_array_equal(b[fld], a[fld], err_msg="%s %s" % (name, fld))
+    np.testing.assert_array_equal(b["snr"].view(np.int32), a["snr"].view(np.int32))
+    assert torch.equal(s1, s2)
+    # two shards == the whole (the second shard starts `halo` samples early: its FIR history is the first shard's tail)
+    h = n_frames // 2
+    lo_s, lo_t = e1.process(flat[: halo + h * n], n_frames=h)
+    hi_s, hi_t = e1.process(flat[h * n:], n_frames=n_frames - h)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([lo_s, hi_s]), s1)
+    assert torch.equal(torch.cat([lo_t, hi_t]).view(torch.int32), t1.view(torch.int32))
+
+
+def test_exact_x2_linearity_of_the_stream_kernel(uchirp):
+    import torch
+    dev = torch.device("cuda:0")
+    frames, _ = synth.device_frames(1 << 15, dev, seed=909, snr_db=-10.0)
+    flat = frames.reshape(-1)
+    e = uchirp.Engine(uchirp.STREAM)
+    c1, p1 = e.process_stream(flat)
+    c2, p2 = e.process_stream(flat * 2.0)
+    torch.cuda.synchronize()
+    assert torch.equal(c2, 2.0 * c1)
+    assert torch.equal(p1[:, 1], p2[:, 1])                                   # peak offsets
+    assert torch.equal(p2[:, 0].view(torch.float32), 2.0 * p1[:, 0].view(torch.float32))   # peak values
