@@ -205,3 +205,21 @@ def test_exact_x2_linearity_of_the_stream_kernel(uchirp):
     assert torch.equal(c2, 2.0 * c1)
     assert torch.equal(p1[:, 1], p2[:, 1])                                   # peak offsets
     assert torch.equal(p2[:, 0].view(torch.float32), 2.0 * p1[:, 0].view(torch.float32))   # peak values
+
+
+@pytest.mark.parametrize("name,variant,kw", _LIN, ids=[c[0] for c in _LIN])
+def test_int32_words_equal_their_float_values_in_every_frame_kernel(uchirp, name, variant, kw):
+    """The ISR's cast (receiver/Src/main.c:664) fused into the loads: DFSDM words (24-bit samples in bits 31:8) and the
+    float32 values of the same words give bit-identical records -- every kernel, 128 Ki frames."""
+    import torch
+    dev = torch.device("cuda:0")
+    frames, _ = synth.device_frames(1 << 17, dev, seed=707, snr_db=-10.0)
+    words = (torch.round(frames).to(torch.int32) * 256).reshape(-1)
+    e = uchirp.Engine(variant, mag_mean=1000.0 * 256.0, **kw)
+    n, halo = e.n, e.halo
+    n_frames = (words.numel() - halo - n) // n + 1
+    si, ti = e.process(words, n_frames=n_frames)
+    sf, tf = e.process(words.to(torch.float32), n_frames=n_frames)
+    torch.cuda.synchronize()
+    assert torch.equal(si, sf)
+    assert torch.equal(ti.view(torch.int32), tf.view(torch.int32))
