@@ -223,3 +223,23 @@ def test_int32_words_equal_their_float_values_in_every_frame_kernel(uchirp, name
     torch.cuda.synchronize()
     assert torch.equal(si, sf)
     assert torch.equal(ti.view(torch.int32), tf.view(torch.int32))
+
+
+@pytest.mark.parametrize("name,variant,kw", [c for c in _LIN if c[0] in ("rx_real", "sync_cplx", "rx_real_41_7_khz")],
+                         ids=["rx_real", "sync_cplx", "rx_real_41_7_khz"])
+def test_a_frame_does_not_depend_on_its_neighbours_or_its_place(uchirp, name, variant, kw):
+    """One frame per transform: the batch in a random order gives the same records in that order, bit for bit (which
+    workgroup, which group, which ring slot a frame meets never shows in its result)."""
+    import torch
+    dev = torch.device("cuda:0")
+    nf = 1 << 16
+    frames, _ = synth.device_frames(nf, dev, seed=606, snr_db=-10.0)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    perm = torch.randperm(nf, generator=g, device=dev)
+    e = uchirp.Engine(variant, mag_mean=1000.0, **kw)
+    s, t = e.process(frames)
+    sp, tp = e.process(frames[perm].contiguous())
+    torch.cuda.synchronize()
+    assert torch.equal(sp, s[perm])
+    assert torch.equal(tp.view(torch.int32), t[perm].view(torch.int32))
