@@ -221,8 +221,9 @@ int uc_set_table(uc_ctx* ctx, int table_id, const float* data, size_t count);
  * record [frame][history][bandwidth2 + k] = |X[k]| for k = -bandwidth2 .. +bandwidth2 (k < 0: bin n + k), history 0 = up
  * reference, 1 = down (one history for DECHIRP_DOWN).  Bin 0 follows UC_FLAG_TRUE_DC (Q2).  With real references both
  * sides of DC hold the same value (Q1: Hermitian mirror).  RX_REAL, SYNC_CPLX, DECHIRP_DOWN; same frame addressing,
- * dtype and stream semantics as uc_process_batch.  A diagnostic / capture-comparison path (it runs the three-round build
- * of the band kernel), not the throughput path.
+ * dtype and stream semantics as uc_process_batch.  A diagnostic / capture-comparison path, not the throughput path: it runs
+ * the build uc_process_batch runs for this geometry (two pruned rounds up to bandwidth2 = 191, three beyond) with the stores
+ * of the window bins added, so its values are bit for bit the ones the statistics are the maxima of.
  */
 int uc_window_bins(const uc_ctx* ctx);   /* 2 * bandwidth2 + 1, or <0 */
 int uc_window_spectrum(uc_ctx* ctx, const void* frames, int dtype, size_t n_frames, size_t stride_elems,

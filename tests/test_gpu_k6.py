@@ -7,9 +7,12 @@ output the reference holds (tests/golden/k6_all.npz, copied by tests/golden/make
 
   * uc_set_table(UP = DOWN = ones) turns RX_REAL -- the headline kernel family -- into exactly that chain:
     int32 ingest -> x Hann -> 2048-point real FFT -> magnitude; uc_window_spectrum returns the magnitudes of the
-    bins its windows reach (here 0 .. 318), which must be the device's at print precision.
-  * SYNC_CPLX with a complex-exponential reference slides the same +-318-bin window over the WHOLE spectrum (two shifts
+    bins its windows reach, which must be the device's at print precision.
+  * SYNC_CPLX with a complex-exponential reference slides the same window over the WHOLE spectrum (shifts that
     cover bins 21 .. 1023), so every live bin of every capture meets a HIP kernel.
+  * Both in TWO window geometries: 318 bins (the three-round WIDE build) and 190 bins -- the DEFAULT two-round build, the
+    code of the kernel the bench times (uc_window_spectrum runs its instantiation with the bin stores added, and the
+    statistics of the throughput instantiation are asserted to be the maxima of exactly those values, bit for bit).
   * The product's Hann table times the raw words must be the device's `.flt` to one float32 ulp (a3).
 
 Also here: uc_window_spectrum / uc_set_table against the oracle on synthetic frames (per-bin parity, a5).
@@ -31,6 +34,9 @@ K6_MISMATCHED = "chirp_experiment/48.1(kHz)_M2A"      # the one trio 
 N = 2048
 # window geometry only (the tables are replaced): (f1 - f0) n / fs = 159.5 -> bandwidth 159, windows of 318 bins
 GEOM = dict(fs=100000.0, f0=10000.0, f1=17788.0, mag_mean=1.0)
+# (f1 - f0) n / fs = 95.2 -> bandwidth 95, windows of 190 bins: the default two-round build (bandwidth2 <= 191)
+GEOM_DEFAULT = dict(fs=100000.0, f0=10000.0, f1=14650.0, mag_mean=1.0)
+GEOMS = [pytest.param(GEOM, 318, id="wide318"), pytest.param(GEOM_DEFAULT, 190, id="default190")]
 PRINT_STEP = 0.5e-6 * np.sqrt(N)                       # the device prints mag / sqrt(N) with six decimals
 
 
@@ -64,29 +70,30 @@ def test_hann_table_times_raw_is_the_device_flt(uchirp):
     assert checked == 23
 
 
-def test_rx_real_with_unit_reference_is_the_devices_rfft_magnitude(uchirp):
+@pytest.mark.parametrize("geom,W", GEOMS)
+def test_rx_real_with_unit_reference_is_the_devices_rfft_magnitude(uchirp, geom, W):
     """a1 + a3 + a5 of the HIP path on real CMSIS-DSP output: raw int32 words -> band_kernel<rx_real> with up = down =
-    1 -> |X[k]|, k = 0 .. 318, against `.fft x sqrt(N)` for every bin at or above 1 kHz; same arg-max.
+    1 -> |X[k]|, k = 0 .. W, against `.fft x sqrt(N)` for every bin at or above 1 kHz; same arg-max.
     Tolerance: MAG_TOL x the frame's largest spectral magnitude (float32 FFT round-off scales with the DC region these
     captures are dominated by, 30 - 100 x the live peak) + the print step of the device's %f."""
-    e = uchirp.Engine(uchirp.RX_REAL, **GEOM)
-    assert e.bandwidth2 == 318
+    e = uchirp.Engine(uchirp.RX_REAL, **geom)
+    assert e.bandwidth2 == W
     ones = np.ones(N, np.float32)
     e.set_table(uchirp.TABLE_UP, ones)
     e.set_table(uchirp.TABLE_DOWN, ones)
     caps = list(_captures())
     frames = np.stack([c[1] for c in caps])
-    spec = e.window_spectrum(frames)                       # [24, 2, 637]
-    assert spec.shape == (len(caps), 2, 2 * 318 + 1)
+    spec = e.window_spectrum(frames)                       # [24, 2, 2 W + 1]
+    assert spec.shape == (len(caps), 2, 2 * W + 1)
     _, st = e.process(frames)
     checked = 0
     for i, (name, raw, flt, freq, mag_dev) in enumerate(caps):
-        g = spec[i, 0, 318:].astype(np.float64)            # bins 0 .. 318
+        g = spec[i, 0, W:].astype(np.float64)              # bins 0 .. W
         # up == down reference: the same spectrum twice (one rides in the real, one in the imaginary part of the complex
         # transform: equal to round-off, not bit for bit)
         assert np.abs(spec[i, 0] - spec[i, 1]).max() <= 2e-6 * spec[i, 0].max()
-        assert np.array_equal(spec[i, 0, :318][::-1], spec[i, 0, 319:])   # Hermitian mirror (Q1)
-        live = np.nonzero(freq[:319] >= 1000.0)[0]
+        assert np.array_equal(spec[i, 0, :W][::-1], spec[i, 0, W + 1:])   # Hermitian mirror (Q1)
+        live = np.nonzero(freq[:W + 1] >= 1000.0)[0]
         scale = g.max()                                    # (the DC region: this kernel's own largest bin)
         err = np.abs(g[live] - mag_dev[live])
         ok = err.max() <= MAG_TOL * scale + PRINT_STEP and np.argmax(g[live]) == np.argmax(mag_dev[live])
@@ -94,33 +101,51 @@ def test_rx_real_with_unit_reference_is_the_devices_rfft_magnitude(uchirp):
             assert not ok, "the mismatched trio is expected to disagree"
             continue
         assert ok, (name, err.max(), MAG_TOL * scale + PRINT_STEP, np.argmax(g[live]), np.argmax(mag_dev[live]))
-        # the statistics path (default two-round build is not used here: 318 bins) reports the same maximum
-        assert st[i, 0]["mag_max_right"] == spec[i, 0, 318:318 + 318].max()
+        # the statistics of uc_process_batch -- at 190 bins band_kernel<rx_real, int32, 3 waves/SIMD>, the throughput
+        # instantiation -- are the maxima of exactly these values, bit for bit, in both histories and both windows
+        for h in (0, 1):
+            assert st[i, h]["mag_max_right"] == spec[i, h, W:W + W].max()
+            assert st[i, h]["mag_max_left"] == spec[i, h, :W].max()
         checked += 1
     assert checked == 23
 
 
-def test_every_live_bin_of_every_capture_through_the_complex_kernel(uchirp):
-    """band_kernel<sync_cplx> with reference e^{-j 2 pi m t / n}: Z[k] = X[k + m], so the +-318-bin window sits on bins
-    m - 318 .. m + 318 of the capture's spectrum.  m = 339 (up slot) and m = 705 (down slot) cover bins 21 .. 1023:
-    every bin the device printed at or above 1 kHz, for all 23 consistent captures, plus the global arg-max."""
-    e = uchirp.Engine(uchirp.SYNC_CPLX, **GEOM)
+def _slide(e, uchirp, shifts):
+    """SYNC_CPLX references e^{-j 2 pi m t / n}, m = shifts[0] in the up slot, shifts[1] in the down slot."""
     t = np.arange(N, dtype=np.float64)
-    shifts = (339, 705)
     for tid, m in zip((uchirp.TABLE_UP, uchirp.TABLE_DOWN), shifts):
         ph = -2.0 * np.pi * m * t / N
         e.set_table(tid, np.stack([np.cos(ph), np.sin(ph)], axis=1).astype(np.float32).reshape(-1))
+
+
+@pytest.mark.parametrize("geom,W", GEOMS)
+def test_every_live_bin_of_every_capture_through_the_complex_kernel(uchirp, geom, W):
+    """band_kernel<sync_cplx> with reference e^{-j 2 pi m t / n}: Z[k] = X[k + m], so the +-W-bin window sits on bins
+    m - W .. m + W of the capture's spectrum.  W = 318: m = 339 (up slot) and m = 705 (down slot) cover bins 21 .. 1023;
+    W = 190 (the default two-round build): m = 211, 591, 833 in two passes.  Every bin the device printed at or above
+    1 kHz, for all 23 consistent captures, plus the global arg-max."""
+    e = uchirp.Engine(uchirp.SYNC_CPLX, **geom)
+    assert e.bandwidth2 == W
+    passes = [(339, 705)] if W == 318 else [(211, 591), (833, 833)]
     caps = list(_captures())
-    spec = e.window_spectrum(np.stack([c[1] for c in caps])).astype(np.float64)      # [24, 2, 637]
+    frames = np.stack([c[1] for c in caps])
+    specs, shifts = [], []
+    for sh in passes:
+        _slide(e, uchirp, sh)
+        sp = e.window_spectrum(frames).astype(np.float64)          # [24, 2, 2 W + 1]
+        for h in (0, 1):
+            specs.append(sp[:, h])
+            shifts.append(sh[h])
+    top = max(float(np.nanmax(sp)) for sp in specs)
     checked = 0
     for i, (name, raw, flt, freq, mag_dev) in enumerate(caps):
         g = np.full(1024, np.nan)
-        for h, m in enumerate(shifts):
-            lo, hi = max(m - 318, 0), min(m + 318, 1023)
-            seg = spec[i, h, lo - m + 318: hi - m + 318 + 1]
+        for sp, m in zip(specs, shifts):
+            lo, hi = max(m - W, 0), min(m + W, 1023)
+            seg = sp[i, lo - m + W: hi - m + W + 1]
             both = ~np.isnan(g[lo:hi + 1])
-            # bins both shifts reach agree with each other to round-off
-            assert np.all(np.abs(g[lo:hi + 1][both] - seg[both]) <= MAG_TOL * np.nanmax(spec[i]))
+            # bins several shifts reach agree with each other to round-off
+            assert np.all(np.abs(g[lo:hi + 1][both] - seg[both]) <= MAG_TOL * top)
             g[lo:hi + 1] = seg
         live = np.nonzero(freq >= 1000.0)[0]
         assert not np.isnan(g[live]).any()
@@ -151,20 +176,16 @@ def test_window_spectrum_matches_the_oracle_bin_by_bin(uchirp, name, kw):
         g = e.window_spectrum(frames)
         assert g.shape == (257, e.spf, 2 * bw2 + 1)
         _, st = e.process(frames)
-        pair = name == "dechirp_down"
         for f in range(257):
             ref = o.spectrum(frames[f])                    # [spf, n] float64
             for h in range(e.spf):
                 want = np.concatenate([ref[h][N - bw2:], ref[h][:bw2 + 1]])
                 assert np.abs(g[f, h] - want).max() <= MAG_TOL * want.max(), (f, h)
-                # the statistics are the maxima of exactly these values.  Bit for bit when both calls run the same build
-                # (windows wider than 191 bins); the default two-round build DERIVES the twiddles of bins >= 128 where
-                # the three-round build reads them from the table, so there the two agree to float32 round-off.
+                # the statistics are the maxima of exactly these values, bit for bit: both calls run the same build (round 4:
+                # the default two-round build has its own instantiation with the bin stores; it used to borrow the
+                # three-round build, whose twiddles for bins >= 128 come from the table instead of being derived)
                 mr, ml = g[f, h, bw2:2 * bw2].max(), g[f, h, :bw2].max()
-                if bw2 > 191 and not pair:
-                    assert st[f, h]["mag_max_right"] == mr and st[f, h]["mag_max_left"] == ml
-                else:
-                    assert abs(st[f, h]["mag_max_right"] - mr) <= 2e-6 * mr and abs(st[f, h]["mag_max_left"] - ml) <= 2e-6 * ml
+                assert st[f, h]["mag_max_right"] == mr and st[f, h]["mag_max_left"] == ml, (f, h)
     # device tensors, overlapping frames
     import torch
     x = torch.from_numpy(frames.reshape(-1)[: 2048 * 9]).to("cuda:0")
@@ -210,3 +231,40 @@ def test_set_table_custom_reference_matches_the_oracle(uchirp, name):
         uchirp.Engine(uchirp.COMPRESS).set_table(uchirp.TABLE_UP, np.ones(N, np.float32))
     with pytest.raises(uchirp.UchirpError):
         uchirp.Engine(uchirp.COMPRESS).window_spectrum(frames)
+
+
+def test_default_build_statistics_against_the_device_spectrum(uchirp):
+    """The THROUGHPUT instantiation itself (uc_process_batch, band_kernel<sync_cplx, int32> two-round build, no spectrum
+    stores) against the device's `.fft`: the reference e^{-j 2 pi m t / n} puts bins m .. m + 189 of the capture into the
+    right window and m - 190 .. m - 1 into the left one; for every shift whose windows lie wholly at or above 1 kHz the
+    statistics' mag_max_right / mag_max_left and their peak bins must be the device's maximum and arg-max over those bins."""
+    W = 190
+    e = uchirp.Engine(uchirp.SYNC_CPLX, **GEOM_DEFAULT)
+    assert e.bandwidth2 == W
+    to_bin_r = {e.idx2freq(k): k for k in range(W)}                 # idx2freq is injective inside a window
+    to_bin_l = {e.idx2freq(N - k): k for k in range(1, W + 1)}      # left window: index n - k, k = 1 .. W
+    caps = list(_captures())
+    frames = np.stack([c[1] for c in caps])
+    checked = 0
+    for sh in ((211, 401), (591, 781), (833, 833)):
+        _slide(e, uchirp, sh)
+        _, st = e.process(frames)
+        for i, (name, raw, flt, freq, mag_dev) in enumerate(caps):
+            if name == K6_MISMATCHED:
+                continue
+            scale = np.abs(np.fft.rfft(raw.astype(np.float64) * np.hanning(N + 1)[:N])).max()
+            tol = MAG_TOL * scale + PRINT_STEP
+            for h, m in enumerate(sh):
+                assert m + W - 1 <= 1023
+                if freq[m - W] < 1000.0:       # (the 41.7 kHz captures: the device forced these bins to 1.0)
+                    continue
+                right, left = mag_dev[m:m + W], mag_dev[m - W:m]
+                assert abs(st[i, h]["mag_max_right"] - right.max()) <= tol, (name, m)
+                assert abs(st[i, h]["mag_max_left"] - left.max()) <= tol, (name, m)
+                # the peak bin is the device's arg-max, or a bin the device itself printed within tolerance of it
+                kr = to_bin_r[int(st[i, h]["max_freq_right"])]
+                kl = to_bin_l[int(st[i, h]["max_freq_left"])]
+                assert right.max() - right[kr] <= 2 * tol, (name, m, kr, int(np.argmax(right)))
+                assert left.max() - left[W - kl] <= 2 * tol, (name, m, kl)
+                checked += 1
+    assert checked >= 23 * 4, checked

@@ -100,7 +100,7 @@ struct uc_ctx {
   DevBuf s_cic_in, s_cic_out;
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
-  int band_blocks_per_cu[2][3][2] = {};  // [wide][mode][dtype]: the instantiations differ in registers
+  int band_blocks_per_cu[3][3][2] = {};  // [default / wide / default + spectrum stores][mode][dtype]: the instantiations differ in registers
   int full_blocks_per_cu[2] = {0, 0};    // [dtype]: the int32 / f32 instantiations differ in registers
   int iq_blocks_per_cu[2] = {0, 0};
   int stream_blocks_per_cu[2] = {0, 0};
@@ -741,7 +741,7 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   p.stats = d_stats;
   p.magmax = d_magmax;
   p.spectrum = d_spectrum;
-  p.wide = (c->tab.bandwidth2 > (uint32_t)uc::kBandNarrowMax || d_spectrum) ? 1u : 0u;
+  p.wide = c->tab.bandwidth2 > (uint32_t)uc::kBandNarrowMax ? 1u : 0u;
   p.mag_mean_scalar = c->cfg.mag_mean;
   p.snr_threshold = c->cfg.snr_threshold;
   p.bw2 = c->tab.bandwidth2;
@@ -758,8 +758,12 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   // the second one is loaded inside the loop, behind the frame prefetch in the in-order vector-memory queue):
   // 2.59e8 against 2.45e8 frames/s (profiles/r03_sync_cplx_waves.txt)
   const int waves = (mode == uc::kModeCplx && !c->band_waves_set) ? 2 : c->band_waves;
-  int& bpc = c->band_blocks_per_cu[p.wide][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
-  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0);
+  // uc_window_spectrum runs the SAME two-round build as the statistics path when the windows fit it (bandwidth2 <= 191): the
+  // instantiation that also stores the window bins (uc_band_kernel.hip: SPEC), so that what the device captures are
+  // compared with is the arithmetic of the throughput kernel
+  const bool spec = d_spectrum != nullptr && !p.wide;
+  int& bpc = c->band_blocks_per_cu[p.wide ? 1 : (spec ? 2 : 0)][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
+  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0, spec);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;
   // DECHIRP_DOWN (frame pairs, the HBM-bound one) runs at the loads-only floor of this kernel structure, and that floor is
   // lower with fewer concurrent streams: 5 workgroups per CU instead of the 6 that fit: 7.69 against 7.54e8 frames/s,

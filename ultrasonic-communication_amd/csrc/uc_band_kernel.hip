@@ -315,7 +315,10 @@ __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
 
 // WIDE: windows of up to 319 bins (three pruned-pass rounds, generic window search, 16-bit indices in the ring);
 // built at 2 waves/SIMD only.  The default build (windows of up to 191 bins) is untouched by it.
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false>
+// SPEC: the same build with the window bins' magnitudes stored as well (uc_window_spectrum; p.spectrum).  A separate
+// instantiation, so that the throughput builds carry neither the branch nor the stores: band_kernel<.., false, false> is
+// instruction for instruction what it was (tools/isa_hist.sh).  The WIDE build tests p.spectrum at run time.
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false>
 __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #ifdef UC_STAMPS
   unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -539,6 +542,36 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     }
   };
 
+  // uc_window_spectrum: the magnitudes pipeline() leaves in signal[] (receiver/Src/main.c:176-179), for the bins dsp()
+  // looks at: bin i of unit f, run `run`; qa / qb = the squared magnitudes the window search sees (x 4 for real references).
+  // Real reference(s): both sides of DC carry the same value (Hermitian mirror, Q1).
+  auto store_spectrum = [&](unsigned f, int run, int i, float qa, float qb) {
+    const size_t wb = 2 * (size_t)bw2 + 1;
+    const float va = (kReal ? 0.5f : 1.0f) * sqrtf(qa);  // (the finaliser's own expression: bit-equal to the stats)
+    const float vb = (kReal ? 0.5f : 1.0f) * sqrtf(qb);
+    if (MODE == kModeCplx) {
+      float* o = p.spectrum + ((size_t)f * 2 + run) * wb + bw2;
+      o[i] = va;
+      if (i) o[-i] = vb;
+    } else if (kPair) {
+      const size_t fa = (size_t)f << psh;
+      float* oa = p.spectrum + fa * wb + bw2;
+      oa[i] = va;
+      oa[-i] = va;
+      if (psh && fa + 1 < p.n_frames) {
+        float* ob = oa + wb;
+        ob[i] = vb;
+        ob[-i] = vb;
+      }
+    } else {
+      float* o = p.spectrum + (size_t)f * 2 * wb + bw2;
+      o[i] = va;
+      o[-i] = va;
+      o[wb + i] = vb;
+      o[wb - i] = vb;
+    }
+  };
+
   unsigned ring_f0 = f;  // frame held by ring slot 0
   int ring_n = 0;        // slots filled
 
@@ -735,34 +768,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
               qa[r] = zl.x * zl.x + zl.y * zl.y;
               qb[r] = zh.x * zh.x + zh.y * zh.y;
             }
-            if (p.spectrum) {
-              // uc_window_spectrum: the magnitudes pipeline() leaves in signal[] (receiver/Src/main.c:176-179), for the
-              // bins dsp() looks at.  Real reference(s): both sides of DC carry the same value (Hermitian mirror, Q1).
-              const size_t wb = 2 * (size_t)bw2 + 1;
-              const float va = (kReal ? 0.5f : 1.0f) * sqrtf(qa[r]);  // (the finaliser's own expression: bit-equal to the stats)
-              const float vb = (kReal ? 0.5f : 1.0f) * sqrtf(qb[r]);
-              if (MODE == kModeCplx) {
-                float* o = p.spectrum + ((size_t)f * 2 + run) * wb + bw2;
-                o[i] = va;
-                if (i) o[-i] = vb;
-              } else if (kPair) {
-                const size_t fa = (size_t)f << psh;
-                float* oa = p.spectrum + fa * wb + bw2;
-                oa[i] = va;
-                oa[-i] = va;
-                if (psh && fa + 1 < p.n_frames) {
-                  float* ob = oa + wb;
-                  ob[i] = vb;
-                  ob[-i] = vb;
-                }
-              } else {
-                float* o = p.spectrum + (size_t)f * 2 * wb + bw2;
-                o[i] = va;
-                o[-i] = va;
-                o[wb + i] = vb;
-                o[wb - i] = vb;
-              }
-            }
+            if (p.spectrum) store_spectrum(f, run, i, qa[r], qb[r]);
           }
         }
         UC_STAMP(6);
@@ -881,6 +887,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             if (do_a) m_a[r] = zl.x * zl.x + zl.y * zl.y;  // |Z|^2: the finaliser takes sqrt
             if (do_b) m_b[r] = zh.x * zh.x + zh.y * zh.y;
           }
+          if constexpr (SPEC) {
+            if (p.spectrum) store_spectrum(f, run, i, m_a[r], m_b[r]);
+          }
         }
       }
       UC_STAMP(6);
@@ -951,16 +960,16 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   UC_CLOCK_END(p.debug, 2);
 }
 
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false>
 static int launch_one(const BandParams& p, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES, WIDE>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
   return (int)hipGetLastError();
 }
 
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false>
 static int occupancy_one() {
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES, WIDE>, T, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC>, T, 0);
   if (e != hipSuccess || nb <= 0) nb = 2 * WAVES;
   return nb;
 }
@@ -969,6 +978,18 @@ static int occupancy_one() {
 
 #define UC_DISPATCH(FN, ...)                                                              \
   do {                                                                                    \
+    if (spec && !wide) { /* uc_window_spectrum on the default two-round build, at each mode's default occupancy */ \
+      if (mode == kModePair) {                                                            \
+        if (dtype == UC_DTYPE_I32) return FN<kModePair, UC_DTYPE_I32, 3, false, true>(__VA_ARGS__);   \
+        return FN<kModePair, UC_DTYPE_F32, 3, false, true>(__VA_ARGS__);                  \
+      }                                                                                   \
+      if (mode == kModeRxReal) {                                                          \
+        if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 3, false, true>(__VA_ARGS__); \
+        return FN<kModeRxReal, UC_DTYPE_F32, 3, false, true>(__VA_ARGS__);                \
+      }                                                                                   \
+      if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, false, true>(__VA_ARGS__);     \
+      return FN<kModeCplx, UC_DTYPE_F32, 2, false, true>(__VA_ARGS__);                    \
+    }                                                                                     \
     if (wide) { /* windows of 192 .. 319 bins: one build per mode and dtype */             \
       if (mode == kModePair) {                                                            \
         if (dtype == UC_DTYPE_I32) return FN<kModePair, UC_DTYPE_I32, 2, true>(__VA_ARGS__);   \
@@ -1007,11 +1028,11 @@ static int occupancy_one() {
 
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream) {
   if (grid <= 0) return (int)hipSuccess;
-  const bool wide = p.wide != 0;
+  const bool wide = p.wide != 0, spec = p.spectrum != nullptr;
   UC_DISPATCH(launch_one, p, grid, stream);
 }
 
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide) {
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec) {
   UC_DISPATCH(occupancy_one);
 }
 

@@ -27,9 +27,9 @@ struct BandParams {
   uc_stats* stats;        // device or nullptr
   float2* magmax;         // device or nullptr: (up, down) mag_max of every frame only (uc_receive_stream's replay needs no
                           // more: 8 instead of 64 bytes per frame to bring back); RX_REAL / SYNC_CPLX
-  float* spectrum;        // device or nullptr (WIDE build only): |X| of the window bins -bw2 .. +bw2 of every history,
+  float* spectrum;        // device or nullptr: |X| of the window bins -bw2 .. +bw2 of every history,
                           // [frame][history][2 bw2 + 1], entry bw2 + k = bin k (k < 0: bin n + k) -- uc_window_spectrum
-  uint32_t wide;          // 1 = the WIDE build (bw2 > kBandNarrowMax, or spectrum != nullptr)
+  uint32_t wide;          // 1 = the WIDE build (bw2 > kBandNarrowMax)
   float mag_mean_scalar;
   float snr_threshold;
   uint32_t bw2;           // window length (<= kBandWideMax; > kBandNarrowMax selects the WIDE build)
@@ -49,7 +49,8 @@ enum BandMode { kModeRxReal = 0, kModeCplx = 1, kModePair = 2 };
 // returns hipError_t as int
 // `waves` = min waves per SIMD the kernel was compiled for (2, 3 or 4): a tuning knob
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide);
+// spec: the instantiation that also stores the window bins (p.spectrum != nullptr on the default two-round build)
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false);
 
 // Full-spectrum pipeline: UC_COMPRESS (FFT x H x IFFT, two frames per complex transform).
 struct FullParams {
