@@ -188,9 +188,37 @@ def valu_table():
     return _VALU
 
 
-def roofline(kernel_key, kernel_name, units, bytes_per_unit, kern_ms, num_cu=256):
+_NUM_CU = {}
+
+
+def num_cus(torch, device):
+    """Compute units of the device the kernel runs on (hipDeviceProp.multiProcessorCount), not a constant."""
+    key = str(device)
+    if key not in _NUM_CU:
+        _NUM_CU[key] = int(torch.cuda.get_device_properties(device).multi_processor_count)
+    return _NUM_CU[key]
+
+
+def live_clock(eng, launch, launches=12):
+    """The shader clock the chip holds under `launch`'s kernel, in THIS run on THIS box: the clock-stamped twin of the
+    kernel (uc_clock_probe, include/uchirp.h: one s_memtime / s_memrealtime stamp pair per wave), `launches` back-to-back
+    launches right behind the timed region (the clocks are where the timed launches left them), read from the last one."""
+    eng.clock_probe(True)
+    try:
+        for _ in range(launches):
+            launch()
+        c = eng.clock_read()
+    finally:
+        eng.clock_probe(False)
+    c["method"] = ("uc_clock_read: median over %d waves of cycles / 100 MHz ticks in the clock-stamped twin of the kernel, last "
+                   "of %d back-to-back launches right behind the timed region of this run" % (c["waves"], launches))
+    return c
+
+
+def roofline(kernel_key, kernel_name, units, bytes_per_unit, kern_ms, num_cu=256, clock=None):
     """Both roofs of one launch: HBM (algorithmic bytes / kernel time / 8 TB/s) and VALU issue (wave-instructions x 4
-    cycles / (4 SIMDs x CUs x in-kernel clock x kernel time)); `bound` = the larger fraction."""
+    cycles / (4 SIMDs x CUs x in-kernel clock x kernel time)); `bound` = the larger fraction.
+    clock: live_clock()'s record of this run; without it the clock of the committed counter pass is used and labelled so."""
     achieved = units * bytes_per_unit / (kern_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
          "kernel": kernel_name, "kernel_ms": kern_ms, "bytes_per_unit": bytes_per_unit}
@@ -198,9 +226,15 @@ def roofline(kernel_key, kernel_name, units, bytes_per_unit, kern_ms, num_cu=256
     v = tab.get(kernel_key)
     if v:
         cyc = v["valu_insts_per_unit"] * 4.0 / 4.0                       # issue cycles per unit and CU: 4 SIMDs share it
-        frac = v["valu_insts_per_unit"] * units * 4.0 / (4.0 * num_cu * v["clock_GHz"] * 1e9 * kern_ms * 1e-3)
+        ghz = clock["shader_ghz"] if clock else v["clock_GHz"]
+        frac = v["valu_insts_per_unit"] * units * 4.0 / (4.0 * num_cu * ghz * 1e9 * kern_ms * 1e-3)
         r["valu"] = {"insts_per_unit": v["valu_insts_per_unit"], "issue_cycles_per_unit": cyc,
-                     "clock_GHz": v["clock_GHz"], "frac": frac, "source": src + ": " + v.get("source", "")}
+                     "clock_GHz": ghz, "num_cu": num_cu,
+                     "clock_source": clock["method"] if clock else "NOT measured in this run: the clock of the committed counter pass",
+                     "clock_GHz_of_the_counter_pass": v["clock_GHz"],
+                     "frac": frac, "source": "instructions per unit: " + src + ": " + v.get("source", "")}
+        if clock:
+            r["valu"]["wave_loop_cycles_median"] = clock["wave_cycles"]
         if "lds_insts_per_unit" in v:
             r["valu"]["lds_insts_per_unit"] = v["lds_insts_per_unit"]
         if frac > r["frac"]:
@@ -272,9 +306,10 @@ def config2_iq(args, device, stream, torch, mag_mean):
 
     ramp = clock_ramp(launch_bb, torch, args.ramp_ms)
     wall, kern = timed_launches(launch_bb, stream, torch, steps, warm)
+    ncu, clk = num_cus(torch, device), live_clock(eng, launch_bb)
     bb = {"mode": "UC_FLAG_IQ_BASEBAND: mix, 27-tap FIR, dechirp by conj(up) and conj(down), 2 x CFFT-1024, windows around DC, symbol",
           "value": nf / (wall * 1e-3), "unit": "frames/s", "ms_per_step": wall, "ramp_launches": ramp,
-          "roofline": roofline("iq1024_bb_f32", "iq1024_kernel<f32,baseband>", nf, 4096 + 1, kern),
+          "roofline": roofline("iq1024_bb_f32", "iq1024_kernel<f32,baseband>", nf, 4096 + 1, kern, ncu, clk),
           "bytes_note": "4096 B in + 1 B symbol out per frame (+ 104 B of FIR history once per launch)",
           "bit_error_rate_vs_transmitted": float((sym != bits).float().mean().item())}
     if not args.no_cpu_baseline:
@@ -283,7 +318,10 @@ def config2_iq(args, device, stream, torch, mag_mean):
         head = x[: 26 + 4096 * n].cpu().numpy()
         rs, rst = o.process(head, halo=26, n_frames=4096)
         clear = clear_frames(rst)
-        bb["symbols_equal_oracle_head4096_clear"] = float((sym[:4096].cpu().numpy()[clear] == rs[clear]).mean())
+        got = sym[:4096].cpu().numpy()
+        # (all clear frames equal AND there are clear frames: the mean of an empty mask is NaN, which no comparison catches)
+        bb["symbols_equal_oracle_head4096_clear"] = float((got[clear] == rs[clear]).mean()) if clear.any() else 0.0
+        bb["oracle_head_clear_frames"] = int(clear.sum())
         bb["oracle_head_near_ties_excluded"] = int((~clear).sum())
         bb["oracle_head_bit_error_rate"] = float((rs != bits[:4096].cpu().numpy()).mean())
     out["baseband"] = bb
@@ -297,10 +335,11 @@ def config2_iq(args, device, stream, torch, mag_mean):
 
     clock_ramp(launch_fw, torch, args.ramp_ms / 3)
     wall, kern = timed_launches(launch_fw, stream, torch, steps, warm)
+    clk = live_clock(eng, launch_fw)
     out["firmware_windows"] = {
         "mode": "the committed firmware's windows at bin (F1+F2) n / fs (iq_modulation/Src/main.c:215-219,283-285): one dechirp run, one history",
         "value": nf / (wall * 1e-3), "unit": "frames/s", "ms_per_step": wall,
-        "roofline": roofline("iq1024_fw_f32", "iq1024_kernel<f32,firmware windows>", nf, 4096 + 32, kern),
+        "roofline": roofline("iq1024_fw_f32", "iq1024_kernel<f32,firmware windows>", nf, 4096 + 32, kern, ncu, clk),
         "bytes_note": "4096 B in + 32 B history record out per frame"}
     out["baseband_over_firmware_windows"] = bb["value"] / out["firmware_windows"]["value"]
     eng.close()
@@ -333,8 +372,9 @@ def config3_stream(args, frames, device, torch):
 
     clock_ramp(launch, torch, args.ramp_ms)
     wall, kern = timed_launches(launch, s1, torch, steps, warm)
+    ncu, clk = num_cus(torch, device), live_clock(eng, launch)
     out["eager"] = {"value": x.numel() / (wall * 1e-3), "unit": "samples/s", "ms_per_step": wall,
-                    "roofline": roofline("stream_d8_f32", "stream_kernel<f32,8>", x.numel(), byts, kern)}
+                    "roofline": roofline("stream_d8_f32", "stream_kernel<f32,8>", x.numel(), byts, kern, ncu, clk)}
     s2 = torch.cuda.Stream(device)
     g = torch.cuda.CUDAGraph()
     s2.wait_stream(s1)
@@ -348,7 +388,7 @@ def config3_stream(args, frames, device, torch):
     torch.cuda.synchronize()
     out["graph_replay"] = {"value": x.numel() / (wall * 1e-3), "unit": "samples/s", "ms_per_step": wall,
                            "roofline": roofline("stream_d8_f32", "stream_kernel<f32,8> (captured hipGraph, replayed)",
-                                                x.numel(), byts, kern)}
+                                                x.numel(), byts, kern, ncu, clk)}
     out["graph_equals_eager"] = bool(torch.equal(comp, comp_g) and torch.equal(pk, pk_g))
     out["graph_over_eager"] = out["graph_replay"]["value"] / out["eager"]["value"]
     if not args.no_cpu_baseline:
@@ -366,75 +406,61 @@ def config3_stream(args, frames, device, torch):
 
 
 def hello_world1(args, device, torch, mag_mean):
-    """The N > 1 leg at world size 1, inside the N = 1 run: configs[4] framing, matched sweep, an RCCL process group of one
-    rank, the asynchronous all-gather of the symbol stream every step (double-buffered as in the N > 1 run), decode.
+    """The N > 1 leg at world size 1, inside the N = 1 run: configs[4] framing, matched sweep, a uc_group of one device
+    (include/uchirp.h: the RCCL communicator and the in-place all-gather of the symbol stream are made and called from C,
+    on the group's gather stream, every step; three buffers in rotation as in the N > 1 run), decode.
     Gives the driver's 1 -> N efficiency a like-for-like anchor (the N = 1 contract line runs configs[1] without a gather)."""
-    import torch.distributed as dist
     import uchirp
     from uchirp import synth
-    own = not dist.is_initialized()
-    if own:
-        sk = socket.socket()
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-        sk.close()
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=device)
+    nf = args.frames
+    grp = uchirp.Group(uchirp.RX_REAL, devices=[device.index], mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
     try:
-        nf = args.frames
-        eng = uchirp.Engine(uchirp.RX_REAL, device=device.index, mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
         frames, sent = synth.device_hello_frames(0, nf, device, seed=1234, snr_db=args.snr, msg=MSG)
         stream = torch.cuda.current_stream(device)
-        sym2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(NBUF)]
         gat2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(NBUF)]
-        works = [None] * NBUF
 
         def step(k, e0=None, e1=None):
-            b = k % NBUF
-            if works[b] is not None:
-                works[b].wait()
             if e0 is not None:
                 e0.record(stream)
-            eng.process(frames, want_stats=False, symbols_out=sym2[b], stream=stream.cuda_stream)
+            grp.process([frames], nf, [gat2[k % NBUF]], streams=[stream.cuda_stream])
             if e1 is not None:
                 e1.record(stream)
-            works[b] = dist.all_gather_into_tensor(gat2[b], sym2[b], async_op=True)
 
-        def drain():
-            for b in range(NBUF):
-                if works[b] is not None:
-                    works[b].wait()
-                    works[b] = None
-
-        clock_ramp(lambda: eng.process(frames, want_stats=False, symbols_out=sym2[0], stream=stream.cuda_stream), torch,
-                   args.ramp_ms)
+        clock_ramp(lambda: step(0), torch, args.ramp_ms)
         for k in range(args.warmup):
             step(k)
-        drain()
+        grp.synchronize()
         torch.cuda.synchronize()
         ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
         t0 = time.perf_counter()
         for k in range(args.steps):
             step(k, ev[k][0], ev[k][1])
-        drain()
+        grp.synchronize()
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         kern = float(np.mean([a.elapsed_time(b) for a, b in ev]))
         g = gat2[(args.steps - 1) % NBUF]
-        ok = bool(torch.equal(g, sym2[(args.steps - 1) % NBUF]))
+        # the checker: the same frames through a plain context (uc_process_batch), no group
+        eng = uchirp.Engine(uchirp.RX_REAL, device=device.index, mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
+        ref, _ = eng.process(frames, want_stats=False)
+        torch.cuda.synchronize()
+        ok = bool(torch.equal(g, ref))
+        eng.close()
         texts = synth.decode_hello(g.cpu().numpy(), len(MSG))
         good = sum(1 for t in texts if t == MSG)
         ms = elapsed / args.steps * 1e3
+        import hashlib
         out = {"workload": "configs[4] at world size 1: %d x 2048-sample frames, K7 'Hello World!' framing, SNR %.0f dB, matched "
-                           "sweep, RCCL all-gather of the symbol stream every step" % (nf, args.snr),
+                           "sweep, all-gather of the symbol stream every step" % (nf, args.snr),
+               "gather_backend": "uc_group_process_batch: RCCL (ncclAllGather, in place) called from C on the group's gather stream",
                "value": nf * args.steps / elapsed, "unit": "frames/s", "ms_per_step": ms, "steps": args.steps,
                "kernel_ms": kern, "gather_ms_exposed": ms - kern, "gathered_equals_decoded": ok,
+               "symbols_sha256": hashlib.sha256(g.cpu().numpy().tobytes()).hexdigest(),
                "transmissions": len(texts), "transmissions_decoded_exactly": good}
-        eng.close()
-        del frames, sym2, gat2
+        del frames, gat2
         return out
     finally:
-        if own:
-            dist.destroy_process_group()
+        grp.close()
 
 
 def stream_measurement(args, eng, frames, rank, torch):
@@ -450,6 +476,7 @@ def stream_measurement(args, eng, frames, rank, torch):
 
     clock_ramp(launch, torch, args.ramp_ms)
     wall, kern = timed_launches(launch, stream, torch, args.steps, args.warmup)
+    ncu, clk = num_cus(torch, x.device), live_clock(eng, launch)
     byts = (x.numel() * 4 + n_out * 4 + n_blocks * 8) / x.numel()
     if rank == 0:
         print(json.dumps({"metric": "input samples/s (stream: FIR decimate + overlap-save compression, side measurement)",
@@ -457,7 +484,7 @@ def stream_measurement(args, eng, frames, rank, torch):
                           "warmup": args.warmup, "ms_per_step": wall, "decim": int(eng.cfg.decim),
                           "blocks": n_blocks, "blocks_per_s": n_blocks / (wall * 1e-3),
                           "roofline": roofline("stream_d%d_f32" % int(eng.cfg.decim), "stream_kernel<f32,%d>" % int(eng.cfg.decim),
-                                               x.numel(), byts, kern)}), flush=True)
+                                               x.numel(), byts, kern, ncu, clk)}), flush=True)
 
 
 SIDE = {  # variant -> (algorithmic bytes per frame, key of profiles/r*_valu_insts.json, kernel)
@@ -489,11 +516,12 @@ def side_measurement(args, eng, frames, world, rank, torch):
 
     clock_ramp(launch, torch, args.ramp_ms)
     wall, kern = timed_launches(launch, stream, torch, args.steps, args.warmup)
+    ncu, clk = num_cus(torch, frames.device), live_clock(eng, launch)
     if rank == 0:
         print(json.dumps({"metric": "chirp frames/s (%s, side measurement)" % args.variant, "value": nfr / (wall * 1e-3),
                           "unit": "frames/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": wall,
                           "frame_len": n, "frames": nfr,
-                          "roofline": roofline(key, kname, nfr, per_frame, kern)}), flush=True)
+                          "roofline": roofline(key, kname, nfr, per_frame, kern, ncu, clk)}), flush=True)
 
 
 def parse_args(argv=None):
@@ -511,6 +539,9 @@ def parse_args(argv=None):
                     help="default rx_real = BASELINE configs[1]; the others are side measurements")
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs[2] / configs[3] block")
     ap.add_argument("--no-hello1", action="store_true", help="N = 1: skip the configs[4] leg at world size 1")
+    ap.add_argument("--single-process", action="store_true",
+                    help="--gpus N in ONE process: a uc_group over N devices (include/uchirp.h), as a C host would drive the node "
+                         "(tests/c/host_multi.c); the default is one process per GPU")
     return ap.parse_args(argv)
 
 
@@ -558,9 +589,116 @@ def launch_ranks(args):
         raise SystemExit("bench.py: a rank failed (exit %s)" % rc if rc != 3 else 3)
 
 
+def single_process(args):
+    """`python bench.py --gpus N --single-process`: configs[4] with ONE host process driving all N GPUs through a uc_group
+    (include/uchirp.h: uc_group_create = ncclCommInitAll, one launch stream + one gather stream per device) -- the shape a C
+    host of the library has (tests/c/host_multi.c is that host in C99); same workload, same timed region, same JSON line as
+    the one-process-per-GPU run.  torch only makes the frames and holds the buffers."""
+    import hashlib
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    world = args.gpus
+    if torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --single-process --gpus %d: only %d device(s) visible" % (world, torch.cuda.device_count()))
+    import uchirp
+    from uchirp import synth
+    sys.stdout.flush()
+    json_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)                              # RCCL's banner and anything else on descriptor 1 goes to stderr
+    nf, mag_mean = args.frames, 1000.0
+    devs = [torch.device("cuda", d) for d in range(world)]
+    grp = uchirp.Group(uchirp.RX_REAL, devices=list(range(world)), mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
+    frames, streams = [], []
+    for r, d in enumerate(devs):
+        f, _ = synth.device_hello_frames(r * nf, nf, d, seed=1234 + r, snr_db=args.snr, msg=MSG)
+        frames.append(f)
+        streams.append(torch.cuda.Stream(d))
+    gat = [[torch.empty(world * nf, dtype=torch.uint8, device=d) for d in devs] for _ in range(NBUF)]
+    handles = [st.cuda_stream for st in streams]
+
+    def step(k, ev=None):
+        if ev is not None:
+            for r in range(world):
+                ev[r][0].record(streams[r])
+        grp.process(frames, world * nf, gat[k % NBUF], streams=handles)
+        if ev is not None:
+            for r in range(world):
+                ev[r][1].record(streams[r])
+
+    def sync():
+        grp.synchronize()
+        for d in devs:
+            torch.cuda.synchronize(d)
+
+    ramp_launches = 0
+    t_r = time.perf_counter()
+    while args.ramp_ms > 0 and (time.perf_counter() - t_r) * 1e3 < args.ramp_ms:
+        for _ in range(4):
+            step(0)
+        sync()
+        ramp_launches += 4
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    evs = []
+    for k in range(args.steps):
+        row = []
+        for d in devs:
+            with torch.cuda.device(d):
+                row.append((torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)))
+        evs.append(row)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k, evs[k])
+    sync()
+    elapsed = time.perf_counter() - t0
+    km = np.array([[a.elapsed_time(b) for a, b in row] for row in evs]).mean(axis=0)       # kernel ms by device
+    last = gat[(args.steps - 1) % NBUF]
+    host = [g.cpu().numpy() for g in last]
+    digs = [hashlib.sha256(h.tobytes()).hexdigest() for h in host]
+    gate_failures = []
+    if len(set(digs)) != 1:
+        gate_failures.append("devices hold different gathered symbol streams")
+    texts = synth.decode_hello(host[0], len(MSG))
+    good = sum(1 for t in texts if t == MSG)
+    if good != len(texts):
+        gate_failures.append("hello: %d of %d transmissions decode" % (good, len(texts)))
+    data = synth.hello_kind_stream(0, world * nf, MSG)
+    m = data != 2
+    value = world * nf * args.steps / elapsed
+    out = {"metric": "chirp frames/s (2048-pt FFT demod)", "value": value, "unit": "frames/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ramp_ms": args.ramp_ms,
+           "ramp_launches": ramp_launches,
+           "gather_backend": "uc_group_process_batch in ONE process: ncclCommInitAll, ncclAllGather in place per device inside "
+                             "one ncclGroupStart/End, called from C",
+           "config": {"workload": "configs[4]: %d x 2048-sample fp32 frames per GPU, frame-sharded 'Hello World!' stream (K7 "
+                                  "framing repeated over the global frame index), SNR %.0f dB, rx_real with the reference "
+                                  "sweep matched to the frame" % (nf, args.snr),
+                      "frames_per_gpu": nf, "frame_len": N, "variant": "rx_real", "time_frame": MATCHED_TIME_FRAME,
+                      "parallelism": "frame-sharded x%d, ONE host process (uc_group), RCCL all-gather of the symbol stream "
+                                     "(1 B/frame) every step" % world},
+           "roofline": roofline("band_rx_real_f32", "band_kernel<rx_real,f32>", nf, BYTES_PER_FRAME, float(km.max())),
+           "per_rank": {"kernel_ms_by_rank": [float(v) for v in km]},
+           "gather_ms_exposed": elapsed / args.steps * 1e3 - float(km.max()),
+           "value_per_gpu": value / world, "symbols_sha256": digs[0],
+           "decoded_text_first": texts[0] if texts else "", "transmissions": len(texts),
+           "transmissions_decoded_exactly": good,
+           "bit_error_rate_vs_transmitted": float((host[0][m] != data[m]).mean()),
+           "gates_failed": gate_failures}
+    print(json.dumps(out), file=json_out, flush=True)
+    grp.close()
+    if gate_failures:
+        sys.stderr.write("bench.py: correctness gate(s) failed: %s\n" % "; ".join(gate_failures))
+        raise SystemExit(3)
+
+
 def main():
     args = parse_args()
     env_world = os.environ.get("WORLD_SIZE")
+    if args.single_process and env_world is None:
+        return single_process(args)
     if env_world is None and args.gpus > 1:
         return launch_ranks(args)
     world = int(env_world or "1")
@@ -627,8 +765,42 @@ def main():
         if hello:
             vkw = dict(vkw, time_frame=MATCHED_TIME_FRAME)
         eng = uchirp.Engine(vid, device=local_rank, mag_mean=mag_mean, **vkw)
+    # The gather of the N > 1 leg goes through the C-ABI: a uc_group of one rank per process (include/uchirp.h,
+    # uc_group_create_rank) -- the RCCL communicator is made from C out of a unique id that rank 0 draws and
+    # torch.distributed merely carries to the others; every step decodes straight into the rank's slice of the gathered
+    # stream and ncclAllGather runs in place on the group's gather stream.  torch.distributed stays the launcher's
+    # rendezvous, the barrier and the max-over-ranks of the contract.  If any rank cannot build its group every rank
+    # falls back to torch.distributed's all_gather_into_tensor (recorded as `gather_backend`); UC_BENCH_TORCH_GATHER=1
+    # selects that path outright.
+    grp, gather_backend = None, "torch.distributed all_gather_into_tensor"
+    if multi and args.variant == "rx_real" and have_gpu and not rehearse and os.environ.get("UC_BENCH_TORCH_GATHER") != "1":
+        idt = torch.zeros(uchirp.GROUP_ID_BYTES, dtype=torch.uint8, device=device)
+        why = ""
+        if rank == 0:
+            try:
+                idt.copy_(torch.frombuffer(bytearray(uchirp.Group.unique_id()), dtype=torch.uint8))
+            except Exception as ex:                      # (an all-zero id tells the others)
+                why = str(ex)
+        dist.broadcast(idt, 0)
+        ok = 0
+        if bool(idt.any().item()):
+            try:
+                grp = uchirp.Group(uchirp.RX_REAL, world=world, rank=rank, unique_id=idt.cpu().numpy().tobytes(),
+                                   device=local_rank, mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
+                ok = 1
+            except Exception as ex:
+                why = str(ex)
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            gather_backend = "uc_group_process_batch: RCCL (ncclAllGather, in place) called from C on the group's gather stream"
+        else:
+            if grp is not None:
+                grp.close()
+                grp = None
+            gather_backend += " (uc_group unavailable: %s)" % (why[:200] or "another rank failed")
     if hello:
-        # rank r owns frames [r nf, (r + 1) nf) of the global stream (uchirp/shard.py::partition, equal shares)
+        # rank r owns frames [r nf, (r + 1) nf) of the global stream (uc_partition, equal shares)
         frames, sent = synth.device_hello_frames(rank * nf, nf, device, seed=1234 + rank, snr_db=args.snr, msg=MSG)
     else:
         frames, sent = synth.device_frames(nf, device, seed=1234 + rank, snr_db=args.snr)
@@ -653,6 +825,13 @@ def main():
 
     def step(k, e0=None, e1=None):
         b = k % NBUF
+        if grp is not None:                   # decode into this rank's slice of gathered2[b] + in-place all-gather, all in C
+            if e0 is not None:
+                e0.record(stream)
+            grp.process([frames], world * nf, [gathered2[b]], streams=[stream.cuda_stream])
+            if e1 is not None:
+                e1.record(stream)
+            return
         if works[b] is not None:
             works[b].wait()
             works[b] = None
@@ -668,6 +847,8 @@ def main():
             works[b] = gather(b)
 
     def drain():
+        if grp is not None:
+            grp.synchronize()
         for b in range(NBUF):
             if works[b] is not None:
                 works[b].wait()
@@ -715,6 +896,12 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     symbols = sym2[(args.steps - 1) % NBUF]
+    if grp is not None:                       # the kernel wrote this rank's symbols straight into its slice of the stream
+        symbols = gathered2[(args.steps - 1) % NBUF][rank * nf:(rank + 1) * nf]
+        if eng is not None:                   # the checker: the same shard through a plain context (uc_process_batch)
+            eng.process(frames, want_stats=False, symbols_out=sym2[0], stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(symbols, sym2[0]), "the group's slice differs from uc_process_batch on the same shard"
     gathered_host = None
     if multi:
         # Every rank holds the concatenation of all ranks' symbols, rank order: its own slice equals what it
@@ -733,6 +920,10 @@ def main():
             digs = [d.cpu() for d in dd]
         assert all(torch.equal(d, digs[0]) for d in digs), "ranks hold different gathered symbol streams"
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in ev])) if have_gpu else None
+    # the clock the chip held under the kernel of the timed region, measured now, on this box (every rank: its own)
+    clk_live = None
+    if eng is not None:
+        clk_live = live_clock(eng, lambda: eng.process(frames, want_stats=False, symbols_out=sym2[0], stream=stream.cuda_stream))
     local_ms = elapsed_local / args.steps * 1e3
     per_rank = None
     if multi:
@@ -755,6 +946,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ramp_ms": args.ramp_ms if have_gpu else 0.0, "ramp_launches": ramp_launches,
         }
+        if multi:
+            out["gather_backend"] = gather_backend
         if hello:
             out["config"] = {"workload": "configs[4]: %d x 2048-sample fp32 frames per GPU, frame-sharded 'Hello World!' "
                                          "stream (K7 framing: G, 7 H, L, 96 data bits, 12 G, repeated over the global frame "
@@ -786,7 +979,8 @@ def main():
                                   % (os.path.relpath(tf, ROOT), nf))
             except Exception:
                 traffic = None
-            out["roofline"] = roofline("band_rx_real_f32", "band_kernel<rx_real,f32>", nf, BYTES_PER_FRAME, kern_ms)
+            out["roofline"] = roofline("band_rx_real_f32", "band_kernel<rx_real,f32>", nf, BYTES_PER_FRAME, kern_ms,
+                                       num_cus(torch, device), clk_live)
             out["roofline"]["bytes_per_frame"] = BYTES_PER_FRAME
             out["roofline"]["traffic"] = traffic
             out["roofline"]["traffic_source"] = traffic_source
@@ -839,8 +1033,8 @@ def main():
                 cfgs[name]["wall_s"] = time.perf_counter() - t_c
             out["configs"] = cfgs
             c2, c3 = cfgs["configs[2]"], cfgs["configs[3]"]
-            if c2.get("baseband", {}).get("symbols_equal_oracle_head4096_clear", 1.0) < 1.0:
-                gate_failures.append("configs[2]: base-band symbols differ from the oracle on clear frames")
+            if not c2.get("baseband", {}).get("symbols_equal_oracle_head4096_clear", 1.0) >= 1.0:   # (NaN fails too)
+                gate_failures.append("configs[2]: base-band symbols differ from the oracle on clear frames (or none is clear)")
             if c3.get("graph_equals_eager") is False:
                 gate_failures.append("configs[3]: graph replay differs from the eager launch")
             if c3.get("head_rel_err_vs_oracle", 0.0) > 2e-5 or c3.get("head_peak_offsets_equal_oracle") is False:
@@ -855,8 +1049,15 @@ def main():
                 h1["over_configs1_value"] = h1["value"] / value
             except Exception as ex:
                 h1 = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+                gate_failures.append("hello_world1 failed: %s" % type(ex).__name__)
             h1["wall_s"] = time.perf_counter() - t_c
             out["hello_world1"] = h1
+            if "value" in h1:
+                # The N > 1 lines of the scaling curve run configs[4] (K7 framing, matched sweep, gather every step); THIS line
+                # runs configs[1] (no gather).  Like for like, the curve's N = 1 point is this one: value(N) / N / anchor.
+                out["scale_anchor"] = {"workload": "configs[4] at world size 1 (the workload of the --gpus N > 1 lines)",
+                                       "n_gpus": 1, "value": h1["value"], "unit": "frames/s", "ms_per_step": h1["ms_per_step"],
+                                       "how": "UC_BENCH_HELLO=1 python bench.py prints this leg as its contract line"}
         if not multi and have_gpu and not args.no_cpu_baseline:
             cb = cpu_baseline(frames[: 1 << 19].cpu().numpy(), mag_mean)
             # the oracle as the checker: GPU symbols of the measured run vs float64 oracle
@@ -869,6 +1070,8 @@ def main():
             out["cpu_baseline"] = cb
         out["gates_failed"] = gate_failures
         print(json.dumps(out), file=json_out, flush=True)
+    if grp is not None:
+        grp.close()
     if multi:
         dist.barrier()
         dist.destroy_process_group()

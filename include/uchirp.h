@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define UC_ABI_VERSION 4
+#define UC_ABI_VERSION 5
 
 /* pipeline variants */
 enum {
@@ -322,6 +322,107 @@ int uc_process_stream(uc_ctx* ctx, const void* samples, int dtype, size_t n_samp
  */
 int uc_dfsdm_sinc5(uc_ctx* ctx, const uint32_t* pdm_words, size_t n_words, int32_t* words_out,
                    void* hip_stream);
+
+/*
+ * ---- Frame sharding across the GPUs of a node (BASELINE.json configs[4]) -----------------------
+ *
+ * The reference's host is a C program (receiver/Src/main.c:311-587) that owns ONE sample stream; on a node of MI355X the
+ * frames of a batch are independent, so the frame index space is block-partitioned over the GPUs (tables replicated, no
+ * data-path collective) and the only exchange is the all-gather of the decoded symbol stream, 1 byte per frame, over
+ * RCCL / xGMI.  A uc_group is that arrangement behind this C-ABI: one uc_ctx per device, one RCCL communicator, one
+ * gather stream per device.  Two ways to build one:
+ *   uc_group_create        ONE process drives n_devices GPUs (ncclCommInitAll); rank r = devices[r]
+ *   uc_group_create_rank   one process per GPU (how bench.py is launched): rank `rank` of `world`, device cfg->device;
+ *                          rank 0 calls uc_group_unique_id and hands the 128 bytes to the others by any means it has
+ *                          (a file, MPI, torch.distributed's store ...)
+ * librccl.so.1 is loaded when the first group is created (dlopen: a process that never builds a group never loads it,
+ * and one that already holds an RCCL -- PyTorch's -- shares it); -ENOSYS if it cannot be found.
+ */
+typedef struct uc_group uc_group;
+#define UC_GROUP_ID_BYTES 128
+
+/* The contiguous block partition of n_units units of work (frames; overlap-save blocks) over `world` ranks: rank r owns
+ * [*first, *first + *count), sizes differ by at most one, the first n_units % world ranks get the extra unit.
+ * Pure arithmetic (no GPU needed). */
+int uc_partition(size_t n_units, int world, int rank, size_t* first, size_t* count);
+
+/* What a rank must HOLD of the sample buffer to process frames [first_frame, first_frame + count) of a batch whose frame i
+ * starts at element halo + i * stride_elems (halo = uc_iq_halo(): the FIR history in front of frame 0; stride_elems < n =
+ * the overlapping FIFO reads): elements [*first_elem, *first_elem + *n_elems) of the buffer.  Neighbouring shards overlap
+ * by n - stride_elems + halo elements -- read-only duplication of the input, never an exchange.  The rank's `frames`
+ * argument is then its copy's element `halo`.  stride_elems == 0 means n.  count == 0 gives an empty span. */
+int uc_frame_span(uint32_t n, size_t stride_elems, size_t halo, size_t first_frame, size_t count,
+                  size_t* first_elem, size_t* n_elems);
+
+/* UC_STREAM: the overlap-save BLOCKS of a stream are independent, so a stream of n_samples (its first `halo` samples are
+ * history, uc_stream_geometry) shards like frames do: rank processes samples [*first_sample, *first_sample + *n_shard) --
+ * the first `halo` of them are history it shares, read-only, with the previous rank -- and produces outputs
+ * [*first_out, *first_out + *n_out) of the whole stream.  Block boundaries coincide with the one-GPU run. */
+int uc_stream_span(const uc_ctx* ctx, size_t n_samples, int world, int rank,
+                   size_t* first_sample, size_t* n_shard, size_t* first_out, size_t* n_out);
+
+int uc_group_unique_id(void* id, size_t cap);  /* writes UC_GROUP_ID_BYTES bytes (ncclGetUniqueId) */
+/* cfg->device is ignored by uc_group_create (devices[] names them) and names THE device for uc_group_create_rank */
+int uc_group_create(const uc_config* cfg, const int32_t* devices, int n_devices, uc_group** out);
+int uc_group_create_rank(const uc_config* cfg, const void* id, int world, int rank, uc_group** out);
+void uc_group_destroy(uc_group* g);
+int uc_group_world(const uc_group* g);        /* ranks in the communicator */
+int uc_group_local_count(const uc_group* g);  /* devices this process drives (n_devices, or 1) */
+int uc_group_first_rank(const uc_group* g);   /* rank of local device 0 (local device l is rank first + l) */
+uc_ctx* uc_group_ctx(uc_group* g, int local); /* the context of local device l (tables, windows, uc_process_batch ...) */
+
+/*
+ * One step of the frame-sharded pipeline, for a batch of n_frames_total frames in all:
+ *   frames[l]    sample 0 of the FIRST frame rank (first + l) owns (uc_partition of n_frames_total; uc_frame_span says
+ *                what the rank must hold around it); device memory of that device, or host memory
+ *   gathered[l]  n_frames_total bytes, device memory of that device (or host): receives the WHOLE symbol stream.
+ * Every local device decodes its shard straight into its slice of gathered[l] on hip_streams[l] (NULL array or NULL
+ * entry: the group's own stream for that device), then the slices are all-gathered IN PLACE on the group's gather
+ * stream of that device (ncclAllGather when world divides n_frames_total, one grouped ncclBroadcast per rank otherwise),
+ * behind an event: the call returns at once and the gather of step k overlaps the kernels of the steps after it.
+ * Buffer hazards are the library's: a later step that writes a `gathered` buffer waits (on the device) for the gather
+ * that last used it, so rotating two or three buffers is all a caller does (three keep a persistent kernel from
+ * waiting for the previous gather's copy kernel: bench.py NBUF).  Read a gathered buffer after uc_group_synchronize(),
+ * or make a stream of yours wait for its gather with uc_group_wait_gather().
+ * Host pointers: the shard is staged through the context (synchronous copy-in), the stream is gathered in a device
+ * buffer of the group and copied out; the call then blocks until gathered[l] is complete.
+ * All ranks of the communicator must make the same sequence of calls (it is a collective).
+ */
+int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, size_t n_frames_total,
+                           size_t stride_elems, uint8_t* const* gathered, void* const* hip_streams);
+/* make hip_stream (of local device l) wait for the most recent gather into `gathered` (device pointer); no host wait */
+int uc_group_wait_gather(uc_group* g, int local, const uint8_t* gathered, void* hip_stream);
+/* wait for everything the group has enqueued on every local device */
+int uc_group_synchronize(uc_group* g);
+
+/* Plain-C hosts without the HIP headers: device memory by ordinal.  uc_device_copy: either side may be host or device
+ * memory (hipMemcpyDefault), synchronous. */
+int uc_device_count(void);
+int uc_device_malloc(int device, size_t bytes, void** out);
+int uc_device_free(int device, void* ptr);
+int uc_device_copy(void* dst, const void* src, size_t bytes);
+
+/*
+ * The shader clock the chip holds UNDER a kernel of this library, measured in the process that quotes it (diagnostic; costs
+ * nothing when off).  libuchirp.so carries every kernel twice: as it is, and with ONE s_memtime / s_memrealtime stamp pair
+ * per wave around the kernel's persistent loop.  After uc_clock_probe(ctx, 1) the launches of this context run the stamped
+ * twin (same grid, same work distribution, same results; a memset of the stamp buffer rides in front of each launch, so do
+ * not time with it); uc_clock_read() waits for the device and reduces the stamps of the LAST launch; uc_clock_probe(ctx, 0)
+ * goes back to the throughput build.  MI355X clocks down to its power cap under these kernels (1.9 - 2.4 GHz by kernel and
+ * data), so a VALU-issue roofline needs THIS number, not the 2.4 GHz of the data sheet.
+ */
+typedef struct uc_clock {
+  double   shader_ghz;   /* median over waves of (shader cycles of the wave's loop) / (the same span in the 100 MHz clock) */
+  double   wave_cycles;  /* median shader cycles a wave spent in its loop */
+  double   span_us;      /* first wave's start to last wave's end */
+  uint32_t waves;        /* waves that stamped */
+} uc_clock;
+int uc_clock_probe(uc_ctx* ctx, int on);
+int uc_clock_read(uc_ctx* ctx, uc_clock* out);
+/* the raw stamps of the last launch, four words per wave: shader cycles of the wave's loop (low 40 bits; bits 40..51 name
+ * the CU), the same span in 100 MHz ticks, absolute start tick, absolute end tick (0 0 0 0: the wave had nothing to do).
+ * Returns the number of words (also when words is NULL or cap_words too small: a size query), or < 0. */
+int uc_clock_stamps(uc_ctx* ctx, uint64_t* words, size_t cap_words);
 
 /* human-readable text of the last error on this thread ("" if none) */
 const char* uc_last_error(void);

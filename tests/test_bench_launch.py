@@ -97,6 +97,18 @@ def test_gpu_hello_leg_on_rccl_at_world_size_one():
     assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("configs[4]")
     assert d["transmissions_decoded_exactly"] == d["transmissions"] == 65536 // 117
     assert d["decoded_text_first"] == "Hello World!" and "rehearsal" not in d and d["gates_failed"] == []
+    # the gather is the C-ABI's: a uc_group of one rank per process, RCCL called from C (include/uchirp.h)
+    assert d["gather_backend"].startswith("uc_group_process_batch")
+
+
+@pytest.mark.gpu
+def test_gpu_single_process_group_line():
+    """`--gpus 1 --single-process`: one host process drives the devices through uc_group_create (ncclCommInitAll) -- the
+    shape of a C host (tests/c/host_multi.c); same workload, same JSON line."""
+    d = _one_line(_run(["--gpus", "1", "--single-process", "--frames", "65536", "--steps", "3", "--warmup", "1", "--ramp-ms", "20"], {}))
+    assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("configs[4]") and d["gates_failed"] == []
+    assert d["transmissions_decoded_exactly"] == d["transmissions"] == 65536 // 117 and d["decoded_text_first"] == "Hello World!"
+    assert d["gather_backend"].startswith("uc_group_process_batch in ONE process") and d["value"] > 0
 
 
 @pytest.mark.gpu
@@ -113,4 +125,10 @@ def test_gpu_default_line_carries_every_single_gpu_config():
     assert c3["graph_replay"]["value"] > 0 and c3["eager"]["value"] > 0 and c3["samples"] == 65536 * 2048
     h = d["hello_world1"]
     assert h["transmissions_decoded_exactly"] == h["transmissions"] == 65536 // 117 and h["gathered_equals_decoded"]
+    assert h["gather_backend"].startswith("uc_group_process_batch") and d["scale_anchor"]["value"] == h["value"]
+    # the clock of the VALU roof is measured in this run (the stamped twin of the kernel), the CU count is the device's
+    v = d["roofline"]["valu"]
+    assert v["clock_source"].startswith("uc_clock_read") and 0.8 < v["clock_GHz"] < 3.0 and v["num_cu"] >= 64
+    assert c2["baseband"]["roofline"]["valu"]["clock_source"].startswith("uc_clock_read")
+    assert c3["eager"]["roofline"]["valu"]["clock_source"].startswith("uc_clock_read")
     assert d["symbols_equal_oracle_head4096_clear"] == 1.0 and d["cpu_baseline"]["kind"] == "port"

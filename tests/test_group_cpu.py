@@ -1,0 +1,88 @@
+"""The partition / halo arithmetic of the multi-GPU leg (include/uchirp.h: uc_partition, uc_frame_span) on the CPU: pure
+integer work in libuchirp.so that needs no GPU.  The Python layer (uchirp/shard.py) keeps its own statement of the same
+partition for the torch.distributed path; the two must agree case by case, and shards cut with them must reproduce the
+frames of the whole batch."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import uchirp
+from uchirp import shard
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_contiguous_balanced_and_equals_shard_py():
+    rng = np.random.default_rng(3)
+    cases = [(0, 1), (0, 8), (1, 8), (7, 8), (8, 8), (9, 8), (1 << 20, 8), ((1 << 20) + 5, 8), (117 * 70, 3)]
+    cases += [(int(rng.integers(0, 1 << 33)), int(rng.integers(1, 65))) for _ in range(300)]
+    for n, world in cases:
+        nxt, sizes = 0, []
+        for r in range(world):
+            first, count = uchirp.partition(n, world, r)
+            assert (first, first + count) == shard.partition(n, world, r)
+            assert first == nxt
+            nxt = first + count
+            sizes.append(count)
+        assert nxt == n and max(sizes) - min(sizes) <= 1 and sorted(sizes, reverse=True) == sizes
+
+
+def test_partition_rejects_bad_ranks():
+    for world, rank in ((0, 0), (-1, 0), (4, 4), (4, -1)):
+        with pytest.raises(uchirp.UchirpError):
+            uchirp.partition(10, world, rank)
+
+
+@pytest.mark.parametrize("n,stride,halo", [(2048, 0, 0), (2048, 2048, 0), (2048, 256, 0), (2048, 512, 0), (1024, 1024, 26),
+                                           (2048, 1, 0), (2048, 300, 26)])
+def test_frame_span_shards_reproduce_the_frames_of_the_whole(n, stride, halo):
+    rng = np.random.default_rng(n + stride + halo)
+    st = stride or n
+    n_frames = 37
+    buf = rng.integers(-1000, 1000, size=halo + (n_frames - 1) * st + n).astype(np.int32)   # halo + frames
+    for world in (1, 2, 3, 8, 40):
+        covered = 0
+        for r in range(world):
+            first, count = uchirp.partition(n_frames, world, r)
+            e0, ne = uchirp.frame_span(n, stride, halo, first, count)
+            lo, hi = shard.partition(n_frames, world, r)
+            s0, s1 = shard.frame_span(lo, hi, n, st, halo)        # relative to sample 0 of frame 0
+            if count == 0:
+                assert (e0, ne) == (0, 0) and (s0, s1) == (0, 0)
+                continue
+            assert (e0, e0 + ne) == (s0 + halo, s1 + halo)
+            mine = buf[e0:e0 + ne]                                  # what the rank holds; its `frames` argument is mine[halo:]
+            for f in range(count):
+                g = first + f
+                assert np.array_equal(mine[f * st: f * st + halo + n], buf[g * st: g * st + halo + n])
+            covered += count
+        assert covered == n_frames
+
+
+def test_group_create_without_a_gpu_reports_enodev_and_never_computes():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    with pytest.raises(uchirp.UchirpError) as ei:
+        uchirp.Group(uchirp.RX_REAL, devices=[0])
+    assert "no HIP device" in str(ei.value) or "librccl" in str(ei.value)
+    L = uchirp.lib()
+    assert L.uc_device_count() == 0
+
+
+def test_c_host_of_the_group_api_is_c99_and_runs_without_a_gpu(tmp_path):
+    """tests/c/host_multi.c: gcc -std=c99 -pedantic -Werror against include/uchirp.h, linked with libuchirp.so only (no HIP
+    header, no RCCL at link time).  Without a GPU it prints uc_group_create's error and exits 0."""
+    exe = str(tmp_path / "host_multi")
+    libdir = os.path.join(ROOT, "ultrasonic-communication_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "host_multi.c"), "-o", exe, "-L" + libdir, "-luchirp", "-lm",
+                           "-Wl,-rpath," + libdir])
+    import torch
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "uc_group_create: -19" in out.stdout

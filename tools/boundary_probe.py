@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
-"""What a kernel boundary costs on this stack: two back-to-back launches of the same kernel on one stream, each with
+"""HISTORICAL (round 3): needs that round's separate diagnostic build libuchirp_clock.so with one stamp buffer per launch
+(git show 1a04a99:ultrasonic-communication_amd/Makefile); since round 4 the stamped twin ships inside libuchirp.so
+(uc_clock_probe / uc_clock_stamps, one buffer per context).  Its result is profiles/r03_boundary_tail.txt.
+What a kernel boundary costs on this stack: two back-to-back launches of the same kernel on one stream, each with
 its own stamp buffer (clock-stamp build): gap = first wave start of launch B - last wave end of launch A, in the
 GPU's own 100 MHz s_memrealtime domain; beside it the launch period of a long back-to-back run.
 Usage: python tools/boundary_probe.py [target=band_rx_real_f32] [frames_log2=20]"""

@@ -1,8 +1,7 @@
 #!/usr/bin/env python3
-"""Wave start/end skew of sinc5_kernel (diagnostic build libuchirp_clock.so).  Usage: python tools/cic_skew_probe.py [words_log2=28]"""
+"""Wave start/end skew of sinc5_kernel (the clock-stamped twin inside libuchirp.so, uc_clock_probe).  Usage: python tools/cic_skew_probe.py [words_log2=28]"""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ["UCHIRP_LIB"] = os.path.join(ROOT, "ultrasonic-communication_amd", "libuchirp_clock.so")
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
 import numpy as np, torch, uchirp
 lg = int(sys.argv[1]) if len(sys.argv) > 1 else 28
@@ -12,14 +11,13 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 w = torch.randint(-(1 << 31), (1 << 31) - 1, (n,), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
 out = torch.empty(n - 4, dtype=torch.int32, device=dev)
 e = uchirp.Engine(uchirp.RX_REAL)
-dbg = torch.zeros(8192 * 4, dtype=torch.int64, device=dev)
-os.environ["UC_DEBUG_PTR"] = str(dbg.data_ptr())
+e.clock_probe(True)
 for _ in range(200):
     e.dfsdm(w, out=out)
 torch.cuda.synchronize()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(); e.dfsdm(w, out=out); b.record(); torch.cuda.synchronize()
-raw = dbg.cpu().numpy().reshape(-1, 4)
+raw = e.clock_stamps().astype(np.int64)
 nw = int((raw[:, 1] > 0).sum())
 blk = np.arange(nw) // 16
 life_all = raw[:nw, 1] / 100.0

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The clock the chip holds under band_kernel (MI355X_MICROARCH.md, 'DVFS give-back' item 6): diagnostic build
-libuchirp_clock.so (make -C ultrasonic-communication_amd libuchirp_clock.so: ONE s_memtime / s_memrealtime stamp
+"""The clock the chip holds under band_kernel (MI355X_MICROARCH.md, 'DVFS give-back' item 6): the clock-stamped twin
+inside libuchirp.so (uc_clock_probe: ONE s_memtime / s_memrealtime stamp
 pair around the persistent loop), >= 2 s of back-to-back launches on random data, then
 clock = d(s_memtime) / d(s_memrealtime) x 100 MHz of the LAST launch, median over workgroups.
 Usage: python tools/clock_probe.py [frames_log2=20] [seconds=2.5] [zeros]   env UC_VARIANT, UC_BAND_WAVES"""
@@ -10,7 +10,6 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-os.environ.setdefault("UCHIRP_LIB", os.path.join(ROOT, "ultrasonic-communication_amd", "libuchirp_clock.so"))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
 import numpy as np
@@ -29,8 +28,7 @@ if zeros:
 sym = torch.empty(nf, dtype=torch.uint8, device=dev)
 variant = int(os.environ.get("UC_VARIANT", "0"))
 e = uchirp.Engine(variant, mag_mean=1000.0)
-dbg = torch.zeros(8192 * 2 * 4, dtype=torch.int64, device=dev)
-os.environ["UC_DEBUG_PTR"] = str(dbg.data_ptr())
+e.clock_probe(True)
 stream = torch.cuda.current_stream(dev)
 want_sym = variant in (0, 1)
 st = None if want_sym else torch.empty((nf, e.spf, 8), dtype=torch.float32, device=dev)
@@ -56,7 +54,7 @@ a.record(stream)
 launch()
 b.record(stream)
 torch.cuda.synchronize()
-d = dbg.cpu().numpy().reshape(-1, 4)
+d = e.clock_stamps().astype(np.int64)
 d = d[d[:, 1] > 0]
 d[:, 0] &= (1 << 40) - 1                      # (bits 40..51 of the cycle word name the CU: tools/run_target.py)
 d = d.astype(np.float64)

@@ -9,7 +9,6 @@ targets="${2:-band_rx_real_f32 band_sync_cplx_f32 band_dechirp_down_f32 compress
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out="gpurun_out/pmcall_$tag"
 mkdir -p "$out"
-make -C ultrasonic-communication_amd libuchirp_clock.so > /dev/null 2>&1
 SQ_A="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
 SQ_B="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM"
 rocprofv3 -L > "$out/counter_list.txt" 2>&1

@@ -8,7 +8,6 @@ tag="${1:-rXX}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out=gpurun_out/pmcr_$tag
 rm -rf $out && mkdir -p $out
-make -C ultrasonic-communication_amd libuchirp_clock.so > /dev/null 2>&1
 if [ -z "$PMC_NO_CLOCK" ]; then
 python3 tools/clock_probe.py 20 2.5 > $out/clock_random.json 2> $out/clock.err && cat $out/clock_random.json
 python3 tools/clock_probe.py 20 2.5 zeros > $out/clock_zeros.json 2>> $out/clock.err && cat $out/clock_zeros.json

@@ -2,7 +2,7 @@
 """One kernel of the library on its own workload, as a profiling target and as the clock probe of every kernel.
 
   python tools/run_target.py <target> [--frames-log2 19] [--iters 3]            launches only (rocprofv3 passes)
-  python tools/run_target.py <target> --clock [--seconds 2.5] [--zeros]         diagnostic build libuchirp_clock.so:
+  python tools/run_target.py <target> --clock [--seconds 2.5] [--zeros]         the clock-stamped twin inside libuchirp.so (uc_clock_probe):
         >= `seconds` of back-to-back launches, then the in-kernel clock d(s_memtime) / d(s_memrealtime) x 100 MHz of
         the last launch (median over waves), loop cycles, start / end skew of the grid
   --info prints {"target", "kernel", "units", "unit", "alg_bytes_per_unit"} of the launch and exits (no GPU work)
@@ -27,8 +27,6 @@ ap.add_argument("--seconds", type=float, default=2.5)
 ap.add_argument("--zeros", action="store_true")
 ap.add_argument("--info", action="store_true")
 args = ap.parse_args()
-if args.clock:
-    os.environ.setdefault("UCHIRP_LIB", os.path.join(ROOT, "ultrasonic-communication_amd", "libuchirp_clock.so"))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "ultrasonic-communication_amd")]
 
 T = args.target
@@ -59,9 +57,6 @@ from uchirp import synth  # noqa: E402
 
 dev = torch.device("cuda:0")
 stream = torch.cuda.current_stream(dev)
-dbg = torch.zeros(16384 * 4 * 4, dtype=torch.int64, device=dev)
-if args.clock:
-    os.environ["UC_DEBUG_PTR"] = str(dbg.data_ptr())
 
 if T.startswith("iq"):
     n = 2048 if T.startswith("iq2048") else 1024
@@ -112,6 +107,8 @@ else:
             e.process(frames, want_symbols=want_sym, want_stats=not want_sym, symbols_out=sym, stats_out=st,
                       stream=stream.cuda_stream)
 
+if args.clock:
+    e.clock_probe(True)
 if not args.clock:
     for _ in range(args.iters):
         launch()
@@ -129,13 +126,12 @@ while time.perf_counter() - t0 < args.seconds:
     torch.cuda.synchronize()
     n_l += 50
 wall = (time.perf_counter() - t0) / n_l
-dbg.zero_()
 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 a.record(stream)
 launch()
 b.record(stream)
 torch.cuda.synchronize()
-raw = dbg.cpu().numpy().reshape(-1, 4)
+raw = e.clock_stamps().astype(np.int64)
 raw = raw[raw[:, 1] > 0]
 cu_key = (raw[:, 0] >> 40) & 0xfff            # XCC_ID << 8 | HW_ID[15:8]: the CU that ran the wave
 d = raw.astype(np.float64)

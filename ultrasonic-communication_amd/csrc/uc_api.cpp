@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -72,6 +73,10 @@ bool is_device_ptr(const void* p) {
 }
 
 }  // namespace
+
+namespace uc {
+void set_error(const char* msg) { g_err = msg ? msg : ""; }  // (uc_group.cpp reports through the same uc_last_error())
+}
 
 // Hand-out counters of the dynamically dealt launches (two 32-bit words each -- next ticket, workgroups gone -- every
 // pair in its own 128-byte line; zeroed once at uc_create, left at zero by every launch's last workgroup):
@@ -140,6 +145,12 @@ struct uc_ctx {
   hipEvent_t switch_ev = nullptr;
   bool wait_switch[kWorkSlots] = {};    // slot i was last used before the switch: free once switch_ev has completed
   bool slot_used[kWorkSlots] = {};
+  // uc_clock_probe(): launches run the clock-stamped twin of their kernel (uc_kernels.hpp: uc::clk) and leave four words
+  // per wave here; clock_waves = the waves of the LAST launch
+  bool clock_probe = false;
+  DevBuf s_clock;
+  size_t clock_waves = 0;
+  int clk_cic_blocks = 0;
 };
 
 extern "C" {
@@ -431,6 +442,7 @@ void uc_destroy(uc_ctx* c) {
   c->s_spec.release();
   c->s_rx_pad.release();
   c->s_rx_mag.release();
+  c->s_clock.release();
   delete c;
 }
 
@@ -557,6 +569,21 @@ static int work_counter_launched(uc_ctx* c, hipStream_t stream, int slot) {
   return 0;
 }
 
+// uc_clock_probe: where the stamps of the launch about to be made go (nullptr when the probe is off): `waves` x 4 words,
+// zeroed on the launch stream in front of the kernel (a wave that leaves before the loop writes nothing)
+static int clock_buffer(uc_ctx* c, size_t grid, int waves_per_wg, hipStream_t stream, unsigned long long** out) {
+  *out = nullptr;
+  if (!c->clock_probe) return 0;
+  const size_t waves = grid * (size_t)waves_per_wg;
+  const int rc = c->s_clock.ensure(waves * 4 * sizeof(unsigned long long));
+  if (rc) return rc;
+  const hipError_t e = hipMemsetAsync(c->s_clock.p, 0, waves * 4 * sizeof(unsigned long long), stream);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(clock stamps)");
+  c->clock_waves = waves;
+  *out = (unsigned long long*)c->s_clock.p;
+  return 0;
+}
+
 static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                               const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream,
                               bool mapped = false, float* d_spectrum = nullptr);
@@ -653,9 +680,6 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
       ip.ifs = (uint32_t)(int32_t)c->cfg.fs;
       ip.snr_threshold = c->cfg.snr_threshold;
     }
-#if defined(UC_CLOCKSTAMP)
-    if (const char* d = getenv("UC_DEBUG_PTR")) ip.debug = (unsigned long long*)strtoull(d, nullptr, 0);
-#endif
     ip.fir_mfma = (n == 1024 && c->iq_fir_mfma) ? c->d_aux : nullptr;
     ip.stagger = c->iq_stagger;
     int& iq_bpc = c->iq_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
@@ -682,7 +706,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
         if (wrc) return wrc;
       }
     }
-    int lrc = uc::launch_iq(dtype, ip, (int)grid, stream, (int)n);
+    if (int crc = clock_buffer(c, grid, n == 1024 ? 1 : 2, stream, &ip.debug)) return crc;
+    int lrc = (c->clock_probe ? uc::clk::launch_iq : uc::launch_iq)(dtype, ip, (int)grid, stream, (int)n);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "iq kernel launch");
     if (int erc = work_counter_launched(c, stream, wslot)) return erc;
     goto copy_back;
@@ -700,9 +725,6 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     fp.symbols = d_sym;
     fp.stats = d_stats;
     fp.mag_mean_scalar = c->cfg.mag_mean;
-#if defined(UC_CLOCKSTAMP)
-    if (const char* d = getenv("UC_DEBUG_PTR")) fp.debug = (unsigned long long*)strtoull(d, nullptr, 0);
-#endif
     int& full_bpc = c->full_blocks_per_cu[dtype == UC_DTYPE_I32 ? 0 : 1];
     if (full_bpc == 0) full_bpc = uc::compress_max_blocks_per_cu(dtype);
     size_t grid = (size_t)c->num_cu * (size_t)full_bpc;
@@ -722,7 +744,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
         if (grid > nchunks) grid = nchunks;
       }
     }
-    int lrc = uc::launch_compress(dtype, fp, (int)grid, stream);
+    if (int crc = clock_buffer(c, grid, 2, stream, &fp.debug)) return crc;
+    int lrc = (c->clock_probe ? uc::clk::launch_compress : uc::launch_compress)(dtype, fp, (int)grid, stream);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "compress kernel launch");
     if (int erc = work_counter_launched(c, stream, wslot)) return erc;
     goto copy_back;
@@ -748,8 +771,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
   p.ifs = (uint32_t)(int32_t)c->cfg.fs;
   p.true_dc = (c->cfg.flags & UC_FLAG_TRUE_DC) ? 1u : 0u;
   p.debug = nullptr;
-#if defined(UC_STAMPS) || defined(UC_CLOCKSTAMP)
-  // diagnostic builds only (libuchirp_stamps.so / libuchirp_clock.so): where the in-kernel stamps go
+#if defined(UC_STAMPS)
+  // diagnostic build only (libuchirp_stamps.so): where the per-phase stamps go
   if (const char* d = getenv("UC_DEBUG_PTR")) p.debug = (unsigned long long*)strtoull(d, nullptr, 0);
 #endif
   const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
@@ -787,7 +810,9 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
     if (wrc) return wrc;
   }
-  int lrc = uc::launch_band(mode, dtype, waves, p, (int)grid, stream);
+  if (c->clock_probe)
+    if (int crc = clock_buffer(c, grid, 2, stream, &p.debug)) return crc;
+  int lrc = (c->clock_probe ? uc::clk::launch_band : uc::launch_band)(mode, dtype, waves, p, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
   if (int erc = work_counter_launched(c, stream, wslot)) return erc;
   }
@@ -806,6 +831,57 @@ copy_back:
     if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
   }
   return 0;
+}
+
+int uc_clock_probe(uc_ctx* c, int on) {
+  if (!c) return fail(-EINVAL, "uc_clock_probe: NULL ctx");
+  c->clock_probe = on != 0;
+  c->clock_waves = 0;
+  return 0;
+}
+
+int uc_clock_read(uc_ctx* c, uc_clock* out) {
+  if (!c || !out) return fail(-EINVAL, "uc_clock_read: NULL argument");
+  memset(out, 0, sizeof(*out));
+  if (!c->clock_probe || c->clock_waves == 0) return fail(-ENODATA, "uc_clock_read: no launch since uc_clock_probe(ctx, 1)");
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
+  std::vector<unsigned long long> w(c->clock_waves * 4);
+  e = hipMemcpy(w.data(), c->s_clock.p, w.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(clock stamps)");
+  // per wave: [0] shader cycles of its loop (low 40 bits; the bits above name the CU), [1] the same span in ticks of the
+  // constant 100 MHz clock, [2] / [3] absolute start / end ticks
+  std::vector<double> ghz, cyc;
+  unsigned long long t0 = ~0ull, t1 = 0;
+  for (size_t i = 0; i < c->clock_waves; i++) {
+    const unsigned long long cycles = w[4 * i] & 0xffffffffffull, ticks = w[4 * i + 1];
+    if (ticks == 0) continue;  // a wave that had nothing to do
+    ghz.push_back((double)cycles / (double)ticks * 0.1);
+    cyc.push_back((double)cycles);
+    if (w[4 * i + 2] < t0) t0 = w[4 * i + 2];
+    if (w[4 * i + 3] > t1) t1 = w[4 * i + 3];
+  }
+  if (ghz.empty()) return fail(-ENODATA, "uc_clock_read: the last launch stamped no wave");
+  std::sort(ghz.begin(), ghz.end());
+  std::sort(cyc.begin(), cyc.end());
+  out->shader_ghz = ghz[ghz.size() / 2];
+  out->wave_cycles = cyc[cyc.size() / 2];
+  out->span_us = (double)(t1 - t0) * 0.01;
+  out->waves = (uint32_t)ghz.size();
+  return 0;
+}
+
+int uc_clock_stamps(uc_ctx* c, uint64_t* words, size_t cap_words) {
+  if (!c) return fail(-EINVAL, "uc_clock_stamps: NULL ctx");
+  if (!c->clock_probe || c->clock_waves == 0) return fail(-ENODATA, "uc_clock_stamps: no launch since uc_clock_probe(ctx, 1)");
+  const size_t nw = c->clock_waves * 4;
+  if (!words || cap_words < nw) return (int)nw;  // (size query)
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e == hipSuccess) e = hipMemcpy(words, c->s_clock.p, nw * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "uc_clock_stamps");
+  return (int)nw;
 }
 
 int uc_set_table(uc_ctx* c, int table_id, const float* data, size_t count) {
@@ -911,9 +987,6 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   cp.t1 = c->d_cic1;
   cp.ctr = nullptr;
   cp.debug = nullptr;
-#if defined(UC_CLOCKSTAMP)
-  if (const char* d = getenv("UC_DEBUG_PTR")) cp.debug = (unsigned long long*)strtoull(d, nullptr, 0);
-#endif
   if (c->cic_blocks_per_cu == 0) {
     c->cic_blocks_per_cu = uc::sinc5_max_blocks_per_cu();
     if (c->cic_blocks_per_cu <= 0) {
@@ -943,7 +1016,12 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
     e = hipMemsetAsync(cp.ctr, 0, bytes, stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(sinc5 tickets)");
   }
-  int lrc = uc::launch_sinc5(cp, (int)grid, stream);
+  if (c->clock_probe) {
+    if (c->clk_cic_blocks == 0) c->clk_cic_blocks = uc::clk::sinc5_max_blocks_per_cu();  // (the twin needs the same LDS opt-in)
+    if (c->clk_cic_blocks <= 0) return fail(-ENOMEM, "uc_dfsdm_sinc5: the clock-stamped kernel's LDS tables do not fit");
+    if (int crc = clock_buffer(c, grid, 4, stream, &cp.debug)) return crc;
+  }
+  int lrc = (c->clock_probe ? uc::clk::launch_sinc5 : uc::launch_sinc5)(cp, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "sinc5 kernel launch");
   if (host_out) {
     e = hipMemcpyAsync(words_out, d_out, n_out * 4, hipMemcpyDeviceToHost, stream);
@@ -964,6 +1042,27 @@ int uc_stream_geometry(const uc_ctx* c, size_t n_samples, size_t* halo, size_t* 
   if (n_out) *n_out = no;
   if (n_blocks) *n_blocks = (no + hp - 1) / hp;
   if (hop) *hop = hp;
+  return 0;
+}
+
+int uc_stream_span(const uc_ctx* c, size_t n_samples, int world, int rank, size_t* first_sample, size_t* n_shard,
+                   size_t* first_out, size_t* n_out) {
+  if (!c) return fail(-EINVAL, "uc_stream_span: NULL ctx");
+  if (c->cfg.variant != UC_STREAM) return fail(-EINVAL, "uc_stream_span: the context is not UC_STREAM");
+  const size_t h = c->stab.halo, hp = c->stab.hop, D = c->stab.decim;
+  const size_t no = n_samples > h ? (n_samples - h) / D : 0;
+  const size_t nb = (no + hp - 1) / hp;
+  size_t b0 = 0, bc = 0;
+  const int rc = uc_partition(nb, world, rank, &b0, &bc);  // whole overlap-save blocks: boundaries as in the one-GPU run
+  if (rc) return rc;
+  size_t q0 = b0 * hp, q1 = (b0 + bc) * hp;
+  if (q0 > no) q0 = no;
+  if (q1 > no) q1 = no;
+  const bool empty = q1 <= q0;
+  if (first_sample) *first_sample = empty ? 0 : q0 * D;
+  if (n_shard) *n_shard = empty ? 0 : h + (q1 - q0) * D;
+  if (first_out) *first_out = q0;
+  if (n_out) *n_out = empty ? 0 : q1 - q0;
   return 0;
 }
 
@@ -1019,9 +1118,6 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
   sp.tw = c->d_tw;
   sp.compressed = d_comp;
   sp.peaks = d_peaks;
-#if defined(UC_CLOCKSTAMP)
-  if (const char* d = getenv("UC_DEBUG_PTR")) sp.debug = (unsigned long long*)strtoull(d, nullptr, 0);
-#endif
   for (int k = 0; k < 2 * uc::kFirTapsDev; k++) sp.ctap[k] = c->stab.ctap[k];
   const int D = (int)c->stab.decim;
   for (int sub = 0; sub < D / 2; sub++) {
@@ -1047,7 +1143,8 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
       if (grid > nchunks) grid = nchunks;
     }
   }
-  int lrc = uc::launch_stream(dtype, D, sp, (int)grid, stream);
+  if (int crc = clock_buffer(c, grid, 2, stream, &sp.debug)) return crc;
+  int lrc = (c->clock_probe ? uc::clk::launch_stream : uc::launch_stream)(dtype, D, sp, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "stream kernel launch");
   if (int erc = work_counter_launched(c, stream, wslot)) return erc;
 

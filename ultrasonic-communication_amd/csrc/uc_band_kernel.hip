@@ -976,6 +976,7 @@ static int occupancy_one() {
 
 }  // namespace
 
+UC_LAUNCH_BEGIN
 #define UC_DISPATCH(FN, ...)                                                              \
   do {                                                                                    \
     if (spec && !wide) { /* uc_window_spectrum on the default two-round build, at each mode's default occupancy */ \
@@ -1035,5 +1036,7 @@ int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, h
 int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec) {
   UC_DISPATCH(occupancy_one);
 }
+
+UC_LAUNCH_END
 
 }  // namespace uc

@@ -240,6 +240,7 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
 
 }  // namespace
 
+UC_LAUNCH_BEGIN
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream) {
   if (grid <= 0 || p.n_words <= 4) return (int)hipSuccess;
   hipLaunchKernelGGL(sinc5_kernel, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
@@ -258,5 +259,7 @@ int sinc5_max_blocks_per_cu() {
 }
 
 int sinc5_tile_outputs() { return kTileOut * (TC / 64); }
+
+UC_LAUNCH_END
 
 }  // namespace uc

@@ -285,6 +285,7 @@ __global__ __launch_bounds__(T, UC_COMPRESS_WAVES) void compress_kernel(const Fu
 
 }  // namespace
 
+UC_LAUNCH_BEGIN
 int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream) {
   if (grid <= 0) return (int)hipSuccess;
   if (dtype == UC_DTYPE_I32)
@@ -302,5 +303,7 @@ int compress_max_blocks_per_cu(int dtype) {
   if (e != hipSuccess || nb <= 0) nb = 4;
   return nb;
 }
+
+UC_LAUNCH_END
 
 }  // namespace uc

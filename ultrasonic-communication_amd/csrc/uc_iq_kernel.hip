@@ -950,6 +950,7 @@ int occ(F kernel, int threads, int fallback) {
 
 }  // namespace
 
+UC_LAUNCH_BEGIN
 #define UC_IQ_DISPATCH(CALL1024, CALL2048)                                  \
   do {                                                                      \
     const bool i32 = dtype == UC_DTYPE_I32;                                 \
@@ -990,5 +991,7 @@ int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma, int narro
 #undef UC_O2048
   return nb;
 }
+
+UC_LAUNCH_END
 
 }  // namespace uc

@@ -143,4 +143,31 @@ int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
 int sinc5_max_blocks_per_cu();
 int sinc5_tile_outputs();
 
+// ---- the clock-stamped twin of every kernel (diagnostic, shipped, costs nothing when off) ----------------------------
+// Every .hip file is compiled TWICE into libuchirp.so: once as it is, once with -DUC_CLOCKSTAMP (Makefile: csrc/*.clk.o),
+// which adds ONE s_memtime / s_memrealtime stamp pair per wave around the kernel's persistent loop (uc_dev.hpp:
+// UC_CLOCK_BEGIN / UC_CLOCK_END; four words per wave go to `debug`).  The second build's launchers live in uc::clk; the
+// kernels themselves have internal linkage in both.  uc_clock_probe() (include/uchirp.h) makes a context launch the twin:
+// the shader clock the chip holds UNDER a kernel, measured in the run that quotes it, not taken from another box.
+#ifdef UC_CLOCKSTAMP
+#define UC_LAUNCH_BEGIN namespace clk {
+#define UC_LAUNCH_END }
+#else
+#define UC_LAUNCH_BEGIN
+#define UC_LAUNCH_END
+#endif
+namespace clk {
+int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false);
+int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream);
+int compress_max_blocks_per_cu(int dtype);
+int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
+int iq_max_blocks_per_cu(int dtype, int n, int baseband, int fir_mfma, int narrow);
+int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream);
+int stream_max_blocks_per_cu(int dtype, int decim);
+int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
+int sinc5_max_blocks_per_cu();
+int sinc5_tile_outputs();
+}  // namespace clk
+
 }  // namespace uc

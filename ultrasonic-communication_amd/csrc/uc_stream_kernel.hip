@@ -355,6 +355,7 @@ int occupancy_one() {
 
 }  // namespace
 
+UC_LAUNCH_BEGIN
 int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStream_t stream) {
   if (grid <= 0) return (int)hipSuccess;
   const bool i32 = dtype == UC_DTYPE_I32;
@@ -375,5 +376,7 @@ int stream_max_blocks_per_cu(int dtype, int decim) {
     default: return 4;
   }
 }
+
+UC_LAUNCH_END
 
 }  // namespace uc

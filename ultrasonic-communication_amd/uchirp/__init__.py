@@ -31,7 +31,12 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_process_frame", "uc_process_batch", "uc_stats_per_frame", "uc_iq_halo",
            "uc_get_table", "uc_get_windows", "uc_idx2freq", "uc_receive_stream", "uc_receive_stream_isr",
            "uc_stream_geometry", "uc_process_stream", "uc_dfsdm_sinc5", "uc_set_table", "uc_window_bins",
-           "uc_window_spectrum"]
+           "uc_window_spectrum",
+           "uc_partition", "uc_frame_span", "uc_stream_span", "uc_group_unique_id", "uc_group_create", "uc_group_create_rank",
+           "uc_group_destroy", "uc_group_world", "uc_group_local_count", "uc_group_first_rank", "uc_group_ctx",
+           "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
+           "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps"]
+GROUP_ID_BYTES = 128
 
 
 class Config(C.Structure):
@@ -40,6 +45,11 @@ class Config(C.Structure):
                 ("time_frame", C.c_float), ("phase_deg", C.c_float), ("snr_threshold", C.c_float),
                 ("mag_mean", C.c_float), ("carrier", C.c_float), ("variant", C.c_int32),
                 ("device", C.c_int32), ("flags", C.c_uint32), ("decim", C.c_uint32)]
+
+
+class Clock(C.Structure):
+    """struct uc_clock (include/uchirp.h)."""
+    _fields_ = [("shader_ghz", C.c_double), ("wave_cycles", C.c_double), ("span_us", C.c_double), ("waves", C.c_uint32)]
 
 
 RX_EVENT_DTYPE = np.dtype([("block", "<u4"), ("sync_position", "<u4"), ("state_before", "u1"), ("state_after", "u1"),
@@ -110,6 +120,28 @@ def lib():
     L.uc_set_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.uc_window_bins.argtypes = [C.c_void_p]
     L.uc_window_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
+    SZP = C.POINTER(C.c_size_t)
+    L.uc_partition.argtypes = [C.c_size_t, C.c_int, C.c_int, SZP, SZP]
+    L.uc_frame_span.argtypes = [C.c_uint32, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, SZP, SZP]
+    L.uc_stream_span.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int, SZP, SZP, SZP, SZP]
+    L.uc_group_unique_id.argtypes = [C.c_void_p, C.c_size_t]
+    L.uc_group_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_void_p)]
+    L.uc_group_create_rank.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+    L.uc_group_destroy.argtypes = [C.c_void_p]
+    L.uc_group_destroy.restype = None
+    for fn in (L.uc_group_world, L.uc_group_local_count, L.uc_group_first_rank, L.uc_group_synchronize):
+        fn.argtypes = [C.c_void_p]
+    L.uc_group_ctx.argtypes = [C.c_void_p, C.c_int]
+    L.uc_group_ctx.restype = C.c_void_p
+    L.uc_group_process_batch.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_size_t, C.c_size_t,
+                                         C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    L.uc_group_wait_gather.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.uc_device_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.uc_device_free.argtypes = [C.c_int, C.c_void_p]
+    L.uc_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.uc_clock_probe.argtypes = [C.c_void_p, C.c_int]
+    L.uc_clock_read.argtypes = [C.c_void_p, C.POINTER(Clock)]
+    L.uc_clock_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     _lib = L
     return L
 
@@ -160,6 +192,23 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def clock_probe(self, on=True):
+        """uc_clock_probe: the following launches run the clock-stamped twin of their kernel (never time with it on)."""
+        _check(lib().uc_clock_probe(self._h, 1 if on else 0), "uc_clock_probe")
+
+    def clock_read(self):
+        """uc_clock_read -> dict(shader_ghz, wave_cycles, span_us, waves) of the last launch (waits for the device)."""
+        c = Clock()
+        _check(lib().uc_clock_read(self._h, C.byref(c)), "uc_clock_read")
+        return {"shader_ghz": c.shader_ghz, "wave_cycles": c.wave_cycles, "span_us": c.span_us, "waves": int(c.waves)}
+
+    def clock_stamps(self):
+        """uc_clock_stamps -> uint64 [waves, 4]: cycles (| CU id << 40), 100 MHz ticks, start tick, end tick of every wave."""
+        nw = _check(lib().uc_clock_stamps(self._h, None, 0), "uc_clock_stamps")
+        a = np.zeros(nw, np.uint64)
+        _check(lib().uc_clock_stamps(self._h, a.ctypes.data_as(C.c_void_p), nw), "uc_clock_stamps")
+        return a.reshape(-1, 4)
 
     def table(self, tid):
         buf = np.zeros(4 * self.n, np.float32)
@@ -421,3 +470,91 @@ def stats_from_tensor(t):
     """View a (n_frames, spf, 8) float32 torch stats tensor as a numpy STATS_DTYPE array."""
     a = t.detach().cpu().numpy()
     return a.view(STATS_DTYPE).reshape(a.shape[0], a.shape[1])
+
+
+def partition(n_units, world, rank):
+    """uc_partition -> (first, count): the contiguous block partition (pure arithmetic, no GPU)."""
+    a, b = C.c_size_t(), C.c_size_t()
+    _check(lib().uc_partition(int(n_units), int(world), int(rank), C.byref(a), C.byref(b)), "uc_partition")
+    return a.value, b.value
+
+
+def frame_span(n, stride, halo, first_frame, count):
+    """uc_frame_span -> (first_elem, n_elems) of the sample buffer a shard must hold."""
+    a, b = C.c_size_t(), C.c_size_t()
+    _check(lib().uc_frame_span(int(n), int(stride), int(halo), int(first_frame), int(count), C.byref(a), C.byref(b)),
+           "uc_frame_span")
+    return a.value, b.value
+
+
+class Group:
+    """One uc_group (include/uchirp.h): the frame-sharded multi-GPU leg -- a uc_ctx per device, an RCCL communicator called
+    from C, the symbol stream all-gathered in place on a side stream.
+      Group(variant, devices=[0, 1, ...])                         one process drives several GPUs
+      Group(variant, world=W, rank=r, unique_id=id, device=d)     one process per GPU; id = Group.unique_id() of rank 0"""
+
+    def __init__(self, variant=RX_REAL, devices=None, world=None, rank=None, unique_id=None, device=0, **over):
+        h = C.c_void_p()
+        if devices is not None:
+            self.cfg = default_config(variant, device=int(devices[0]), **over)
+            arr = (C.c_int32 * len(devices))(*[int(d) for d in devices])
+            _check(lib().uc_group_create(C.byref(self.cfg), arr, len(devices), C.byref(h)), "uc_group_create")
+        else:
+            if unique_id is None or len(unique_id) != GROUP_ID_BYTES:
+                raise ValueError("unique_id must be the %d bytes of Group.unique_id()" % GROUP_ID_BYTES)
+            self.cfg = default_config(variant, device=int(device), **over)
+            _check(lib().uc_group_create_rank(C.byref(self.cfg), C.c_char_p(bytes(unique_id)), int(world), int(rank),
+                                              C.byref(h)), "uc_group_create_rank")
+        self._h = h
+        self.world = lib().uc_group_world(h)
+        self.n_local = lib().uc_group_local_count(h)
+        self.first_rank = lib().uc_group_first_rank(h)
+        self.n = int(self.cfg.n)
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(GROUP_ID_BYTES)
+        _check(lib().uc_group_unique_id(buf, GROUP_ID_BYTES), "uc_group_unique_id")
+        return buf.raw
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uc_group_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _ptr(x):
+        if x is None:
+            return None
+        if _is_torch(x):
+            return x.data_ptr()
+        if isinstance(x, np.ndarray):
+            return x.ctypes.data
+        return int(x)
+
+    def process(self, frames, n_frames_total, gathered, stride=0, streams=None, dtype=DTYPE_F32):
+        """uc_group_process_batch.  frames / gathered: one tensor / array / address per LOCAL device (a shard's first
+        frame; the n_frames_total-byte buffer for the whole symbol stream); streams: HIP stream handles or None."""
+        nl = self.n_local
+        if len(frames) != nl or len(gathered) != nl:
+            raise ValueError("one frames / gathered entry per local device (%d)" % nl)
+        fa = (C.c_void_p * nl)(*[self._ptr(f) for f in frames])
+        ga = (C.c_void_p * nl)(*[self._ptr(x) for x in gathered])
+        sa = None
+        if streams is not None:
+            sa = (C.c_void_p * nl)(*[int(s) if s else None for s in streams])
+        _check(lib().uc_group_process_batch(self._h, fa, dtype, int(n_frames_total), int(stride), ga, sa),
+               "uc_group_process_batch")
+
+    def wait_gather(self, local, gathered, stream):
+        _check(lib().uc_group_wait_gather(self._h, int(local), C.c_void_p(self._ptr(gathered)), C.c_void_p(int(stream) if stream else None)),
+               "uc_group_wait_gather")
+
+    def synchronize(self):
+        _check(lib().uc_group_synchronize(self._h), "uc_group_synchronize")
