@@ -416,8 +416,11 @@ def hello_world1(args, device, torch, mag_mean):
     grp = uchirp.Group(uchirp.RX_REAL, devices=[device.index], mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
     try:
         frames, sent = synth.device_hello_frames(0, nf, device, seed=1234, snr_db=args.snr, msg=MSG)
-        stream = torch.cuda.current_stream(device)
+        # a stream of its own: a NULL entry in uc_group_process_batch's stream list means "the group's own stream", and
+        # torch's default stream IS the NULL stream -- the HIP events below must sit on the stream the kernel runs on
+        stream = torch.cuda.Stream(device)
         gat2 = [torch.empty(nf, dtype=torch.uint8, device=device) for _ in range(NBUF)]
+        torch.cuda.synchronize()
 
         def step(k, e0=None, e1=None):
             if e0 is not None:
@@ -461,6 +464,60 @@ def hello_world1(args, device, torch, mag_mean):
         return out
     finally:
         grp.close()
+
+
+def receive_leg(args, device, torch):
+    """SURVEY.md section 8 f1 as a number: the WHOLE receiver (ISR FIFO, the 8 dsp() offsets x {up, down} of every block,
+    main()'s switch and resync, byte assembly: receiver/Src/main.c:417-554, 243-273, 659-668) for thousands of recorded
+    microphone streams at once -- uc_receive_streams: one pack kernel, one band-kernel launch over every 256-sample offset
+    of every stream, the switch replayed on the device one lane per stream.  Streams: 40 blocks of noise + a sample skew,
+    the K7 "Hello World!" transmission rendered at 78 125 Hz, noise; generated on the device.  Real time for ONE
+    microphone is 38.1 blocks/s (the MCU keeps up with exactly one)."""
+    import ctypes as C
+    import uchirp
+    from uchirp import tx
+    fs, nb = 78125.0, 176
+    tone = torch.from_numpy(tx.render(MSG, fs_rx=fs, amplitude=2000.0).astype(np.float32)).to(device)
+    out = {"workload": "recorded streams of %d blocks (%.2f s of microphone signal each): 40 blocks of noise + 777 samples, the K7 "
+                       "'%s' transmission at 78 125 Hz (amplitude 2000, noise sigma 50), noise" % (nb, nb * N / fs, MSG),
+           "blocks_per_stream": nb, "real_time_blocks_per_s_per_stream": fs / N}
+    L = uchirp.lib()
+    stream = torch.cuda.current_stream(device)
+    for ns, var, name in ((4096, uchirp.SYNC_CPLX, "sync_cplx_4096_streams"), (4096, uchirp.RX_REAL, "rx_real_4096_streams"),
+                          (64, uchirp.RX_REAL, "rx_real_64_streams"), (1, uchirp.RX_REAL, "rx_real_1_stream")):
+        g = torch.Generator(device=device)
+        g.manual_seed(ns)
+        x = torch.randn((ns, nb * N), generator=g, device=device) * 50.0
+        lead = 40 * N + 777
+        x[:, lead:lead + tone.numel()] += tone
+        eng = uchirp.Engine(var, device=device.index)
+        cap = 64
+        text = torch.zeros((ns, cap), dtype=torch.uint8, device=device)
+        ntext = torch.zeros(ns, dtype=torch.int32, device=device)
+
+        def call():
+            rc = L.uc_receive_streams(eng._h, C.c_void_p(x.data_ptr()), uchirp.DTYPE_F32, ns, nb * N, 0, None,
+                                      C.c_void_p(text.data_ptr()), cap, C.c_void_p(ntext.data_ptr()), None, 0, None,
+                                      C.c_void_p(stream.cuda_stream))
+            if rc != 0:
+                raise RuntimeError(L.uc_last_error().decode())
+
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        reps = 5 if ns > 64 else 20
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / reps
+        texts = [bytes(r[:k]).decode("latin-1") for r, k in zip(text.cpu().numpy(), ntext.cpu().numpy())]
+        out[name] = {"streams": ns, "ms_per_call": dt * 1e3, "blocks_per_s": ns * nb / dt,
+                     "dsp_frames_per_s": ns * (nb + 2) * 8 / dt, "x_real_time": ns * nb / dt / (fs / N),
+                     "streams_decoding_the_text": sum(1 for t in texts if MSG in t), "first_text": texts[0]}
+        eng.close()
+        del x, text, ntext
+    return out
 
 
 def stream_measurement(args, eng, frames, rank, torch):
@@ -539,6 +596,7 @@ def parse_args(argv=None):
                     help="default rx_real = BASELINE configs[1]; the others are side measurements")
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs[2] / configs[3] block")
     ap.add_argument("--no-hello1", action="store_true", help="N = 1: skip the configs[4] leg at world size 1")
+    ap.add_argument("--no-receive", action="store_true", help="N = 1: skip the multi-stream receiver leg")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N in ONE process: a uc_group over N devices (include/uchirp.h), as a C host would drive the node "
                          "(tests/c/host_multi.c); the default is one process per GPU")
@@ -814,6 +872,9 @@ def main():
     gathered2 = [torch.empty(world * nf, dtype=torch.uint8, device=device) for _ in range(NBUF)] if multi else None
     works = [None] * NBUF
     stream = torch.cuda.current_stream(device) if have_gpu else None
+    # the group's launches go to a stream of their own (a NULL entry in uc_group_process_batch's stream list means "the
+    # group's own stream", and torch's default stream IS the NULL stream: the HIP events must sit where the kernel runs)
+    gstream = torch.cuda.Stream(device) if grp is not None else None
 
     def gather(b):
         if rehearse:  # gloo has no device all-gather: stage through the host (rehearsal only)
@@ -827,10 +888,10 @@ def main():
         b = k % NBUF
         if grp is not None:                   # decode into this rank's slice of gathered2[b] + in-place all-gather, all in C
             if e0 is not None:
-                e0.record(stream)
-            grp.process([frames], world * nf, [gathered2[b]], streams=[stream.cuda_stream])
+                e0.record(gstream)
+            grp.process([frames], world * nf, [gathered2[b]], streams=[gstream.cuda_stream])
             if e1 is not None:
-                e1.record(stream)
+                e1.record(gstream)
             return
         if works[b] is not None:
             works[b].wait()
@@ -1058,6 +1119,18 @@ def main():
                 out["scale_anchor"] = {"workload": "configs[4] at world size 1 (the workload of the --gpus N > 1 lines)",
                                        "n_gpus": 1, "value": h1["value"], "unit": "frames/s", "ms_per_step": h1["ms_per_step"],
                                        "how": "UC_BENCH_HELLO=1 python bench.py prints this leg as its contract line"}
+        if not multi and have_gpu and not args.no_receive:
+            t_c = time.perf_counter()
+            try:
+                rx = receive_leg(args, device, torch)
+                if rx["sync_cplx_4096_streams"]["streams_decoding_the_text"] != 4096:
+                    gate_failures.append("receive: %d of 4096 streams decode the text (complex reference)"
+                                         % rx["sync_cplx_4096_streams"]["streams_decoding_the_text"])
+            except Exception as ex:
+                rx = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+                gate_failures.append("receive failed: %s" % type(ex).__name__)
+            rx["wall_s"] = time.perf_counter() - t_c
+            out["receive"] = rx
         if not multi and have_gpu and not args.no_cpu_baseline:
             cb = cpu_baseline(frames[: 1 << 19].cpu().numpy(), mag_mean)
             # the oracle as the checker: GPU symbols of the measured run vs float64 oracle

@@ -270,6 +270,26 @@ int uc_receive_stream_isr(uc_ctx* ctx, const void* samples, int dtype, size_t n_
                           uc_rx_event* trace /*nullable*/, size_t trace_cap, size_t* n_trace /*nullable*/);
 
 /*
+ * The same receiver for MANY recorded streams at once ("one independent stream per GPU (replicas
+ * across streams)" -- here thousands per GPU): stream s = n_samples words at samples + s * stream_stride_elems
+ * (stream_stride_elems == 0: n_samples; n_samples / n blocks each).  One copy kernel lays every stream's ACCEPTED blocks
+ * out behind the FIFO's 2 n initial zeros (busy: n_streams x (n_samples / n) bytes, nullable -- busy[s][b] != 0 drops block
+ * b of stream s as the ISR would, receiver/Src/main.c:661), ONE launch of the band kernel evaluates every 256-sample
+ * offset of every stream, and main()'s switch (main.c:417-554) + resync() (main.c:243-273) are replayed ON THE DEVICE,
+ * one lane per stream: include/uchirp_mainloop.hpp compiled for the device, the code uc_receive_stream replays on the
+ * host, so a stream's text and trace are the ones uc_receive_stream[_isr] gives for it alone, bit for bit.
+ *   text    n_streams x text_cap bytes: the decoded characters of stream s at text + s * text_cap, NUL-terminated
+ *   n_text  (nullable) characters per stream
+ *   trace   (nullable) n_streams x trace_cap records, one per processed block of the stream; n_trace (nullable) how many
+ * Every pointer may be host or device memory; with device pointers only, the call is asynchronous on hip_stream.
+ * Device memory held by the context: the packed copy of the streams (4 bytes per sample) + 8 bytes per 256 samples.
+ */
+int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_streams, size_t n_samples,
+                       size_t stream_stride_elems, const uint8_t* busy /*nullable*/, char* text, size_t text_cap,
+                       uint32_t* n_text /*nullable*/, uc_rx_event* trace /*nullable*/, size_t trace_cap,
+                       uint32_t* n_trace /*nullable*/, void* hip_stream);
+
+/*
  * UC_STREAM -- BASELINE config 4: streaming FIR-LPF decimate front-end + overlap-save
  * frequency-domain chirp compression over ONE continuous real sample stream x[r].
  *

@@ -2,7 +2,9 @@
 // ONE header-only implementation over an abstract dsp().  Both users replay exactly this code:
 //   * libuchirp.so's uc_receive_stream (csrc/uc_api.cpp): dsp() looks the frame up in the statistics of one batched
 //     launch over every FIFO offset;
-//   * the C++ host layer (include/uchirp_receiver.hpp, tests/cpp/rx_main.cpp): dsp() is one GPU call per frame.
+//   * the C++ host layer (include/uchirp_receiver.hpp, tests/cpp/rx_main.cpp): dsp() is one GPU call per frame;
+//   * uc_receive_streams (csrc/uc_rx_kernel.hip): the SAME code compiled for the device, one lane per recorded stream
+//     (every function below is __host__ __device__ under hipcc).
 // (The CPU oracle keeps its own, independent C restatement: oracle/uc_oracle.c, uco_receive_stream.)
 //
 // `Dsp` provides
@@ -15,18 +17,24 @@
 
 #include "uchirp.h"
 
+#if defined(__HIP__) || defined(__HIPCC__)
+#define UC_HD __host__ __device__
+#else
+#define UC_HD
+#endif
+
 namespace uchirp {
 
 // symbol_snr(): main.c:233-236
 template <class Dsp>
-inline float symbol_snr(Dsp& d, uint32_t sync_position, typename Dsp::history_t* phist, int updown) {
+UC_HD inline float symbol_snr(Dsp& d, uint32_t sync_position, typename Dsp::history_t* phist, int updown) {
   d.dsp(sync_position, phist, phist->mag_mean, updown);
   return phist->snr;
 }
 
 // resync(): main.c:243-273
 template <class Dsp>
-inline void resync(Dsp& d, uint32_t n, float snr, typename Dsp::history_t hist[], uint32_t offset, uint32_t* sync_position,
+UC_HD inline void resync(Dsp& d, uint32_t n, float snr, typename Dsp::history_t hist[], uint32_t offset, uint32_t* sync_position,
                    int updown) {
   const int32_t sync_position_l = (int32_t)*sync_position - (int32_t)offset;
   const int32_t sync_position_r = (int32_t)*sync_position + (int32_t)offset;
@@ -55,17 +63,17 @@ class MainLoop {
  public:
   typedef typename Dsp::history_t history_t;
 
-  MainLoop(uint32_t n, float snr_threshold) : n_(n), thr_(snr_threshold), offset_(n / 8), shift_(n / 4), sync_position_(n / 2) {
+  UC_HD MainLoop(uint32_t n, float snr_threshold) : n_(n), thr_(snr_threshold), offset_(n / 8), shift_(n / 4), sync_position_(n / 2) {
     for (float& v : mag_stat_) v = 1E37f;  // main.c:321
     for (history_t& h : history_) h = history_t();
   }
 
-  int state() const { return state_; }
-  uint32_t sync_position() const { return sync_position_; }
+  UC_HD int state() const { return state_; }
+  UC_HD uint32_t sync_position() const { return sync_position_; }
 
   // `put(char)` receives the decoded characters ('\n' ends a message), as the firmware's printf does
   template <class Put>
-  loop_event step(Dsp& d, Put&& put) {
+  UC_HD loop_event step(Dsp& d, Put&& put) {
     loop_event ev{state_, state_, -1, sync_position_, 0.0f, 0.0f};
     switch (state_) {
       case UC_STATE_IDLE: {

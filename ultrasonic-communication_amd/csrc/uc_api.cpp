@@ -15,6 +15,7 @@
 #include "../../include/uchirp.h"
 #include "../../include/uchirp_mainloop.hpp"
 #include "uc_kernels.hpp"
+#include "uc_rx.hpp"
 #include "uc_tables.hpp"
 
 namespace {
@@ -110,7 +111,8 @@ struct uc_ctx {
   int iq_blocks_per_cu[2] = {0, 0};
   int stream_blocks_per_cu[2] = {0, 0};
   DevBuf s_comp, s_peaks, s_spec;
-  DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream: zero-prefixed stream, (up, down) mag_max per frame
+  DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream[s]: zero-prefixed stream(s), (up, down) mag_max per frame
+  DevBuf s_rx_in, s_rx_busy, s_rx_acc, s_rx_na, s_rx_text, s_rx_ntext, s_rx_trace, s_rx_ntrace;  // uc_receive_streams staging
   std::vector<float2> h_rx_mag;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID / UC_BAND_GROUP / UC_STATIC_DEAL): not part of the ABI
   bool band_waves_set = false;  // UC_BAND_WAVES given: use it for every mode (default: 3, SYNC_CPLX 2 -- see process_batch_impl)
@@ -442,6 +444,9 @@ void uc_destroy(uc_ctx* c) {
   c->s_spec.release();
   c->s_rx_pad.release();
   c->s_rx_mag.release();
+  for (DevBuf* b : {&c->s_rx_in, &c->s_rx_busy, &c->s_rx_acc, &c->s_rx_na, &c->s_rx_text, &c->s_rx_ntext, &c->s_rx_trace,
+                    &c->s_rx_ntrace})
+    b->release();
   c->s_clock.release();
   delete c;
 }
@@ -1203,30 +1208,7 @@ int uc_process_frame(uc_ctx* c, const int32_t* pcm_in, float mag_mean, uint8_t* 
 // stream; control: main()'s switch (include/uchirp_mainloop.hpp, shared with the
 // C++ host layer) replayed on the host over the (up, down) mag_max of every frame.
 // ---------------------------------------------------------------------------
-namespace {
-
-struct HistLite {  // the members of struct history the switch reads
-  float mag_max = 0.0f, mag_mean = 0.0f, snr = 0.0f;
-};
-
-struct RxReplay {
-  typedef HistLite history_t;
-  const float2* magmax;  // [n_frames]: (up, down)
-  size_t n_frames;
-  uint32_t n;
-  size_t block;  // current block index b: FIFO = padded[b*n, b*n + 3n)
-
-  // dsp(): receiver/Src/main.c:183-231 -- the frame at FIFO offset pos is frame (b*n + pos)/256
-  void dsp(uint32_t pos, HistLite* h, float mag_mean, int updown) const {
-    const size_t g = (block * (size_t)n + pos) / 256;
-    const float m = updown == UC_UP_CHIRP ? magmax[g].x : magmax[g].y;
-    h->mag_max = m;
-    h->mag_mean = mag_mean;
-    h->snr = (m - mag_mean) / mag_mean;  // main.c:229
-  }
-};
-
-}  // namespace
+using uc::RxReplay;
 
 extern "C" int uc_receive_stream_isr(uc_ctx* c, const void* samples, int dtype, size_t n_samples, const uint8_t* busy,
                                      char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
@@ -1306,4 +1288,137 @@ extern "C" int uc_receive_stream_isr(uc_ctx* c, const void* samples, int dtype, 
 extern "C" int uc_receive_stream(uc_ctx* c, const void* samples, int dtype, size_t n_samples, char* text,
                                  size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
   return uc_receive_stream_isr(c, samples, dtype, n_samples, nullptr, text, text_cap, trace, trace_cap, n_trace);
+}
+
+// ---------------------------------------------------------------------------
+// uc_receive_streams: the same receiver for MANY recorded streams at once -- pack (zero prefix, drop-on-busy), ONE batched
+// launch over every 256-sample offset of every stream, main()'s switch replayed on the device, one lane per stream
+// (csrc/uc_rx_kernel.hip: include/uchirp_mainloop.hpp compiled for the device).
+// ---------------------------------------------------------------------------
+extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, size_t n_streams, size_t n_samples,
+                                  size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
+                                  uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
+                                  void* hip_stream) {
+  if (!c || !text || text_cap == 0) return fail(-EINVAL, "uc_receive_streams: NULL argument");
+  if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX)
+    return fail(-ENOTSUP, "uc_receive_streams: variant %d has no up/down state machine", (int)c->cfg.variant);
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return fail(-EINVAL, "uc_receive_streams: bad dtype %d", dtype);
+  if (n_streams == 0) return 0;
+  const uint32_t n = c->cfg.n;
+  if (stream_stride_elems == 0) stream_stride_elems = n_samples;
+  if (stream_stride_elems < n_samples) return fail(-EINVAL, "uc_receive_streams: streams overlap (stride %zu < %zu samples)",
+                                                   stream_stride_elems, n_samples);
+  const size_t nb = n_samples / n;
+  if (nb >= ((size_t)1 << 31) / 8 || text_cap >= ((size_t)1 << 31) || trace_cap >= ((size_t)1 << 31))
+    return fail(-EINVAL, "uc_receive_streams: stream too long");
+  if (trace && trace_cap == 0) trace = nullptr;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  bool host_out = false;
+
+  // outputs: straight into device buffers of the caller, else through staging
+  char* d_text = text;
+  if (!is_device_ptr(text)) {
+    if (int rc = c->s_rx_text.ensure(n_streams * text_cap)) return rc;
+    d_text = (char*)c->s_rx_text.p;
+    host_out = true;
+  }
+  uint32_t* d_ntext = n_text;
+  if (n_text && !is_device_ptr(n_text)) {
+    if (int rc = c->s_rx_ntext.ensure(n_streams * sizeof(uint32_t))) return rc;
+    d_ntext = (uint32_t*)c->s_rx_ntext.p;
+    host_out = true;
+  }
+  uc_rx_event* d_trace = trace;
+  if (trace && !is_device_ptr(trace)) {
+    if (int rc = c->s_rx_trace.ensure(n_streams * trace_cap * sizeof(uc_rx_event))) return rc;
+    d_trace = (uc_rx_event*)c->s_rx_trace.p;
+    host_out = true;
+  }
+  uint32_t* d_ntrace = n_trace;
+  if (n_trace && !is_device_ptr(n_trace)) {
+    if (int rc = c->s_rx_ntrace.ensure(n_streams * sizeof(uint32_t))) return rc;
+    d_ntrace = (uint32_t*)c->s_rx_ntrace.p;
+    host_out = true;
+  }
+  if (nb == 0) {  // nothing to process: empty texts, zero counts
+    e = hipMemsetAsync(d_text, 0, n_streams * text_cap, stream);
+    if (e == hipSuccess && d_ntext) e = hipMemsetAsync(d_ntext, 0, n_streams * sizeof(uint32_t), stream);
+    if (e == hipSuccess && d_ntrace) e = hipMemsetAsync(d_ntrace, 0, n_streams * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(empty streams)");
+  }
+
+  // inputs
+  const void* d_in = samples;
+  size_t in_stride = stream_stride_elems;
+  if (nb) {
+    if (!samples) return fail(-EINVAL, "uc_receive_streams: samples is NULL");
+    if (!is_device_ptr(samples)) {
+      const size_t span = (n_streams - 1) * stream_stride_elems + nb * (size_t)n;
+      if (int rc = c->s_rx_in.ensure(span * 4)) return rc;
+      e = hipMemcpyAsync(c->s_rx_in.p, samples, span * 4, hipMemcpyHostToDevice, stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(streams)");
+      d_in = c->s_rx_in.p;
+    }
+    const uint32_t* d_acc = nullptr;
+    const uint32_t* d_na = nullptr;
+    if (busy) {
+      const uint8_t* d_busy = busy;
+      if (!is_device_ptr(busy)) {
+        if (int rc = c->s_rx_busy.ensure(n_streams * nb)) return rc;
+        e = hipMemcpyAsync(c->s_rx_busy.p, busy, n_streams * nb, hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(busy)");
+        d_busy = (const uint8_t*)c->s_rx_busy.p;
+      }
+      int rc = c->s_rx_acc.ensure(n_streams * nb * sizeof(uint32_t));
+      if (!rc) rc = c->s_rx_na.ensure(n_streams * sizeof(uint32_t));
+      if (rc) return rc;
+      const int lrc = uc::launch_rx_accept(d_busy, n_streams, (uint32_t)nb, (uint32_t*)c->s_rx_acc.p, (uint32_t*)c->s_rx_na.p, stream);
+      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx accept kernel launch");
+      d_acc = (const uint32_t*)c->s_rx_acc.p;
+      d_na = (const uint32_t*)c->s_rx_na.p;
+    }
+    const size_t pitch = (2 + nb) * (size_t)n;
+    const size_t n_frames = (n_streams * pitch - n) / 256 + 1;
+    if (n_frames >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_receive_streams: %zu frames in one launch (at most 2^31 - 1)", n_frames);
+    int rc = c->s_rx_pad.ensure(n_streams * pitch * 4);
+    if (!rc) rc = c->s_rx_mag.ensure(n_frames * sizeof(float2));
+    if (rc) return rc;
+    const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
+    int lrc = uc::launch_rx_pack(d_in, in_stride, n, (uint32_t)nb, n_streams, d_acc, d_na, c->s_rx_pad.p, pitch, al16, stream);
+    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
+    rc = process_batch_impl(c, c->s_rx_pad.p, dtype, n_frames, 256, nullptr, nullptr, nullptr, (float2*)c->s_rx_mag.p, hip_stream);
+    if (rc) return rc;
+    uc::RxParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.magmax = (const float2*)c->s_rx_mag.p;
+    rp.n_streams = n_streams;
+    rp.pitch = pitch;
+    rp.n = n;
+    rp.nb = (uint32_t)nb;
+    rp.snr_threshold = c->cfg.snr_threshold;
+    rp.acc = d_acc;
+    rp.na = d_na;
+    rp.text = d_text;
+    rp.text_cap = (uint32_t)text_cap;
+    rp.n_text = d_ntext;
+    rp.trace = d_trace;
+    rp.trace_cap = (uint32_t)trace_cap;
+    rp.n_trace = d_ntrace;
+    lrc = uc::launch_rx_replay(rp, stream);
+    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
+  }
+  if (host_out) {
+    if (d_text != text) e = hipMemcpyAsync(text, d_text, n_streams * text_cap, hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && n_text && d_ntext != n_text)
+      e = hipMemcpyAsync(n_text, d_ntext, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && trace && d_trace != trace)
+      e = hipMemcpyAsync(trace, d_trace, n_streams * trace_cap * sizeof(uc_rx_event), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess && n_trace && d_ntrace != n_trace)
+      e = hipMemcpyAsync(n_trace, d_ntrace, n_streams * sizeof(uint32_t), hipMemcpyDeviceToHost, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "uc_receive_streams: copy back");
+  }
+  return 0;
 }

@@ -195,11 +195,13 @@ int uc_group_unique_id(void* id, size_t cap) {
 void uc_group_destroy(uc_group* g) {
   if (!g) return;
   for (Local& L : g->loc) {
+    if (!L.ctx) continue;  // (never came to life -- a bad ordinal, say: nothing of it to wait for or free)
     (void)hipSetDevice(L.device);
     if (L.compute) (void)hipStreamSynchronize(L.compute);
     if (L.gather) (void)hipStreamSynchronize(L.gather);
   }
   for (Local& L : g->loc) {
+    if (!L.ctx) continue;
     (void)hipSetDevice(L.device);
     if (L.comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(L.comm);
     if (L.ctx) uc_destroy(L.ctx);
@@ -210,6 +212,7 @@ void uc_group_destroy(uc_group* g) {
     if (L.gather) (void)hipStreamDestroy(L.gather);
     if (L.d_gathered) (void)hipFree(L.d_gathered);
   }
+  (void)hipGetLastError();  // (HIP's last-error slot is sticky: leave nothing of the teardown for the next launch to report)
   delete g;
 }
 

@@ -1,0 +1,57 @@
+// uc_rx.hpp -- what the host replay (uc_api.cpp: uc_receive_stream) and the device replay (uc_rx_kernel.hip:
+// uc_receive_streams) of main()'s switch share: the dsp() stand-in that looks a frame up in the statistics of the batched
+// launch, and the launch interface of the rx kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/uchirp.h"
+#include "../../include/uchirp_mainloop.hpp"
+
+namespace uc {
+
+struct HistLite {  // the members of struct history (receiver/Src/main.c:124-136) the switch reads
+  float mag_max = 0.0f, mag_mean = 0.0f, snr = 0.0f;
+};
+
+// dsp() (receiver/Src/main.c:183-231) over a packed stream: the FIFO at accepted block b is packed[b n, b n + 3 n), so the
+// frame at FIFO offset pos is frame (b n + pos) / 256 of the stride-256 launch
+struct RxReplay {
+  typedef HistLite history_t;
+  const float2* magmax;  // (up, down) mag_max of every 256-sample offset of this stream
+  size_t n_frames;       // (host replay only: bound of magmax)
+  uint32_t n;
+  size_t block;          // current accepted block index b
+  UC_HD void dsp(uint32_t pos, HistLite* h, float mag_mean, int updown) const {
+    const size_t g = (block * (size_t)n + pos) / 256;
+    const float2 mm = magmax[g];
+    const float m = updown == UC_UP_CHIRP ? mm.x : mm.y;
+    h->mag_max = m;
+    h->mag_mean = mag_mean;
+    h->snr = (m - mag_mean) / mag_mean;  // main.c:229
+  }
+};
+
+struct RxParams {
+  const float2* magmax;  // device: (up, down) mag_max of every 256-sample offset of the packed buffer
+  size_t n_streams;
+  size_t pitch;          // samples per packed stream = (2 + nb) n
+  uint32_t n, nb;
+  float snr_threshold;
+  const uint32_t* acc;   // device or nullptr (no busy mask): [n_streams][nb] indices of the accepted blocks
+  const uint32_t* na;    // device or nullptr: accepted blocks per stream
+  char* text;            // device: [n_streams][text_cap]
+  uint32_t text_cap;
+  uint32_t* n_text;      // device or nullptr
+  uc_rx_event* trace;    // device or nullptr: [n_streams][trace_cap]
+  uint32_t trace_cap;
+  uint32_t* n_trace;     // device or nullptr
+};
+
+int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);
+int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, size_t n_streams, const uint32_t* acc,
+                   const uint32_t* na, void* dst, size_t pitch, bool aligned16, hipStream_t stream);
+int launch_rx_replay(const RxParams& p, hipStream_t stream);
+
+}  // namespace uc

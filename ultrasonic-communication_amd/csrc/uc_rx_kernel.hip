@@ -1,0 +1,131 @@
+// uc_rx_kernel.hip -- the receiver's main loop for MANY recorded streams at once (uc_receive_streams, include/uchirp.h).
+//
+// Replaces, per stream (reference lines):
+//   the ISR's FIFO incl. its drop-on-busy            receiver/Src/main.c:659-668   -> accept_kernel + pack_kernel
+//   4 dsp() calls per block                          receiver/Src/main.c:447-451, 493-504, 243-250
+//                                                    -> ONE launch of the band kernel over every 256-sample offset of
+//                                                       every stream (uc_api.cpp), (up, down) mag_max per offset
+//   while (1) { switch (state) ... }  + resync()     receiver/Src/main.c:417-554, 243-273   -> replay_kernel
+//
+// The switch is sequential per stream and tiny (about thirty words of state, a handful of 8-byte reads per block), so it
+// runs ONE LANE PER STREAM: 64 streams per wave, lanes diverge over the four states.  It is the code of
+// include/uchirp_mainloop.hpp compiled for the device -- the very functions the host replays for uc_receive_stream and
+// that tests/cpp/rx_main.cpp drives one GPU call per frame -- so the three cannot drift apart.
+// Layout of the packed buffer: stream s owns (2 + nb) * n samples at s * pitch: 2 n zeros (fifo_queue starts as 3 n zeros,
+// main.c:94, and the first accepted block lands in its last third), then its ACCEPTED blocks in order, then zeros.
+#include <hip/hip_runtime.h>
+
+#include "../../include/uchirp_mainloop.hpp"
+#include "uc_rx.hpp"
+
+namespace uc {
+
+namespace {
+
+constexpr int kPackThreads = 256;
+
+// acc[s][k] = index of the k-th accepted block of stream s, na[s] = how many (busy[s][b] != 0: the ISR drops block b)
+__global__ __launch_bounds__(64) void accept_kernel(const uint8_t* busy, uint32_t nb, uint32_t* acc, uint32_t* na) {
+  const size_t s = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint8_t* bz = busy + s * nb;
+  uint32_t* out = acc + s * nb;
+  uint32_t count = 0;
+  for (uint32_t b0 = 0; b0 < nb; b0 += 64) {
+    const uint32_t b = b0 + (uint32_t)lane;
+    const bool ok = b < nb && bz[b] == 0;
+    const unsigned long long m = __ballot(ok);
+    if (ok) out[count + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = b;
+    count += (uint32_t)__popcll(m);
+  }
+  if (lane == 0) na[s] = count;
+}
+
+// one workgroup per (stream, slot j of the packed stream): 2048 words; VEC = words per access (4 when everything is
+// 16-byte aligned, else 1)
+template <int VEC>
+__global__ __launch_bounds__(kPackThreads) void pack_kernel(const uint32_t* src, size_t src_stride, uint32_t n, uint32_t nb,
+                                                            const uint32_t* acc, const uint32_t* na, uint32_t* dst,
+                                                            size_t pitch) {
+  const size_t s = blockIdx.y;
+  const uint32_t j = blockIdx.x;  // slot: 0, 1 = the zero prefix, 2 + k = k-th accepted block
+  uint32_t* d = dst + s * pitch + (size_t)j * n;
+  const uint32_t* from = nullptr;
+  if (j >= 2) {
+    const uint32_t k = j - 2;
+    const uint32_t count = na ? na[s] : nb;
+    if (k < count) from = src + s * src_stride + (size_t)(acc ? acc[s * nb + k] : k) * n;
+  }
+  if (VEC == 4) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    const v4u zero = {0u, 0u, 0u, 0u};
+    for (uint32_t i = threadIdx.x; i < n / 4; i += kPackThreads)
+      reinterpret_cast<v4u*>(d)[i] = from ? reinterpret_cast<const v4u*>(from)[i] : zero;
+  } else {
+    for (uint32_t i = threadIdx.x; i < n; i += kPackThreads) d[i] = from ? from[i] : 0u;
+  }
+}
+
+// main()'s loop, one lane per stream
+__global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
+  const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
+  if (s >= p.n_streams) return;
+  const uint32_t count = p.na ? p.na[s] : p.nb;
+  RxReplay rx{p.magmax + s * (p.pitch / 256), 0, p.n, 0};
+  uchirp::MainLoop<RxReplay> loop(p.n, p.snr_threshold);
+  char* text = p.text + s * p.text_cap;
+  uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
+  uint32_t ntext = 0, nt = 0;
+  auto put = [&](char ch) {
+    if (ntext + 1 < p.text_cap) text[ntext++] = ch;
+  };
+  for (uint32_t i = 0; i < count; i++) {
+    rx.block = i;
+    const uchirp::loop_event le = loop.step(rx, put);
+    if (trace && nt < p.trace_cap) {
+      uc_rx_event ev;
+      ev.block = p.acc ? p.acc[s * p.nb + i] : i;
+      ev.sync_position = le.sync_position;
+      ev.state_before = (uint8_t)le.state_before;
+      ev.state_after = (uint8_t)le.state_after;
+      ev.bit = (int8_t)le.bit;
+      ev.reserved = 0;
+      ev.snr_up = le.snr_up;
+      ev.snr_down = le.snr_down;
+      trace[nt] = ev;
+    }
+    nt++;
+  }
+  text[ntext] = '\0';
+  if (p.n_text) p.n_text[s] = ntext;
+  if (p.n_trace) p.n_trace[s] = nt;
+}
+
+}  // namespace
+
+int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream) {
+  if (n_streams == 0) return (int)hipSuccess;
+  hipLaunchKernelGGL(accept_kernel, dim3((unsigned)n_streams), dim3(64), 0, stream, busy, nb, acc, na);
+  return (int)hipGetLastError();
+}
+
+int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, size_t n_streams, const uint32_t* acc,
+                   const uint32_t* na, void* dst, size_t pitch, bool aligned16, hipStream_t stream) {
+  if (n_streams == 0) return (int)hipSuccess;
+  const dim3 grid(nb + 2, (unsigned)n_streams);
+  if (aligned16)
+    hipLaunchKernelGGL(pack_kernel<4>, grid, dim3(kPackThreads), 0, stream, (const uint32_t*)src, src_stride, n, nb, acc, na,
+                       (uint32_t*)dst, pitch);
+  else
+    hipLaunchKernelGGL(pack_kernel<1>, grid, dim3(kPackThreads), 0, stream, (const uint32_t*)src, src_stride, n, nb, acc, na,
+                       (uint32_t*)dst, pitch);
+  return (int)hipGetLastError();
+}
+
+int launch_rx_replay(const RxParams& p, hipStream_t stream) {
+  if (p.n_streams == 0) return (int)hipSuccess;
+  hipLaunchKernelGGL(replay_kernel, dim3((unsigned)((p.n_streams + 63) / 64)), dim3(64), 0, stream, p);
+  return (int)hipGetLastError();
+}
+
+}  // namespace uc

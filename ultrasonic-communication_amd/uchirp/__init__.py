@@ -35,7 +35,7 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_partition", "uc_frame_span", "uc_stream_span", "uc_group_unique_id", "uc_group_create", "uc_group_create_rank",
            "uc_group_destroy", "uc_group_world", "uc_group_local_count", "uc_group_first_rank", "uc_group_ctx",
            "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
-           "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps"]
+           "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams"]
 GROUP_ID_BYTES = 128
 
 
@@ -139,6 +139,8 @@ def lib():
     L.uc_device_malloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(C.c_void_p)]
     L.uc_device_free.argtypes = [C.c_int, C.c_void_p]
     L.uc_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
+    L.uc_receive_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
+                                     C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.uc_clock_probe.argtypes = [C.c_void_p, C.c_int]
     L.uc_clock_read.argtypes = [C.c_void_p, C.POINTER(Clock)]
     L.uc_clock_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -294,6 +296,46 @@ class Engine:
                                            text, 4096, trace.ctypes.data_as(C.c_void_p), nb, C.byref(nt)),
                "uc_receive_stream")
         return text.value.decode("latin-1"), trace[:nt.value]
+
+    def receive_many(self, samples, busy=None, text_cap=64, want_trace=True, stream=None):
+        """uc_receive_streams: samples [n_streams, n_samples] (numpy int32 / float32, or a contiguous torch device tensor);
+        busy [n_streams, n_samples // n] or None.  Returns (texts: list of str, traces: list of RX_EVENT_DTYPE arrays or
+        None).  Host results either way (the call waits)."""
+        if _is_torch(samples):
+            import torch
+            t = samples
+            if t.dim() != 2 or not t.is_contiguous() or t.dtype not in (torch.int32, torch.float32) or t.device.type != "cuda":
+                raise ValueError("samples must be a contiguous 2-d int32 / float32 GPU tensor")
+            dt = DTYPE_I32 if t.dtype == torch.int32 else DTYPE_F32
+            ns, nsmp = int(t.shape[0]), int(t.shape[1])
+            ptr = C.c_void_p(t.data_ptr())
+            if stream is None:
+                stream = torch.cuda.current_stream(t.device).cuda_stream
+        else:
+            a = np.ascontiguousarray(samples)
+            if a.ndim != 2 or a.dtype not in (np.int32, np.float32):
+                raise TypeError("samples must be a 2-d int32 / float32 array")
+            dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
+            ns, nsmp = a.shape
+            ptr = a.ctypes.data_as(C.c_void_p)
+        nb = nsmp // self.n
+        bz = None
+        if busy is not None:
+            bz = np.ascontiguousarray(busy, np.uint8)
+            if bz.shape != (ns, nb):
+                raise ValueError("busy must be [n_streams, n_samples // n]")
+        text = np.zeros((ns, text_cap), np.uint8)
+        ntext = np.zeros(ns, np.uint32)
+        trace = np.zeros((ns, max(nb, 1)), RX_EVENT_DTYPE) if want_trace else None
+        ntrace = np.zeros(ns, np.uint32)
+        _check(lib().uc_receive_streams(self._h, ptr, dt, ns, nsmp, 0, bz.ctypes.data_as(C.c_void_p) if bz is not None else None,
+                                        text.ctypes.data_as(C.c_void_p), text_cap, ntext.ctypes.data_as(C.c_void_p),
+                                        trace.ctypes.data_as(C.c_void_p) if trace is not None else None, max(nb, 1),
+                                        ntrace.ctypes.data_as(C.c_void_p), C.c_void_p(stream) if stream else None),
+               "uc_receive_streams")
+        texts = [bytes(text[i, :ntext[i]]).decode("latin-1") for i in range(ns)]
+        traces = [trace[i, :ntrace[i]] for i in range(ns)] if want_trace else None
+        return texts, traces
 
     def stream_geometry(self, n_samples):
         """uc_stream_geometry -> (halo, n_out, n_blocks, hop) for a buffer of n_samples (UC_STREAM)."""
