@@ -189,11 +189,19 @@ int uc_process_frame(uc_ctx* ctx, const int32_t* pcm_in, float mag_mean,
  * A launch recorded during stream capture gets a counter that its graph owns for the life of the context (960 per
  * context, then static deal).
  * Every launch leaves its counter at zero (its last workgroup resets it), so nothing but the kernel node is recorded.
+ * A graph's counter belongs to the context: destroy (or stop replaying) the graphs captured from a context before
+ * uc_destroy() frees it.  The counter guard never waits for the device and never fails a launch: if an event call is
+ * refused (a stream of this thread is under a global-mode capture) the launch is dealt statically instead.
  */
 int uc_process_batch(uc_ctx* ctx, const void* frames, int dtype,
                      size_t n_frames, size_t stride_elems,
                      const float* mag_mean, uint8_t* symbols, uc_stats* stats,
                      void* hip_stream);
+
+/* Diagnostic: the number of hand-out counter words of this context that are not zero although nothing is in flight (waits
+ * for the device first).  Always 0 -- a launch leaves its counter at zero; anything else means a kernel returned without
+ * passing the hand-out's exit, and the next launch on that counter would silently skip frame groups. */
+int uc_debug_busy_counters(uc_ctx* ctx);
 
 /* number of uc_stats records uc_process_batch writes per frame (1 or 2) */
 int uc_stats_per_frame(const uc_ctx* ctx);
@@ -212,6 +220,8 @@ int uc_get_table(const uc_ctx* ctx, int table_id, float* out, size_t cap);
  * table_id: UC_TABLE_UP, UC_TABLE_DOWN or UC_TABLE_HANN; count must equal what uc_get_table returns for it.
  * RX_REAL, SYNC_CPLX and DECHIRP_DOWN only (-ENOTSUP otherwise).  Synchronous: waits for the device, then rebuilds the
  * fused reference * Hann tables the kernels read.  Window geometry (bandwidth, idx_left_zero) is unchanged.
+ * All or nothing: on failure both the host copy (uc_get_table) and the device tables keep the old reference.  The wait
+ * covers launches already enqueued; a graph captured from this context must not be REPLAYED while the call runs.
  */
 int uc_set_table(uc_ctx* ctx, int table_id, const float* data, size_t count);
 

@@ -193,7 +193,7 @@ class Oracle:
                                           4096, _ptr(trace), nb, C.byref(nt))
         if rc < 0:
             raise RuntimeError("uco_receive_stream rc=%d" % rc)
-        return text.value.decode("latin-1"), trace[:nt.value]
+        return text.raw[:rc].decode("latin-1"), trace[:nt.value]    # (the returned count: a decoded byte may be 0)
 
     def stream_geometry(self, n_samples):
         """(halo, n_out, n_blocks, hop) for a buffer of n_samples (UC_STREAM)."""

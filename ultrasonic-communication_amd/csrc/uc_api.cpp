@@ -147,6 +147,8 @@ struct uc_ctx {
   hipEvent_t switch_ev = nullptr;
   bool wait_switch[kWorkSlots] = {};    // slot i was last used before the switch: free once switch_ev has completed
   bool slot_used[kWorkSlots] = {};
+  bool switch_lost = false;             // the switch event could not be recorded: slots used before it never come back
+  bool graph_slots_warned = false;
   // uc_clock_probe(): launches run the clock-stamped twin of their kernel (uc_kernels.hpp: uc::clk) and leave four words
   // per wave here; clock_waves = the waves of the LAST launch
   bool clock_probe = false;
@@ -420,6 +422,13 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
 void uc_destroy(uc_ctx* c) {
   if (!c) return;
   (void)hipSetDevice(c->device);
+  if (c->d_work) {
+    const char* tuning = getenv("UC_TUNING");
+    if (tuning && atoi(tuning) != 0) {  // debug / CI: a counter left non-zero = a kernel exit that skipped handout_leave
+      const int busy = uc_debug_busy_counters(c);
+      if (busy > 0) fprintf(stderr, "libuchirp: uc_destroy(%p): %d hand-out counter word(s) not zero\n", (void*)c, busy);
+    }
+  }
   if (c->d_tab0) (void)hipFree(c->d_tab0);
   if (c->d_tab1) (void)hipFree(c->d_tab1);
   if (c->d_tab2) (void)hipFree(c->d_tab2);
@@ -521,22 +530,43 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, 
   const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
   unsigned idx;
   if (capturing) {
-    if (c->graph_next >= kGraphSlots) return 0;
+    if (c->graph_next >= kGraphSlots) {
+      if (!c->graph_slots_warned) {  // once per context: the launch still works, dealt statically (a few percent slower)
+        c->graph_slots_warned = true;
+        fprintf(stderr, "libuchirp: context %p has handed out all %u graph-owned hand-out counters (one per captured launch, "
+                        "never recycled); further captured launches use the static deal\n", (void*)c, kGraphSlots);
+      }
+      return 0;
+    }
     idx = kWorkSlots + c->graph_next++;
   } else {
+    // The guard below records and queries events.  While ANOTHER stream of this thread is being captured in the global
+    // capture mode (torch.cuda.graph's default) such calls are illegal and would invalidate that capture; an error from
+    // any of them must therefore never fail the launch: give the counter up and deal this launch statically (same
+    // results).  No call here ever waits for the device.
+    auto give_up = [&](hipError_t) {
+      (void)hipGetLastError();
+      return 0;
+    };
     if (!c->multi_stream) {
       if (!c->ring_stream_set) {
         c->ring_stream = stream;
         c->ring_stream_set = true;
       } else if (stream != c->ring_stream) {
+        hipStreamCaptureStatus rcap = hipStreamCaptureStatusNone;
+        const bool ring_capturing = c->ring_stream && hipStreamIsCapturing(c->ring_stream, &rcap) == hipSuccess &&
+                                    rcap != hipStreamCaptureStatusNone;
+        if (ring_capturing) return give_up(hipSuccess);  // (an event recorded there would become a graph node)
         const hipError_t e = hipEventRecord(c->switch_ev, c->ring_stream);
-        if (e == hipSuccess) {
-          for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = c->slot_used[i];
-        } else {
-          // (the first stream no longer exists: nothing to record on -- wait once for whatever it left behind)
+        if (e != hipSuccess) {
+          // the first stream no longer exists, or a capture elsewhere forbids the call: nothing is known about the slots
+          // used so far -- retire the ring for good (every slot stays "in use before the switch" until an event says
+          // otherwise, which none will: static deal for this context's eager launches from here on)
           (void)hipGetLastError();
-          const hipError_t e2 = hipDeviceSynchronize();
-          if (e2 != hipSuccess) return hip_fail(e2, "hipDeviceSynchronize(stream switch)");
+          for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = c->slot_used[i];
+          c->switch_lost = true;
+        } else {
+          for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = c->slot_used[i];
         }
         c->multi_stream = true;
       }
@@ -544,15 +574,16 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, 
     idx = c->work_next % kWorkSlots;
     if (c->multi_stream) {
       if (c->wait_switch[idx]) {
+        if (c->switch_lost) return 0;
         const hipError_t q = hipEventQuery(c->switch_ev);
         if (q == hipErrorNotReady) return 0;  // launches from before the switch still run: deal this one statically
-        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(stream switch)");
+        if (q != hipSuccess) return give_up(q);
         for (unsigned i = 0; i < kWorkSlots; i++) c->wait_switch[i] = false;
       }
       if (c->work_busy[idx]) {
         const hipError_t q = hipEventQuery(c->work_ev[idx]);
         if (q == hipErrorNotReady) return 0;  // still in flight: do not advance, deal this launch statically
-        if (q != hipSuccess) return hip_fail(q, "hipEventQuery(work counter)");
+        if (q != hipSuccess) return give_up(q);
         c->work_busy[idx] = false;
       }
     }
@@ -569,7 +600,14 @@ static int work_counter_launched(uc_ctx* c, hipStream_t stream, int slot) {
   c->slot_used[slot] = true;
   if (!c->multi_stream) return 0;  // one stream so far: stream order is the guard
   const hipError_t e = hipEventRecord(c->work_ev[slot], stream);
-  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(work counter)");
+  if (e != hipSuccess) {
+    // (a capture on another stream forbids the call): the launch is out and correct; without its event the slot cannot be
+    // shown free again, so it stays busy -- later launches that land on it are dealt statically
+    (void)hipGetLastError();
+    c->wait_switch[slot] = true;
+    c->switch_lost = true;
+    return 0;
+  }
   c->work_busy[slot] = true;
   return 0;
 }
@@ -908,8 +946,36 @@ int uc_set_table(uc_ctx* c, int table_id, const float* data, size_t count) {
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   e = hipDeviceSynchronize();  // no launch of this context may still be reading the old tables
   if (e != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
+  // all or nothing: the host copy (what uc_get_table reports) changes only if every device table took the new reference;
+  // on a failed upload the old reference is put back on both sides
+  const std::vector<float> old = *dst;
   memcpy(dst->data(), data, count * sizeof(float));
-  return upload_device_tables(c);
+  int rc = upload_device_tables(c);
+  if (rc) {
+    const std::string why = g_err;
+    *dst = old;
+    (void)upload_device_tables(c);  // (best effort: the same copies that just failed may fail again)
+    g_err = why;
+  }
+  return rc;
+}
+
+// Diagnostic: hand-out counters that are not zero although no launch of the context is in flight (waits for the device).
+// Always 0: every dynamically dealt launch leaves its counter at zero when its last workgroup exits (uc_dev.hpp:
+// handout_leave).  A non-zero value means a kernel path returned without passing that exit -- the next launch on that slot
+// would skip work groups silently.  tests/test_gpu_handout.py asserts it behind every kernel family.
+int uc_debug_busy_counters(uc_ctx* c) {
+  if (!c) return fail(-EINVAL, "uc_debug_busy_counters: NULL ctx");
+  hipError_t e = hipSetDevice(c->device);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  if (e != hipSuccess) return hip_fail(e, "hipDeviceSynchronize");
+  const size_t words = (size_t)(kWorkSlots + kGraphSlots) * kWorkStride / sizeof(unsigned int);
+  std::vector<unsigned int> w(words);
+  e = hipMemcpy(w.data(), c->d_work, words * sizeof(unsigned int), hipMemcpyDeviceToHost);
+  if (e != hipSuccess) return hip_fail(e, "hipMemcpy(work counters)");
+  int busy = 0;
+  for (unsigned int v : w) busy += v != 0;
+  return busy;
 }
 
 int uc_window_bins(const uc_ctx* c) {

@@ -35,7 +35,7 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_partition", "uc_frame_span", "uc_stream_span", "uc_group_unique_id", "uc_group_create", "uc_group_create_rank",
            "uc_group_destroy", "uc_group_world", "uc_group_local_count", "uc_group_first_rank", "uc_group_ctx",
            "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
-           "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams"]
+           "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters"]
 GROUP_ID_BYTES = 128
 
 
@@ -141,6 +141,7 @@ def lib():
     L.uc_device_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
     L.uc_receive_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.uc_debug_busy_counters.argtypes = [C.c_void_p]
     L.uc_clock_probe.argtypes = [C.c_void_p, C.c_int]
     L.uc_clock_read.argtypes = [C.c_void_p, C.POINTER(Clock)]
     L.uc_clock_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -194,6 +195,10 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def busy_counters(self):
+        """uc_debug_busy_counters: hand-out counter words left non-zero with nothing in flight (always 0)."""
+        return _check(lib().uc_debug_busy_counters(self._h), "uc_debug_busy_counters")
 
     def clock_probe(self, on=True):
         """uc_clock_probe: the following launches run the clock-stamped twin of their kernel (never time with it on)."""
@@ -292,10 +297,11 @@ class Engine:
             bz = np.ascontiguousarray(busy, np.uint8).reshape(-1)
             if bz.size != nb:
                 raise ValueError("busy must hold one flag per %d-sample block" % self.n)
-        _check(lib().uc_receive_stream_isr(self._h, ptr, dt, count, bz.ctypes.data_as(C.c_void_p) if bz is not None else None,
-                                           text, 4096, trace.ctypes.data_as(C.c_void_p), nb, C.byref(nt)),
-               "uc_receive_stream")
-        return text.value.decode("latin-1"), trace[:nt.value]
+        nch = _check(lib().uc_receive_stream_isr(self._h, ptr, dt, count, bz.ctypes.data_as(C.c_void_p) if bz is not None else None,
+                                                 text, 4096, trace.ctypes.data_as(C.c_void_p), nb, C.byref(nt)),
+                     "uc_receive_stream")
+        # (the returned count, not the C string: a decoded byte may be 0)
+        return text.raw[:nch].decode("latin-1"), trace[:nt.value]
 
     def receive_many(self, samples, busy=None, text_cap=64, want_trace=True, stream=None):
         """uc_receive_streams: samples [n_streams, n_samples] (numpy int32 / float32, or a contiguous torch device tensor);
