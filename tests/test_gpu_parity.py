@@ -1006,3 +1006,46 @@ def test_band_frame_groups_dynamic_hand_out(uchirp, variant, monkeypatch, uc_tun
                 assert np.array_equal(gst[:same].view(np.uint32), gst0[:same].view(np.uint32)), (env, cnt)
                 for fld in ("mag_max", "mag_max_left", "mag_max_right"):
                     assert np.allclose(gst[same:][fld], gst0[same:cnt][fld], rtol=2e-6, atol=0.0), (env, cnt, fld)
+
+
+def test_mixed_host_and_device_pointers(uchirp):
+    """uc_process_batch takes host or device memory PER ARGUMENT.  Every combination gives the
+    all-device results; a call with any host OUTPUT returns with that output complete (it waits), a call whose host
+    arguments are inputs only stays asynchronous on the caller's stream."""
+    import ctypes as C
+    import itertools
+    import torch
+    nf = 300
+    frames, _ = synth.make_frames(nf, seed=21, snr_db=-3.0)
+    mm = (np.random.default_rng(2).random((nf, 2)).astype(np.float32) * 500 + 800)
+    e = uchirp.Engine(uchirp.RX_REAL)
+    L = uchirp.lib()
+    dev = torch.device("cuda", 0)
+    ref_sym, ref_st = e.process(torch.from_numpy(frames).to(dev), mag_mean=torch.from_numpy(mm.reshape(-1)).to(dev))
+    torch.cuda.synchronize()
+    ref_sym, ref_st = ref_sym.cpu().numpy(), ref_st.cpu().numpy()
+    stream = torch.cuda.Stream()
+    for f_dev, m_dev, s_dev, t_dev in itertools.product((False, True), repeat=4):
+        f_t = torch.from_numpy(frames).to(dev) if f_dev else None
+        m_t = torch.from_numpy(mm.reshape(-1)).to(dev) if m_dev else None
+        s_t = torch.zeros(nf, dtype=torch.uint8, device=dev) if s_dev else None
+        t_t = torch.zeros((nf, 2, 8), dtype=torch.float32, device=dev) if t_dev else None
+        s_h = np.zeros(nf, np.uint8)
+        t_h = np.zeros((nf, 2, 8), np.float32)
+        torch.cuda.synchronize()
+        rc = L.uc_process_batch(e._h, C.c_void_p(f_t.data_ptr()) if f_dev else frames.ctypes.data_as(C.c_void_p), uchirp.DTYPE_F32,
+                                nf, 0, C.c_void_p(m_t.data_ptr()) if m_dev else mm.ctypes.data_as(C.c_void_p),
+                                C.c_void_p(s_t.data_ptr()) if s_dev else s_h.ctypes.data_as(C.c_void_p),
+                                C.c_void_p(t_t.data_ptr()) if t_dev else t_h.ctypes.data_as(C.c_void_p),
+                                C.c_void_p(stream.cuda_stream))
+        assert rc == 0, L.uc_last_error()
+        if not s_dev:                       # a host output is complete when the call returns: no synchronize here
+            assert np.array_equal(s_h, ref_sym), (f_dev, m_dev, s_dev, t_dev)
+        if not t_dev:
+            assert np.array_equal(t_h.view(np.uint32), ref_st.view(np.uint32)), (f_dev, m_dev, s_dev, t_dev)
+        stream.synchronize()
+        if s_dev:
+            assert np.array_equal(s_t.cpu().numpy(), ref_sym), (f_dev, m_dev, s_dev, t_dev)
+        if t_dev:
+            assert np.array_equal(t_t.cpu().numpy().view(np.uint32), ref_st.view(np.uint32)), (f_dev, m_dev, s_dev, t_dev)
+    e.close()
