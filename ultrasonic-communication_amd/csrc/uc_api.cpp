@@ -523,6 +523,17 @@ int32_t uc_idx2freq(const uc_ctx* c, uint32_t idx) {
 //   capture      : a slot the graph owns from now on (kGraphSlots per context, never recycled): two graphs replayed on
 //                  two streams never share a counter, and a graph's own replays are serialised by the runtime.
 //                  *slot = -1.  When the graph slots are used up: nullptr (static deal).
+// Event queries are "potentially unsafe" calls: while ANY stream of the thread is being captured in the global capture mode
+// (torch.cuda.graph's default) they are refused AND invalidate that capture.  The guard's events have nothing to do with
+// a capture in progress, so its calls run with the thread's capture mode switched to relaxed for their duration (what
+// allocators that must touch the runtime during someone else's capture do).
+struct RelaxedCapture {
+  hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+  bool ok;
+  RelaxedCapture() { ok = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess; if (!ok) (void)hipGetLastError(); }
+  ~RelaxedCapture() { if (ok) (void)hipThreadExchangeStreamCaptureMode(&mode); }
+};
+
 static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, int* slot) {
   *out = nullptr;
   *slot = -1;
@@ -540,14 +551,14 @@ static int take_work_counter(uc_ctx* c, hipStream_t stream, unsigned int** out, 
     }
     idx = kWorkSlots + c->graph_next++;
   } else {
-    // The guard below records and queries events.  While ANOTHER stream of this thread is being captured in the global
-    // capture mode (torch.cuda.graph's default) such calls are illegal and would invalidate that capture; an error from
-    // any of them must therefore never fail the launch: give the counter up and deal this launch statically (same
-    // results).  No call here ever waits for the device.
+    // The guard below records and queries events (under RelaxedCapture, above).  An error from any of them must never fail
+    // the launch: give the counter up and deal this launch statically (same results).  No call here ever waits for the
+    // device.
     auto give_up = [&](hipError_t) {
       (void)hipGetLastError();
       return 0;
     };
+    const RelaxedCapture relaxed;
     if (!c->multi_stream) {
       if (!c->ring_stream_set) {
         c->ring_stream = stream;
@@ -599,6 +610,7 @@ static int work_counter_launched(uc_ctx* c, hipStream_t stream, int slot) {
   if (slot < 0) return 0;
   c->slot_used[slot] = true;
   if (!c->multi_stream) return 0;  // one stream so far: stream order is the guard
+  const RelaxedCapture relaxed;
   const hipError_t e = hipEventRecord(c->work_ev[slot], stream);
   if (e != hipSuccess) {
     // (a capture on another stream forbids the call): the launch is out and correct; without its event the slot cannot be
