@@ -24,18 +24,11 @@
 //     ping-ponging between the tile and the (then idle) image area: one barrier per exchange.
 //   * |y| for the hop = 2049 - L valid outputs leaves as coalesced dword stores; the block maximum
 //     is a DPP wave reduction on squared magnitudes.
-//   * Overlap carry (round 4, D >= 8): consecutive blocks share L - 1 decimated samples.  A workgroup that goes on to the
-//     NEXT block of the stream keeps the un-rotated FIR outputs of the last 63 * (32 / D) of them in LDS and does not
-//     load the 3 x 2 KiB of input that only they depend on; the values are what the FIR would recompute (same samples,
-//     same tap order) and take the new block's rotation like any other output, so results stay bit for bit.
 // HBM traffic per input sample: 4 B in + 4/D B out (+ 8 B of peak record per block).
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 #include "uc_xform.hpp"
 
-#ifndef UC_STREAM_CARRY
-#define UC_STREAM_CARRY 1  // 0: every block loads and filters all of its input (the round-3 kernel), for A/B
-#endif
 #ifndef UC_STREAM_KNOCK
 #define UC_STREAM_KNOCK 0  // diagnostic builds only: 1 no loads in the loop, 2 no FIR arithmetic, 4 no transforms, 8 no stores,
                            // 16 / 32 the round-2 nt mix / every load nt, 64 a whole block of loads in flight,
@@ -53,11 +46,7 @@ constexpr int kTileOff = kImgF4 * 4;                                        // f
 constexpr int kRedOff = kTileOff + 2 * kN;
 constexpr int kTw2Off = kRedOff + 16;         // W_256^(t k), t < 16, k < 16: forward pass 2
 constexpr int kTwBOff = kTw2Off + 2 * 256;    // W_128^(t k), t < 16, k < 8: inverse pass B
-constexpr int kCarryOff = kTwBOff + 2 * 128;  // overlap carry: 63 threads x (32 / D) un-rotated FIR outputs (D >= 8)
-constexpr int kCarryThreads = 63;             // floor((L - 1) / (32 / D)) for every D
-constexpr bool carry_on(int d) { return UC_STREAM_CARRY && d >= 8; }  // (D = 4: 4 KiB more LDS would cost a workgroup per CU)
-constexpr int lds_floats(int d) { return kCarryOff + (carry_on(d) ? 2 * kCarryThreads * (32 / d) : 0); }
-static_assert(lds_floats(8) * 4 * 4 <= 160 * 1024, "four workgroups per CU");
+constexpr int kLdsFloats = kTwBOff + 2 * 128;
 
 // acc += c * x.lo / c * x.hi: complex constant (SGPR pair) times a real sample broadcast from one
 // half of a register pair -- one packed FMA for the I and the Q branch of the FIR
@@ -91,10 +80,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   constexpr int WIN4 = (WIN + 3) / 4;
   static_assert(D == 4 || D == 8 || D == 16, "decimation");
 
-  constexpr bool kCarry = carry_on(D);
-  constexpr int NCARRY = kCarryThreads * OPT;  // outputs of a block that its predecessor on this workgroup hands over
-  __shared__ __attribute__((aligned(16))) float lds[lds_floats(D)];
-  float* carry = lds + kCarryOff;
+  __shared__ __attribute__((aligned(16))) float lds[kLdsFloats];
   v4f* img = reinterpret_cast<v4f*>(lds);
   float* tile = lds + kTileOff;
   float* red = lds + kRedOff;
@@ -170,10 +156,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   // Two register sets: the loads run TWO sub-tiles ahead of the FIR (and through the transforms).
   constexpr int kDepth = (UC_STREAM_KNOCK & 64) ? NSUB : 2;  // (64: a whole block of input in flight -- diagnostic, with 2 + 4)
   v4u stg[kDepth][9];
-  // carried: the block follows its predecessor on this workgroup -- the first 63 threads' outputs of sub-tile 0 come out of
-  // the carry, so the 3 x 128 float4 that only their windows read (samples [0, 2016) of the sub-tile; thread 63's window
-  // starts at sample 2016 = float4 504, inside load 3) are not loaded
-  auto issue_loads = [&](unsigned blk, int sub, v4u (&dst)[9], bool carried) {
+  auto issue_loads = [&](unsigned blk, int sub, v4u (&dst)[9]) {
     size_t first = (size_t)blk * (size_t)(HOP * D) + (size_t)sub * kSubIn;
     if (UC_STREAM_KNOCK & 128) first &= ~(size_t)31;  // (128: loads on the 128-byte grid -- WRONG samples, timing only)
     const size_t left = p.n_samples > first ? p.n_samples - first : 0;
@@ -184,13 +167,8 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     // with the dynamic hand-out: default everywhere 1.833 / 1.836-1.858 ms per 2^31 samples, the nt mix 1.904 /
     // 1.847-1.917, nt everywhere 1.944 (profiles/r03_stream_knock.txt).
     if (!(UC_STREAM_KNOCK & 32) && (!(UC_STREAM_KNOCK & 16) || sub == NSUB - 1)) {  // (16: the nt mix of round 2, 32: every load nt)
-      if (kCarry && sub == 0 && carried) {
 #pragma unroll
-        for (int r = 3; r < 8; r++) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, T * 16 * r, 0);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 8; r++) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, T * 16 * r, 0);
-      }
+      for (int r = 0; r < 8; r++) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, T * 16 * r, 0);
       dst[8] = __builtin_amdgcn_raw_buffer_load_b128(rx, voff16, kSubIn * 4, 0);
     } else {
 #pragma unroll
@@ -200,8 +178,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
   };
 
 #pragma unroll
-  for (int s = 0; s < kDepth; s++) issue_loads(b, s, stg[s], false);
-  bool carried = false;  // this block's first NCARRY outputs sit in `carry` (written by the previous block of this workgroup)
+  for (int s = 0; s < kDepth; s++) issue_loads(b, s, stg[s]);
 
   float* tb = lds;  // second transform tile: the image area is free once the last window is read
 
@@ -233,19 +210,15 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
 #pragma unroll
       for (int r = 0; r < 8; r++) {
         const int q = j + T * r;  // float4 index inside the sub-tile
-        if (kCarry && s == 0 && r < 3) {
-          if (!carried) img[q + (q >> 3)] = cvt4<DTYPE>(cur[r]);  // (carried: not loaded, and read by carried threads only)
-        } else {
-          img[q + (q >> 3)] = cvt4<DTYPE>(cur[r]);
-        }
+        img[q + (q >> 3)] = cvt4<DTYPE>(cur[r]);
       }
       if (j < 7) {
         const int q = kSubIn / 4 + j;
         img[q + (q >> 3)] = cvt4<DTYPE>(cur[8]);
       }
 #if !(UC_STREAM_KNOCK & 1)  // (knock-out builds, tools/stream_knock.sh: what each stage costs; never shipped)
-      if (s + kDepth < NSUB) issue_loads(b, s + kDepth, cur, false);
-      else if (more) issue_loads(bn, s + kDepth - NSUB, cur, !hop);  // (not behind a chunk change: bn = b + 1)
+      if (s + kDepth < NSUB) issue_loads(b, s + kDepth, cur);
+      else if (more) issue_loads(bn, s + kDepth - NSUB, cur);
 #endif
       __syncthreads();
 
@@ -274,33 +247,6 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
             const v2f c = mkv(p.ctap[2 * k], p.ctap[2 * k + 1]);
             if (w & 1) pk_fma_c_xhi(acc[u], c, xs[w >> 1]);
             else pk_fma_c_xlo(acc[u], c, xs[w >> 1]);
-          }
-        }
-      }
-      if (kCarry) {
-        if (s == 0) {
-          // the outputs the previous block already filtered: un-rotated, exactly what the loop above would have produced
-          // from the samples that were not loaded (the accumulators of these threads hold stale-image garbage)
-          int cj = j;
-          asm volatile("" : "+v"(cj));  // (keep the address out of the registers that live across the block loop)
-          if (carried && cj < kCarryThreads) {
-#pragma unroll
-            for (int h = 0; h < OPT / 2; h++) {
-              const v4f c4 = *reinterpret_cast<const v4f*>(carry + 2 * (OPT * cj + 2 * h));
-              acc[2 * h] = mkv(c4.x, c4.y);
-              acc[2 * h + 1] = mkv(c4.z, c4.w);
-            }
-          }
-        }
-        if (s == NSUB - 1) {
-          // hand the next block its first NCARRY outputs: output i of block b + 1 is output HOP + i of this one
-          // (every block of a run but the last has a successor; writing always keeps the path uniform)
-          int cj = j;
-          asm volatile("" : "+v"(cj));
-#pragma unroll
-          for (int u = 0; u < OPT; u++) {
-            const int i = (NSUB - 1) * SUBOUT + OPT * cj + u - HOP;
-            if (i >= 0 && i < NCARRY) lds_st(carry, i, acc[u]);
           }
         }
       }
@@ -388,7 +334,6 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
     }
     if (!more) break;
     b = bn;
-    carried = !hop;  // the next block continues this one (a chunk change starts afresh)
     if (hop) bend = b + gmask + 1u < nblk ? b + gmask + 1u : nblk;
   }
   if (dyn && j == 0) handout_leave(p.work_ctr);  // the last workgroup out leaves the counter at zero for the next launch
