@@ -188,6 +188,46 @@ def valu_table():
     return _VALU
 
 
+def live_traffic(frames_log2=19, timeout_s=150):
+    """HBM bytes per frame of the headline kernel from the PMC counters, collected IN THIS RUN: two child processes,
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md
+    prescribes: they do not fit one pass) over `python3 tools/run_target.py band_rx_real_f32` -- the same kernel on 2^19
+    frames of the same synthetic workload -- with the guide's gfx950 correction (FETCH_SIZE tallies a 128-byte request as 64
+    bytes: x 2; WRITE_SIZE exact; both reported in KiB).  Returns None when rocprofv3 is not there or a pass fails."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    exe = shutil.which("rocprofv3")
+    if not exe:
+        return None
+    raw = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="uc_pmc_", dir="/tmp")
+        try:
+            subprocess.run([exe, "--kernel-trace", "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable,
+                            os.path.join(ROOT, "tools", "run_target.py"), "band_rx_real_f32", "--frames-log2", str(frames_log2),
+                            "--iters", "3"], cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), timeout=timeout_s,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, check=True)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            vals = [float(r["Counter_Value"]) for f in files for r in csv.DictReader(open(f))
+                    if "band_kernel" in r["Kernel_Name"] and r["Counter_Name"] == ctr]
+            if not vals:
+                return None
+            raw[ctr] = sum(vals) / len(vals)
+        except (subprocess.SubprocessError, OSError, KeyError, ValueError):
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    nfr = 1 << frames_log2
+    rd, wr = raw["FETCH_SIZE"] * 1024.0 * 2.0, raw["WRITE_SIZE"] * 1024.0
+    return {"hbm_bytes_per_frame": (rd + wr) / nfr, "read_bytes_per_frame": rd / nfr, "write_bytes_per_frame": wr / nfr,
+            "FETCH_SIZE_KiB_raw": raw["FETCH_SIZE"], "WRITE_SIZE_KiB_raw": raw["WRITE_SIZE"], "frames_per_profiled_launch": nfr,
+            "method": "measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (two child processes, separate "
+                      "passes) over tools/run_target.py band_rx_real_f32 --frames-log2 %d; gfx950 correction FETCH_SIZE x 2"
+                      % frames_log2}
+
+
 _NUM_CU = {}
 
 
@@ -597,6 +637,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs[2] / configs[3] block")
     ap.add_argument("--no-hello1", action="store_true", help="N = 1: skip the configs[4] leg at world size 1")
     ap.add_argument("--no-receive", action="store_true", help="N = 1: skip the multi-stream receiver leg")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="N = 1: do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE); roofline.traffic then "
+                         "comes from the committed record and says so")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N in ONE process: a uc_group over N devices (include/uchirp.h), as a C host would drive the node "
                          "(tests/c/host_multi.c); the default is one process per GPU")
@@ -1043,6 +1086,14 @@ def main():
             out["roofline"] = roofline("band_rx_real_f32", "band_kernel<rx_real,f32>", nf, BYTES_PER_FRAME, kern_ms,
                                        num_cus(torch, device), clk_live)
             out["roofline"]["bytes_per_frame"] = BYTES_PER_FRAME
+            if not multi and not args.no_live_traffic:
+                t_c = time.perf_counter()
+                lt = live_traffic()
+                if lt:
+                    traffic, traffic_source = lt["hbm_bytes_per_frame"] * nf, lt.pop("method")
+                    lt["wall_s"] = time.perf_counter() - t_c
+                    out["roofline"]["traffic_counters"] = lt
+                    out["roofline"]["traffic_over_algorithmic"] = lt["hbm_bytes_per_frame"] / BYTES_PER_FRAME
             out["roofline"]["traffic"] = traffic
             out["roofline"]["traffic_source"] = traffic_source
             if not multi:
