@@ -201,6 +201,9 @@ def live_traffic(frames_log2=19, timeout_s=150):
     exe = shutil.which("rocprofv3")
     if not exe:
         return None
+    # (this process is itself being profiled -- tools/profile_round.sh: no profiler inside a profiler)
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None
     raw = {}
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         d = tempfile.mkdtemp(prefix="uc_pmc_", dir="/tmp")
