@@ -26,6 +26,11 @@
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 
+#ifndef UC_IQ_KNOCK
+#define UC_IQ_KNOCK 0  // diagnostic builds only (tools/ab_build.sh; results WRONG by construction, timing only):
+                       // 1 = no carrier mix (the image holds (x, x)): the VALU a carrier folded into the taps would save
+#endif
+
 namespace uc {
 
 namespace {
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
 #pragma unroll
     for (int u = 0; u < 17; u++) {
       const float x = cvt1<DTYPE>(xn[u]);
-      lds_st(img, mix_idx(j + T * u), mkv(x * cs[u].x, x * cs[u].y));
+      lds_st(img, mix_idx(j + T * u), (UC_IQ_KNOCK & 1) ? mkv(x, x) : mkv(x * cs[u].x, x * cs[u].y));
     }
     if (has_next) load_frame(fnext);
     __syncthreads();  // B1: image complete; the previous frame's pruned-pass reads of the tile are done
@@ -700,7 +705,7 @@ __global__ __launch_bounds__(T1, 2) void iq1024_kernel(const IqParams p) {
     for (int u = 0; u < 17; u++) {
       const float x = cvt1<DTYPE>(xn[u]);
       const int m = j + T1 * u;
-      lds_st(lds, FIRM ? m + ((m >> 4) << 1) : mix_idx(m), mkv(x * cs[u].x, x * cs[u].y));
+      lds_st(lds, FIRM ? m + ((m >> 4) << 1) : mix_idx(m), (UC_IQ_KNOCK & 1) ? mkv(x, x) : mkv(x * cs[u].x, x * cs[u].y));
     }
     if (has_next) load_frame(fnext);
     __syncthreads();  // single wave: no s_barrier is emitted, only the LDS wait
