@@ -347,8 +347,11 @@ int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, si
     dst[(size_t)l] = d;
     // write-after-gather: an earlier gather that still reads or writes this buffer must be done before the kernel
     // overwrites the rank's slice of it (device-side wait, nothing blocks here)
+    // ... and the ring slot this step will recycle: a gather that drops out of the ring must be complete before anything
+    // newer runs, or a caller rotating more than kHazardRing buffers could overwrite one behind the guard's back
+    const unsigned recycle = L.hz_next % kHazardRing;
     for (int k = 0; k < kHazardRing; k++)
-      if (L.hz_buf[k] && overlaps(L.hz_buf[k], L.hz_bytes[k], d, n_frames_total)) {
+      if (L.hz_buf[k] && ((unsigned)k == recycle || overlaps(L.hz_buf[k], L.hz_bytes[k], d, n_frames_total))) {
         e = hipStreamWaitEvent(cs, L.hz_ev[k], 0);
         if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(gather -> kernel)");
       }
