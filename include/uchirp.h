@@ -292,7 +292,10 @@ int uc_receive_stream_isr(uc_ctx* ctx, const void* samples, int dtype, size_t n_
  *   n_text  (nullable) characters per stream
  *   trace   (nullable) n_streams x trace_cap records, one per processed block of the stream; n_trace (nullable) how many
  * Every pointer may be host or device memory; with device pointers only, the call is asynchronous on hip_stream.
- * Device memory held by the context: the packed copy of the streams (4 bytes per sample) + 8 bytes per 256 samples.
+ * Without a busy mask, and with streams a multiple of 256 samples apart, nothing is copied: the band kernel runs over the
+ * caller's buffer as it lies (only [2 n zeros | first block] of every stream is staged for the offsets that reach into the
+ * FIFO's initial zeros); otherwise the context holds a packed copy of the streams (4 bytes per sample).  Either way
+ * 8 bytes per 256 samples of statistics.
  */
 int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_streams, size_t n_samples,
                        size_t stream_stride_elems, const uint8_t* busy /*nullable*/, char* text, size_t text_cap,

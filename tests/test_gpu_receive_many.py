@@ -71,6 +71,12 @@ def test_many_streams_equal_one_stream_at_a_time(uchirp, variant):
         assert t2[s] == t1 and np.array_equal(tr2[s].view(np.uint8), tr1.view(np.uint8))
         t1i, tr1i = e.receive(xi[s])
         assert t3[s] == t1i and np.array_equal(tr3[s].view(np.uint8), tr1i.view(np.uint8))
+    # streams NOT a multiple of 256 samples apart (the packed path without a busy mask): the ragged tail is ignored
+    xr = np.concatenate([x[:9], np.full((9, 100), 7.0, np.float32)], axis=1)
+    t4, tr4 = e.receive_many(xr)
+    for s in range(9):
+        t1, tr1 = e.receive(x[s])
+        assert t4[s] == t1 and np.array_equal(tr4[s].view(np.uint8), tr1.view(np.uint8))
     # one stream, a stream shorter than a block, every block dropped, no trace wanted, a tiny text buffer
     t, tr = e.receive_many(x[:1])
     assert t[0] == texts[0] or busy[0].any()

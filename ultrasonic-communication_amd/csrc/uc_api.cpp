@@ -1457,20 +1457,48 @@ extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, siz
       d_acc = (const uint32_t*)c->s_rx_acc.p;
       d_na = (const uint32_t*)c->s_rx_na.p;
     }
-    const size_t pitch = (2 + nb) * (size_t)n;
-    const size_t n_frames = (n_streams * pitch - n) / 256 + 1;
-    if (n_frames >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_receive_streams: %zu frames in one launch (at most 2^31 - 1)", n_frames);
-    int rc = c->s_rx_pad.ensure(n_streams * pitch * 4);
-    if (!rc) rc = c->s_rx_mag.ensure(n_frames * sizeof(float2));
-    if (rc) return rc;
-    const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
-    int lrc = uc::launch_rx_pack(d_in, in_stride, n, (uint32_t)nb, n_streams, d_acc, d_na, c->s_rx_pad.p, pitch, al16, stream);
-    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
-    rc = process_batch_impl(c, c->s_rx_pad.p, dtype, n_frames, 256, nullptr, nullptr, nullptr, (float2*)c->s_rx_mag.p, hip_stream);
-    if (rc) return rc;
+    // No busy mask and streams a multiple of 256 samples apart: NO packed copy.  The band kernel runs over the caller's
+    // buffer as it lies (every 256-sample offset; the frames that straddle two streams are never looked at), and the 16
+    // offsets per stream that reach into the FIFO's 2 n initial zeros come from a second, small launch over
+    // [2 n zeros | first block] of every stream (the pack kernel with ONE block: 3 n words per stream).
+    const bool direct = !busy && (in_stride % 256u) == 0;
+    size_t pitch, n_frames;
+    const float2* d_head = nullptr;
+    if (direct) {
+      const size_t hp = 3 * (size_t)n, nh = (n_streams * hp - n) / 256 + 1;
+      const size_t span = (n_streams - 1) * in_stride + nb * (size_t)n;
+      pitch = in_stride;
+      n_frames = (span - n) / 256 + 1;
+      if (n_frames >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_receive_streams: %zu frames in one launch (at most 2^31 - 1)", n_frames);
+      int rc = c->s_rx_pad.ensure(n_streams * hp * 4);
+      if (!rc) rc = c->s_rx_mag.ensure((n_frames + nh) * sizeof(float2));
+      if (rc) return rc;
+      const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
+      int lrc = uc::launch_rx_pack(d_in, in_stride, n, 1u, n_streams, nullptr, nullptr, c->s_rx_pad.p, hp, al16, stream);
+      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
+      float2* d_mag = (float2*)c->s_rx_mag.p;
+      rc = process_batch_impl(c, c->s_rx_pad.p, dtype, nh, 256, nullptr, nullptr, nullptr, d_mag + n_frames, hip_stream);
+      if (!rc) rc = process_batch_impl(c, d_in, dtype, n_frames, 256, nullptr, nullptr, nullptr, d_mag, hip_stream);
+      if (rc) return rc;
+      d_head = d_mag + n_frames;
+    } else {
+      pitch = (2 + nb) * (size_t)n;
+      n_frames = (n_streams * pitch - n) / 256 + 1;
+      if (n_frames >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_receive_streams: %zu frames in one launch (at most 2^31 - 1)", n_frames);
+      int rc = c->s_rx_pad.ensure(n_streams * pitch * 4);
+      if (!rc) rc = c->s_rx_mag.ensure(n_frames * sizeof(float2));
+      if (rc) return rc;
+      const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
+      int lrc = uc::launch_rx_pack(d_in, in_stride, n, (uint32_t)nb, n_streams, d_acc, d_na, c->s_rx_pad.p, pitch, al16, stream);
+      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
+      rc = process_batch_impl(c, c->s_rx_pad.p, dtype, n_frames, 256, nullptr, nullptr, nullptr, (float2*)c->s_rx_mag.p, hip_stream);
+      if (rc) return rc;
+    }
+    int lrc;
     uc::RxParams rp;
     memset(&rp, 0, sizeof(rp));
     rp.magmax = (const float2*)c->s_rx_mag.p;
+    rp.head = d_head;
     rp.n_streams = n_streams;
     rp.pitch = pitch;
     rp.n = n;

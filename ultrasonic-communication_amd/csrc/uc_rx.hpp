@@ -19,13 +19,19 @@ struct HistLite {  // the members of struct history (receiver/Src/main.c:124-136
 // frame at FIFO offset pos is frame (b n + pos) / 256 of the stride-256 launch
 struct RxReplay {
   typedef HistLite history_t;
-  const float2* magmax;  // (up, down) mag_max of every 256-sample offset of this stream
+  const float2* magmax;  // (up, down) mag_max of every 256-sample offset of this stream's PACKED form (2 n zeros, then the
+                         // accepted blocks): entry g = packed offset 256 g
   size_t n_frames;       // (host replay only: bound of magmax)
   uint32_t n;
   size_t block;          // current accepted block index b
+  // uc_receive_streams without a packed copy: the offsets that reach into the zero prefix (g < head_count = 2 n / 256) come
+  // from a small second launch over [2 n zeros | first block] of every stream, all others straight from the caller's
+  // buffer; `magmax` is then biased so that entry g (g >= head_count) is stream offset 256 g - 2 n.  nullptr: packed form.
+  const float2* head = nullptr;
+  uint32_t head_count = 0;
   UC_HD void dsp(uint32_t pos, HistLite* h, float mag_mean, int updown) const {
     const size_t g = (block * (size_t)n + pos) / 256;
-    const float2 mm = magmax[g];
+    const float2 mm = (head && g < head_count) ? head[g] : magmax[g];
     const float m = updown == UC_UP_CHIRP ? mm.x : mm.y;
     h->mag_max = m;
     h->mag_mean = mag_mean;
@@ -34,9 +40,12 @@ struct RxReplay {
 };
 
 struct RxParams {
-  const float2* magmax;  // device: (up, down) mag_max of every 256-sample offset of the packed buffer
+  const float2* magmax;  // device: (up, down) mag_max of every 256-sample offset of the packed buffer (or, with `head`, of
+                         // the caller's own buffer)
+  const float2* head;    // device or nullptr: the same for [2 n zeros | first block] of every stream, 3 n samples apart
   size_t n_streams;
-  size_t pitch;          // samples per packed stream = (2 + nb) n
+  size_t pitch;          // samples between streams in the buffer `magmax` was computed over: (2 + nb) n packed, else the
+                         // caller's stream stride (a multiple of 256)
   uint32_t n, nb;
   float snr_threshold;
   const uint32_t* acc;   // device or nullptr (no busy mask): [n_streams][nb] indices of the accepted blocks

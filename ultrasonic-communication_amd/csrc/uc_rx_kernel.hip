@@ -11,6 +11,9 @@
 // runs ONE LANE PER STREAM: 64 streams per wave, lanes diverge over the four states.  It is the code of
 // include/uchirp_mainloop.hpp compiled for the device -- the very functions the host replays for uc_receive_stream and
 // that tests/cpp/rx_main.cpp drives one GPU call per frame -- so the three cannot drift apart.
+// Without a busy mask (and streams a multiple of 256 samples apart) nothing is packed: the band kernel runs over the
+// caller's buffer as it lies, and only the 16 offsets per stream that reach into the FIFO's initial zeros come from a small
+// second launch over [2 n zeros | first block] of every stream (uc_api.cpp).
 // Layout of the packed buffer: stream s owns (2 + nb) * n samples at s * pitch: 2 n zeros (fifo_queue starts as 3 n zeros,
 // main.c:94, and the first accepted block lands in its last third), then its ACCEPTED blocks in order, then zeros.
 #include <hip/hip_runtime.h>
@@ -72,6 +75,12 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   if (s >= p.n_streams) return;
   const uint32_t count = p.na ? p.na[s] : p.nb;
   RxReplay rx{p.magmax + s * (p.pitch / 256), 0, p.n, 0};
+  if (p.head) {
+    // unpacked: entry g of `magmax` must be stream offset 256 g - 2 n of THIS stream (never read below g = 2 n / 256)
+    rx.head_count = 2 * p.n / 256;
+    rx.magmax = p.magmax + ((ptrdiff_t)(s * (p.pitch / 256)) - (ptrdiff_t)rx.head_count);
+    rx.head = p.head + s * (3 * (size_t)p.n / 256);
+  }
   uchirp::MainLoop<RxReplay> loop(p.n, p.snr_threshold);
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
