@@ -419,7 +419,9 @@ uc_ctx* uc_group_ctx(uc_group* g, int local); /* the context of local device l (
  * or make a stream of yours wait for its gather with uc_group_wait_gather().
  * Host pointers: the shard is staged through the context (synchronous copy-in), the stream is gathered in a device
  * buffer of the group and copied out; the call then blocks until gathered[l] is complete.
- * All ranks of the communicator must make the same sequence of calls (it is a collective).
+ * All ranks of the communicator must make the same sequence of calls (it is a collective).  A negative return may leave
+ * this rank's part of the step half enqueued (the other ranks then wait in the collective): treat it as fatal for the group
+ * -- uc_group_destroy and rebuild -- not as something to retry.
  */
 int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, size_t n_frames_total,
                            size_t stride_elems, uint8_t* const* gathered, void* const* hip_streams);

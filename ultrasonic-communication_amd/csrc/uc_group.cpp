@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -55,7 +56,10 @@ struct Rccl {
 };
 Rccl g_rccl;
 
+std::mutex g_rccl_mutex;  // (groups may be built from several threads; the table below is filled once)
+
 int load_rccl() {
+  const std::lock_guard<std::mutex> lock(g_rccl_mutex);
   if (g_rccl.handle) return 0;
   // by soname first: a process that already holds an RCCL (PyTorch bundles one with the same soname) gets THAT one back
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
