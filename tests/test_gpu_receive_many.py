@@ -86,6 +86,12 @@ def test_many_streams_equal_one_stream_at_a_time(uchirp, variant):
     assert t == [""] * 4 and all(len(q) == 0 for q in tr)
     t, tr = e.receive_many(x[:8], want_trace=False, text_cap=3)
     assert tr is None and all(len(q) <= 2 for q in t)
+    # more streams than a grid dimension holds (70 000 one-block streams), with and without a busy mask
+    many = np.tile(x[:7, :N], (10000, 1))
+    t, tr = e.receive_many(many, want_trace=False)
+    assert len(t) == 70000 and all(q == "" for q in t)
+    t, tr = e.receive_many(many, busy=np.zeros((70000, 1), np.uint8))
+    assert all(len(q) == 1 for q in tr) and all(q == "" for q in t)
     e.close()
     with pytest.raises(uchirp.UchirpError):
         uchirp.Engine(uchirp.COMPRESS).receive_many(x[:2])

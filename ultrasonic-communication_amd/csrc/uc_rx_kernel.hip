@@ -50,8 +50,9 @@ template <int VEC>
 __global__ __launch_bounds__(kPackThreads) void pack_kernel(const uint32_t* src, size_t src_stride, uint32_t n, uint32_t nb,
                                                             const uint32_t* acc, const uint32_t* na, uint32_t* dst,
                                                             size_t pitch) {
-  const size_t s = blockIdx.y;
-  const uint32_t j = blockIdx.x;  // slot: 0, 1 = the zero prefix, 2 + k = k-th accepted block
+  // (a flat grid: neither the streams nor the blocks of one stream are bounded by the 65 535 of gridDim.y)
+  const size_t s = blockIdx.x / (nb + 2u);
+  const uint32_t j = blockIdx.x % (nb + 2u);  // slot: 0, 1 = the zero prefix, 2 + k = k-th accepted block
   uint32_t* d = dst + s * pitch + (size_t)j * n;
   const uint32_t* from = nullptr;
   if (j >= 2) {
@@ -121,7 +122,7 @@ int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_
 int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, size_t n_streams, const uint32_t* acc,
                    const uint32_t* na, void* dst, size_t pitch, bool aligned16, hipStream_t stream) {
   if (n_streams == 0) return (int)hipSuccess;
-  const dim3 grid(nb + 2, (unsigned)n_streams);
+  const dim3 grid((unsigned)((size_t)(nb + 2) * n_streams));  // < 2^28: the frame count of the launch behind it is 8 x this
   if (aligned16)
     hipLaunchKernelGGL(pack_kernel<4>, grid, dim3(kPackThreads), 0, stream, (const uint32_t*)src, src_stride, n, nb, acc, na,
                        (uint32_t*)dst, pitch);
