@@ -7,8 +7,9 @@
 //                                                       every stream (uc_api.cpp), (up, down) mag_max per offset
 //   while (1) { switch (state) ... }  + resync()     receiver/Src/main.c:417-554, 243-273   -> replay_kernel
 //
-// The switch is sequential per stream and tiny (about thirty words of state, a handful of 8-byte reads per block), so it
-// runs ONE LANE PER STREAM: 64 streams per wave, lanes diverge over the four states.  It is the code of
+// The switch is sequential per stream and tiny (about thirty words of state, a handful of 8-byte reads per block).  Up to
+// 16 Ki streams it runs ONE WAVE PER STREAM (the lanes stage the next block's FIFO statistics in LDS while lane 0 runs the
+// switch out of LDS); beyond that ONE LANE PER STREAM, 64 streams per wave, lanes diverging over the four states.  It is the code of
 // include/uchirp_mainloop.hpp compiled for the device -- the very functions the host replays for uc_receive_stream and
 // that tests/cpp/rx_main.cpp drives one GPU call per frame -- so the three cannot drift apart.
 // Without a busy mask (and streams a multiple of 256 samples apart) nothing is packed: the band kernel runs over the
@@ -111,6 +112,80 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   if (p.n_trace) p.n_trace[s] = nt;
 }
 
+// The same loop, ONE WAVE PER STREAM (up to a few thousand streams: a lane per stream would leave the chip empty and pay a
+// global-memory round trip for every dsp() of the switch, ~1 us per block).  The FIFO of a block spans offsets
+// pos = 0 .. 2 n in steps of 256: seventeen (up, down) records.  The lanes fetch the NEXT block's seventeen into LDS while
+// lane 0 runs the switch over the current block's -- the switch itself never touches global memory.
+struct RxWindow {
+  typedef HistLite history_t;
+  const float2* win;  // LDS: record pos / 256 of the current block
+  __device__ void dsp(uint32_t pos, HistLite* h, float mag_mean, int updown) const {
+    const float2 mm = win[pos >> 8];
+    const float m = updown == UC_UP_CHIRP ? mm.x : mm.y;
+    h->mag_max = m;
+    h->mag_mean = mag_mean;
+    h->snr = (m - mag_mean) / mag_mean;  // main.c:229
+  }
+};
+
+__global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
+  __shared__ float2 win[2][32];
+  const size_t s = blockIdx.x;
+  const int lane = threadIdx.x;
+  const uint32_t count = p.na ? p.na[s] : p.nb;
+  const uint32_t per_block = p.n / 256, span = 2 * per_block + 1;  // 8 offsets per block, 17 per FIFO
+  RxReplay rx{p.magmax + s * (p.pitch / 256), 0, p.n, 0};
+  if (p.head) {
+    rx.head_count = 2 * p.n / 256;
+    rx.magmax = p.magmax + ((ptrdiff_t)(s * (p.pitch / 256)) - (ptrdiff_t)rx.head_count);
+    rx.head = p.head + s * (3 * (size_t)p.n / 256);
+  }
+  auto fetch = [&](uint32_t block) {  // record `lane` of the FIFO at accepted block `block`
+    float2 v = make_float2(0.f, 0.f);
+    if ((uint32_t)lane < span && block < count) {
+      const size_t g = (size_t)block * per_block + (size_t)lane;
+      v = (rx.head && g < rx.head_count) ? rx.head[g] : rx.magmax[g];
+    }
+    return v;
+  };
+  if (lane < 32) win[0][lane] = fetch(0);
+  __syncthreads();
+  uchirp::MainLoop<RxWindow> loop(p.n, p.snr_threshold);
+  char* text = p.text + s * p.text_cap;
+  uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
+  uint32_t ntext = 0, nt = 0;
+  auto put = [&](char ch) {
+    if (ntext + 1 < p.text_cap) text[ntext++] = ch;
+  };
+  for (uint32_t i = 0; i < count; i++) {
+    const float2 next = fetch(i + 1);  // in flight while lane 0 works
+    if (lane == 0) {
+      RxWindow w{win[i & 1]};
+      const uchirp::loop_event le = loop.step(w, put);
+      if (trace && nt < p.trace_cap) {
+        uc_rx_event ev;
+        ev.block = p.acc ? p.acc[s * p.nb + i] : i;
+        ev.sync_position = le.sync_position;
+        ev.state_before = (uint8_t)le.state_before;
+        ev.state_after = (uint8_t)le.state_after;
+        ev.bit = (int8_t)le.bit;
+        ev.reserved = 0;
+        ev.snr_up = le.snr_up;
+        ev.snr_down = le.snr_down;
+        trace[nt] = ev;
+      }
+      nt++;
+    }
+    if (lane < 32) win[(i + 1) & 1][lane] = next;
+    __syncthreads();  // (one wave: an LDS wait, no s_barrier)
+  }
+  if (lane == 0) {
+    text[ntext] = '\0';
+    if (p.n_text) p.n_text[s] = ntext;
+    if (p.n_trace) p.n_trace[s] = nt;
+  }
+}
+
 }  // namespace
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream) {
@@ -132,9 +207,16 @@ int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, 
   return (int)hipGetLastError();
 }
 
+// Up to kWaveStreams streams: a wave per stream (latency: the switch runs out of LDS).  Beyond that a lane per stream (the
+// chip is full either way, and 64 streams share a wave's instruction issue).
+constexpr size_t kWaveStreams = 16384;
+
 int launch_rx_replay(const RxParams& p, hipStream_t stream) {
   if (p.n_streams == 0) return (int)hipSuccess;
-  hipLaunchKernelGGL(replay_kernel, dim3((unsigned)((p.n_streams + 63) / 64)), dim3(64), 0, stream, p);
+  if (p.n_streams <= kWaveStreams && p.n <= 2048)  // (17 FIFO records fit the 32-entry window)
+    hipLaunchKernelGGL(replay_wave_kernel, dim3((unsigned)p.n_streams), dim3(64), 0, stream, p);
+  else
+    hipLaunchKernelGGL(replay_kernel, dim3((unsigned)((p.n_streams + 63) / 64)), dim3(64), 0, stream, p);
   return (int)hipGetLastError();
 }
 
