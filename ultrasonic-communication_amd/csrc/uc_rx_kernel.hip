@@ -129,7 +129,8 @@ struct RxWindow {
 };
 
 __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
-  __shared__ float2 win[2][32];
+  constexpr int kAhead = 8;                      // blocks whose statistics are in flight: a global load takes ~1 us here,
+  __shared__ float2 win[2 * kAhead][32];         // a pass of the switch ~0.15 us
   const size_t s = blockIdx.x;
   const int lane = threadIdx.x;
   const uint32_t count = p.na ? p.na[s] : p.nb;
@@ -148,7 +149,15 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
     }
     return v;
   };
-  if (lane < 32) win[0][lane] = fetch(0);
+  float2 pend[kAhead];
+#pragma unroll
+  for (int k = 0; k < kAhead; k++) pend[k] = fetch((uint32_t)k);
+  if (lane < 32) {
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) win[k][lane] = pend[k];
+  }
+#pragma unroll
+  for (int k = 0; k < kAhead; k++) pend[k] = fetch((uint32_t)(kAhead + k));
   __syncthreads();
   uchirp::MainLoop<RxWindow> loop(p.n, p.snr_threshold);
   char* text = p.text + s * p.text_cap;
@@ -157,26 +166,35 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
   auto put = [&](char ch) {
     if (ntext + 1 < p.text_cap) text[ntext++] = ch;
   };
-  for (uint32_t i = 0; i < count; i++) {
-    const float2 next = fetch(i + 1);  // in flight while lane 0 works
+  for (uint32_t base = 0; base < count; base += kAhead) {
     if (lane == 0) {
-      RxWindow w{win[i & 1]};
-      const uchirp::loop_event le = loop.step(w, put);
-      if (trace && nt < p.trace_cap) {
-        uc_rx_event ev;
-        ev.block = p.acc ? p.acc[s * p.nb + i] : i;
-        ev.sync_position = le.sync_position;
-        ev.state_before = (uint8_t)le.state_before;
-        ev.state_after = (uint8_t)le.state_after;
-        ev.bit = (int8_t)le.bit;
-        ev.reserved = 0;
-        ev.snr_up = le.snr_up;
-        ev.snr_down = le.snr_down;
-        trace[nt] = ev;
+      const uint32_t end = base + kAhead < count ? base + kAhead : count;
+      for (uint32_t i = base; i < end; i++) {
+        RxWindow w{win[i % (2 * kAhead)]};
+        const uchirp::loop_event le = loop.step(w, put);
+        if (trace && nt < p.trace_cap) {
+          uc_rx_event ev;
+          ev.block = p.acc ? p.acc[s * p.nb + i] : i;
+          ev.sync_position = le.sync_position;
+          ev.state_before = (uint8_t)le.state_before;
+          ev.state_after = (uint8_t)le.state_after;
+          ev.bit = (int8_t)le.bit;
+          ev.reserved = 0;
+          ev.snr_up = le.snr_up;
+          ev.snr_down = le.snr_down;
+          trace[nt] = ev;
+        }
+        nt++;
       }
-      nt++;
     }
-    if (lane < 32) win[(i + 1) & 1][lane] = next;
+    // the statistics of blocks base + 8 .. base + 15, requested a whole group of passes ago, go to the half of the ring the
+    // passes above did not read; then the requests for the group after that go out
+    if (lane < 32) {
+#pragma unroll
+      for (int k = 0; k < kAhead; k++) win[(base + kAhead + k) % (2 * kAhead)][lane] = pend[k];
+    }
+#pragma unroll
+    for (int k = 0; k < kAhead; k++) pend[k] = fetch(base + 2 * kAhead + (uint32_t)k);
     __syncthreads();  // (one wave: an LDS wait, no s_barrier)
   }
   if (lane == 0) {
