@@ -19,6 +19,8 @@
 // main.c:94, and the first accepted block lands in its last third), then its ACCEPTED blocks in order, then zeros.
 #include <hip/hip_runtime.h>
 
+#include <new>
+
 #include "../../include/uchirp_mainloop.hpp"
 #include "uc_rx.hpp"
 
@@ -83,7 +85,12 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
     rx.magmax = p.magmax + ((ptrdiff_t)(s * (p.pitch / 256)) - (ptrdiff_t)rx.head_count);
     rx.head = p.head + s * (3 * (size_t)p.n / 256);
   }
-  uchirp::MainLoop<RxReplay> loop(p.n, p.snr_threshold);
+  // main()'s locals live in LDS: the switch indexes history[] and mag_stat[] dynamically, which as a plain local object
+  // would put them in scratch -- a global-memory round trip per access, ~1 us per pass (measured); odd word stride per lane
+  typedef uchirp::MainLoop<RxReplay> Loop;
+  constexpr int kLoopWords = (int)((sizeof(Loop) + 3) / 4) | 1;
+  __shared__ uint32_t loop_mem[64 * kLoopWords];
+  Loop& loop = *new (loop_mem + threadIdx.x * kLoopWords) Loop(p.n, p.snr_threshold);
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
   uint32_t ntext = 0, nt = 0;
@@ -158,8 +165,13 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
   }
 #pragma unroll
   for (int k = 0; k < kAhead; k++) pend[k] = fetch((uint32_t)(kAhead + k));
+  // main()'s locals in LDS, as in replay_kernel (only lane 0 touches them)
+  typedef uchirp::MainLoop<RxWindow> Loop;
+  __shared__ uint32_t loop_mem[(sizeof(Loop) + 3) / 4];
+  Loop* loopp = reinterpret_cast<Loop*>(loop_mem);
+  if (lane == 0) new (loop_mem) Loop(p.n, p.snr_threshold);
   __syncthreads();
-  uchirp::MainLoop<RxWindow> loop(p.n, p.snr_threshold);
+  Loop& loop = *loopp;
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
   uint32_t ntext = 0, nt = 0;
