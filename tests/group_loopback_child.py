@@ -1,0 +1,79 @@
+"""Child process of tests/test_gpu_group_loopback.py: the group logic of uc_group.cpp at world 2 .. 8 on ONE GPU, with the
+loop-back stand-in for RCCL (tests/stubs/loopback_rccl.cpp; UC_TUNING=1 UC_RCCL_LIB=... UC_GROUP_SHARE_DEVICES=1 set by the
+parent).  Every "rank" lives on device 0; each decodes ITS shard of the batch into its slice of its own gathered buffer, the
+loop-back library copies the slices between the ranks' buffers.  Checked against ONE plain context over the whole batch."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
+import numpy as np
+import torch
+import uchirp
+from uchirp import synth
+
+dev = torch.device("cuda", 0)
+N = 2048
+checks = 0
+
+
+def run(variant, kw, flat, n_frames, stride, halo, world, steps=7, dtype=uchirp.DTYPE_F32):
+    """flat: the whole sample buffer on the device (halo samples in front of frame 0)."""
+    global checks
+    n = kw.get("n", N)
+    eng = uchirp.Engine(variant, **kw)
+    want, _ = eng.process(flat, n_frames=n_frames, stride=stride, want_stats=False)
+    torch.cuda.synchronize()
+    g = uchirp.Group(variant, devices=[0] * world, **kw)
+    assert (g.world, g.n_local, g.first_rank) == (world, world, 0)
+    ptrs, keep = [], []
+    for r in range(world):
+        first, count = uchirp.partition(n_frames, world, r)
+        e0, ne = uchirp.frame_span(n, stride, halo, first, count)
+        # the rank holds ITS span only: a private copy, so that a read outside it would hit unrelated memory
+        mine = flat[e0:e0 + ne].clone() if count else flat[:1].clone()
+        keep.append(mine)
+        ptrs.append(mine.data_ptr() + 4 * halo)
+    bufs = [[torch.full((n_frames,), 0x77, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(3)]
+    for k in range(steps):
+        g.process(ptrs, n_frames, bufs[k % 3], stride=stride, dtype=dtype)
+    g.synchronize()
+    for k in range(3):
+        for r in range(world):
+            assert torch.equal(bufs[k][r], want), (variant, world, n_frames, k, r)
+            checks += 1
+    # one buffer per rank reused every step: the write-after-gather guard serialises, results unchanged
+    one = [torch.zeros(n_frames, dtype=torch.uint8, device=dev) for _ in range(world)]
+    for k in range(4):
+        g.process(ptrs, n_frames, one, stride=stride, dtype=dtype)
+    g.synchronize()
+    assert all(torch.equal(o, want) for o in one)
+    g.close()
+    eng.close()
+    return want
+
+
+# configs[4]: the 'Hello World!' stream, sharded; even and ragged shares (the grouped-broadcast path), more ranks than frames
+for world in (2, 3, 8):
+    for nf in (117 * 16, 117 * 16 + 5, 5):
+        frames, _ = synth.device_hello_frames(0, nf, dev, seed=nf + world, snr_db=-10.0)
+        sym = run(uchirp.RX_REAL, dict(mag_mean=1000.0, time_frame=N / 78125.0), frames.reshape(-1), nf, 0, 0, world)
+        if nf >= 117:
+            texts = synth.decode_hello(sym.cpu().numpy(), 12)
+            assert texts and all(t == "Hello World!" for t in texts)
+# overlapping FIFO reads (stride 256): neighbouring shards overlap by n - 256 samples
+flat = synth.device_frames(40, dev, seed=9, snr_db=-3.0)[0].reshape(-1)
+nfr = (flat.numel() - N) // 256 + 1
+for world in (2, 5):
+    run(uchirp.SYNC_CPLX, dict(mag_mean=1000.0), flat, nfr, 256, 0, world)
+# base-band I/Q: 26 samples of FIR history in front of every shard
+BB = dict(n=1024, fs=100000.0, carrier=18000.0, f0=16500.0, f1=19500.0, time_frame=1024 / 1e5, flags=uchirp.FLAG_IQ_BASEBAND,
+          mag_mean=1000.0)
+x, _ = synth.device_iq_stream(999, 1024, dev, seed=4, snr_db=-5.0)
+for world in (2, 4):
+    run(uchirp.IQ, BB, x, 999, 0, 26, world)
+# int32 DFSDM words
+fi = (synth.device_frames(333, dev, seed=2, snr_db=0.0)[0].round().to(torch.int64) * 256).to(torch.int32).reshape(-1)
+run(uchirp.RX_REAL, dict(mag_mean=256000.0, time_frame=N / 78125.0), fi, 333, 0, 0, 3, dtype=uchirp.DTYPE_I32)
+print("loopback ok: %d gathered buffers checked" % checks)

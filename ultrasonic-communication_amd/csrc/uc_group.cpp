@@ -13,6 +13,7 @@
 #include <rccl/rccl.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -40,6 +41,11 @@ int fail(int code, const char* fmt, ...) {
 
 int hip_fail(hipError_t e, const char* what) { return fail(-EIO, "%s: %s", what, hipGetErrorString(e)); }
 
+bool tuning_on() {
+  const char* t = getenv("UC_TUNING");
+  return t && atoi(t) != 0;
+}
+
 // ---- RCCL, loaded on first use ---------------------------------------------------------------------------------------
 struct Rccl {
   void* handle = nullptr;
@@ -64,9 +70,17 @@ int load_rccl() {
   // by soname first: a process that already holds an RCCL (PyTorch bundles one with the same soname) gets THAT one back
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
+  // Rehearsal hook (read only under UC_TUNING=1, like every other experiment switch): another library with the same entry
+  // points.  tests/stubs/loopback_rccl.cpp uses it to run the group logic at world > 1 on ONE GPU (RCCL refuses two ranks
+  // on one device).  Never a measurement.
+  if (tuning_on())
+    if (const char* over = getenv("UC_RCCL_LIB")) {
+      h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+      if (!h) return fail(-ENOSYS, "uc_group: UC_RCCL_LIB=%s: %s", over, dlerror());
+    }
   for (const char* nm : names) {
-    h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
     if (h) break;
+    h = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
   }
   if (!h) return fail(-ENOSYS, "uc_group: librccl.so.1 not found (%s)", dlerror());
   Rccl r;
@@ -244,7 +258,9 @@ int uc_group_create(const uc_config* cfg, const int32_t* devices, int n_devices,
   if (!cfg || !devices || !out) return fail(-EINVAL, "uc_group_create: NULL argument");
   *out = nullptr;
   if (n_devices <= 0 || n_devices > 64) return fail(-EINVAL, "uc_group_create: %d devices", n_devices);
-  for (int a = 0; a < n_devices; a++)
+  // (rehearsal on one GPU, UC_TUNING=1 UC_GROUP_SHARE_DEVICES=1 with the loop-back library: several ranks on one device)
+  const bool share = tuning_on() && getenv("UC_GROUP_SHARE_DEVICES") && atoi(getenv("UC_GROUP_SHARE_DEVICES")) != 0;
+  for (int a = 0; a < n_devices && !share; a++)
     for (int b = a + 1; b < n_devices; b++)
       if (devices[a] == devices[b]) return fail(-EINVAL, "uc_group_create: device %d named twice", (int)devices[a]);
   if (cfg->variant == UC_STREAM) return fail(-ENOTSUP, "uc_group_create: UC_STREAM has no frames (shard it with uc_stream_span)");
