@@ -703,7 +703,10 @@ def single_process(args):
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
     world = args.gpus
-    if torch.cuda.device_count() < world:
+    # UC_BENCH_REHEARSE=1 (with UC_TUNING=1 UC_GROUP_SHARE_DEVICES=1 UC_RCCL_LIB=<tests/stubs/loopback_rccl.cpp built>): every
+    # rank on device 0, the loop-back stand-in for RCCL -- the plumbing of this mode on a one-GPU box, never a measurement
+    rehearse = os.environ.get("UC_BENCH_REHEARSE") == "1"
+    if not rehearse and torch.cuda.device_count() < world:
         raise SystemExit("bench.py --single-process --gpus %d: only %d device(s) visible" % (world, torch.cuda.device_count()))
     import uchirp
     from uchirp import synth
@@ -711,8 +714,8 @@ def single_process(args):
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)                              # RCCL's banner and anything else on descriptor 1 goes to stderr
     nf, mag_mean = args.frames, 1000.0
-    devs = [torch.device("cuda", d) for d in range(world)]
-    grp = uchirp.Group(uchirp.RX_REAL, devices=list(range(world)), mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
+    devs = [torch.device("cuda", 0 if rehearse else d) for d in range(world)]
+    grp = uchirp.Group(uchirp.RX_REAL, devices=[d.index for d in devs], mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
     frames, streams = [], []
     for r, d in enumerate(devs):
         f, _ = synth.device_hello_frames(r * nf, nf, d, seed=1234 + r, snr_db=args.snr, msg=MSG)
@@ -791,6 +794,8 @@ def single_process(args):
            "transmissions_decoded_exactly": good,
            "bit_error_rate_vs_transmitted": float((host[0][m] != data[m]).mean()),
            "gates_failed": gate_failures}
+    if rehearse:
+        out["rehearsal"] = "every rank on device 0, loop-back stand-in for RCCL: plumbing only, not a measurement"
     print(json.dumps(out), file=json_out, flush=True)
     grp.close()
     if gate_failures:

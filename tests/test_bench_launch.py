@@ -134,3 +134,19 @@ def test_gpu_default_line_carries_every_single_gpu_config():
     assert c2["baseband"]["roofline"]["valu"]["clock_source"].startswith("uc_clock_read")
     assert c3["eager"]["roofline"]["valu"]["clock_source"].startswith("uc_clock_read")
     assert d["symbols_equal_oracle_head4096_clear"] == 1.0 and d["cpu_baseline"]["kind"] == "port"
+
+
+@pytest.mark.gpu
+def test_gpu_single_process_three_ranks_rehearsed_on_one_gpu(tmp_path):
+    """`--gpus 3 --single-process` on the one GPU of this box: every rank on device 0, the loop-back stand-in for RCCL
+    (tests/stubs/loopback_rccl.cpp).  Plumbing of the one-host-process mode at N > 1: partition, per-device streams and
+    events, gather, digests, decode, JSON line."""
+    so = str(tmp_path / "libloopback_rccl.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "stubs", "loopback_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64"],
+                          stderr=subprocess.DEVNULL)
+    d = _one_line(_run(["--gpus", "3", "--single-process", "--frames", "35100", "--steps", "4", "--warmup", "1", "--ramp-ms", "10"],
+                       {"UC_BENCH_REHEARSE": "1", "UC_TUNING": "1", "UC_RCCL_LIB": so, "UC_GROUP_SHARE_DEVICES": "1"}))
+    assert d["n_gpus"] == 3 and "rehearsal" in d and d["gates_failed"] == []
+    assert d["transmissions"] == 3 * 35100 // 117 and d["transmissions_decoded_exactly"] == d["transmissions"]
+    assert len(d["per_rank"]["kernel_ms_by_rank"]) == 3
