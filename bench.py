@@ -881,9 +881,13 @@ def main():
     # rendezvous, the barrier and the max-over-ranks of the contract.  If any rank cannot build its group every rank
     # falls back to torch.distributed's all_gather_into_tensor (recorded as `gather_backend`); UC_BENCH_TORCH_GATHER=1
     # selects that path outright.
+    # (UC_BENCH_REHEARSE=1 on a one-GPU box: the group path runs too when the loop-back stand-in for RCCL is named --
+    # UC_TUNING=1 UC_RCCL_LIB=<tests/stubs/loopback_rccl.cpp built> -- otherwise the rehearsal gathers through gloo)
     grp, gather_backend = None, "torch.distributed all_gather_into_tensor"
-    if multi and args.variant == "rx_real" and have_gpu and not rehearse and os.environ.get("UC_BENCH_TORCH_GATHER") != "1":
-        idt = torch.zeros(uchirp.GROUP_ID_BYTES, dtype=torch.uint8, device=device)
+    if (multi and args.variant == "rx_real" and have_gpu and os.environ.get("UC_BENCH_TORCH_GATHER") != "1"
+            and (not rehearse or os.environ.get("UC_RCCL_LIB"))):
+        ctl = torch.device("cpu") if rehearse else device           # where the launcher's own collectives live (gloo / RCCL)
+        idt = torch.zeros(uchirp.GROUP_ID_BYTES, dtype=torch.uint8, device=ctl)
         why = ""
         if rank == 0:
             try:
@@ -899,7 +903,7 @@ def main():
                 ok = 1
             except Exception as ex:
                 why = str(ex)
-        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        flag = torch.tensor([ok], dtype=torch.int32, device=ctl)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
             gather_backend = "uc_group_process_batch: RCCL (ncclAllGather, in place) called from C on the group's gather stream"

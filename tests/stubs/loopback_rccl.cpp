@@ -2,25 +2,55 @@
 // the group logic at world > 1 (partition offsets, in-place all-gather, the ragged broadcast path, several local devices in
 // one ncclGroupStart/End, the write-after-gather guard) can be REHEARSED ON ONE GPU.  RCCL itself refuses two ranks on one
 // device, and this build has no multi-GPU box; the real library is what every shipped path loads (librccl.so.1) -- this
-// one is only ever loaded when a test sets UC_TUNING=1 UC_RCCL_LIB=<this file's .so>.  Single process only (ncclCommInitAll);
-// "ranks" may share a device.  Never a measurement.
+// one is only ever loaded when a test sets UC_TUNING=1 UC_RCCL_LIB=<this file's .so>.  "Ranks" may share a device.  Never a
+// measurement.  Two forms:
+//   one process, several ranks (ncclCommInitAll)       device-to-device copies between the ranks' buffers, stream-ordered
+//   one process per rank (ncclCommInitRank, world > 1)  the slices travel through a POSIX shared-memory segment named by
+//                                                       the unique id; the calls are SYNCHRONOUS (stream synchronise, copy
+//                                                       out, barrier, copy in, barrier) -- good enough to rehearse the
+//                                                       launcher's plumbing, nothing like the real transport
 //
 // Semantics reproduced: collectives are enqueued on the stream each rank names and complete in stream order; a rank's
 // contribution is read when THAT rank's stream reaches the call (an event per rank and collective), so a rank that is late
 // delays the others exactly as a real collective would.  Operations are collected between ncclGroupStart / ncclGroupEnd
 // and issued at ncclGroupEnd, as RCCL does for one thread driving several devices.
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <stdio.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
+#include <atomic>
 #include <vector>
 
 namespace {
 
+// shared segment of the one-process-per-rank form: a sense-reversing barrier, then the payload
+struct Shared {
+  std::atomic<unsigned> arrived, generation;
+  char pad[56];
+  char data[1];
+};
+constexpr size_t kPayload = 64u << 20;  // bytes a collective may move in all
+
 struct Comm {
   int rank, world, device;
-  std::vector<Comm*>* peers;  // all communicators of the clique, by rank
+  std::vector<Comm*>* peers;  // one process: all communicators of the clique, by rank; nullptr in the per-process form
+  Shared* shm = nullptr;
+  char shm_name[40] = {0};
 };
+
+void barrier(Comm* c) {
+  const unsigned gen = c->shm->generation.load();
+  if (c->shm->arrived.fetch_add(1) + 1 == (unsigned)c->world) {
+    c->shm->arrived.store(0);
+    c->shm->generation.fetch_add(1);
+  } else {
+    while (c->shm->generation.load() == gen) usleep(50);
+  }
+}
 
 struct Op {
   int kind;  // 0 all-gather, 1 broadcast
@@ -75,9 +105,35 @@ ncclResult_t issue(const std::vector<Op*>& by_rank) {
   return ncclSuccess;
 }
 
+// one process per rank: synchronous, through the shared segment
+ncclResult_t issue_shared(Op& o) {
+  Comm* c = o.comm;
+  if (hipSetDevice(c->device) != hipSuccess || hipStreamSynchronize(o.stream) != hipSuccess) return ncclUnhandledCudaError;
+  if (o.kind == 0) {
+    if (o.bytes * (size_t)c->world > kPayload) return ncclInvalidArgument;
+    if (hipMemcpy(c->shm->data + (size_t)c->rank * o.bytes, o.send, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    barrier(c);
+    if (hipMemcpy(o.recv, c->shm->data, o.bytes * (size_t)c->world, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  } else {
+    if (o.bytes > kPayload) return ncclInvalidArgument;
+    if (c->rank == o.root && hipMemcpy(c->shm->data, o.send, o.bytes, hipMemcpyDeviceToHost) != hipSuccess) return ncclUnhandledCudaError;
+    barrier(c);
+    if (c->rank != o.root && hipMemcpy(o.recv, c->shm->data, o.bytes, hipMemcpyHostToDevice) != hipSuccess) return ncclUnhandledCudaError;
+  }
+  barrier(c);  // the payload area is free again
+  return ncclSuccess;
+}
+
 ncclResult_t flush() {
   // the k-th operation of every rank belongs to the k-th collective (each rank issues its operations in the same order)
   if (g_ops.empty()) return ncclSuccess;
+  if (g_ops[0].comm->shm) {
+    ncclResult_t rc = ncclSuccess;
+    for (Op& o : g_ops)
+      if (rc == ncclSuccess) rc = issue_shared(o);
+    g_ops.clear();
+    return rc;
+  }
   const int world = g_ops[0].comm->world;
   std::vector<std::vector<Op*>> q((size_t)world);
   for (Op& o : g_ops) {
@@ -101,7 +157,7 @@ ncclResult_t flush() {
 
 ncclResult_t submit(const Op& o) {
   g_ops.push_back(o);
-  if (g_depth == 0) return o.comm->world == 1 ? flush() : ncclInvalidUsage;  // several ranks from one thread need a group
+  if (g_depth == 0) return (o.comm->world == 1 || o.comm->shm) ? flush() : ncclInvalidUsage;  // several ranks from one thread need a group
   return ncclSuccess;
 }
 
@@ -111,7 +167,15 @@ extern "C" {
 
 ncclResult_t ncclGetVersion(int* v) { if (v) *v = 0; return ncclSuccess; }
 const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "loop-back RCCL stand-in: error"; }
-ncclResult_t ncclGetUniqueId(ncclUniqueId* id) { memset(id, 0x5a, sizeof(*id)); return ncclSuccess; }
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
+  memset(id, 0x5a, sizeof(*id));
+  FILE* f = fopen("/dev/urandom", "rb");
+  if (f) {
+    (void)!fread(id->internal, 1, 16, f);
+    fclose(f);
+  }
+  return ncclSuccess;
+}
 
 ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
   auto* peers = new std::vector<Comm*>((size_t)ndev);
@@ -123,19 +187,39 @@ ncclResult_t ncclCommInitAll(ncclComm_t* comms, int ndev, const int* devlist) {
   return ncclSuccess;
 }
 
-ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId, int rank) {
-  if (nranks != 1 || rank != 0) return ncclInvalidUsage;  // one process only: no peers to find
+ncclResult_t ncclCommInitRank(ncclComm_t* comm, int nranks, ncclUniqueId id, int rank) {
   int dev = 0;
   (void)hipGetDevice(&dev);
-  auto* peers = new std::vector<Comm*>(1);
-  Comm* c = new Comm{0, 1, dev, peers};
-  (*peers)[0] = c;
+  if (nranks == 1) {
+    auto* peers = new std::vector<Comm*>(1);
+    Comm* c = new Comm{0, 1, dev, peers};
+    (*peers)[0] = c;
+    *comm = reinterpret_cast<ncclComm_t>(c);
+    return ncclSuccess;
+  }
+  Comm* c = new Comm{rank, nranks, dev, nullptr};
+  snprintf(c->shm_name, sizeof(c->shm_name), "/uc_lb_%02x%02x%02x%02x%02x%02x%02x%02x", (unsigned char)id.internal[0],
+           (unsigned char)id.internal[1], (unsigned char)id.internal[2], (unsigned char)id.internal[3],
+           (unsigned char)id.internal[4], (unsigned char)id.internal[5], (unsigned char)id.internal[6], (unsigned char)id.internal[7]);
+  const int fd = shm_open(c->shm_name, O_CREAT | O_RDWR, 0600);
+  if (fd < 0 || ftruncate(fd, (off_t)(sizeof(Shared) + kPayload)) != 0) { delete c; return ncclSystemError; }
+  void* m = mmap(nullptr, sizeof(Shared) + kPayload, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+  close(fd);
+  if (m == MAP_FAILED) { delete c; return ncclSystemError; }
+  c->shm = static_cast<Shared*>(m);  // (a fresh segment is all zeros: the barrier starts at generation 0)
+  barrier(c);                        // everybody has mapped it
+  if (rank == 0) shm_unlink(c->shm_name);
   *comm = reinterpret_cast<ncclComm_t>(c);
   return ncclSuccess;
 }
 
 ncclResult_t ncclCommDestroy(ncclComm_t comm) {
   Comm* c = reinterpret_cast<Comm*>(comm);
+  if (c->shm) {
+    munmap(c->shm, sizeof(Shared) + kPayload);
+    delete c;
+    return ncclSuccess;
+  }
   (*c->peers)[(size_t)c->rank] = nullptr;
   bool last = true;
   for (Comm* p : *c->peers) last = last && p == nullptr;

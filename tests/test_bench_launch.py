@@ -143,10 +143,27 @@ def test_gpu_single_process_three_ranks_rehearsed_on_one_gpu(tmp_path):
     events, gather, digests, decode, JSON line."""
     so = str(tmp_path / "libloopback_rccl.so")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                           os.path.join(ROOT, "tests", "stubs", "loopback_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64"],
+                           os.path.join(ROOT, "tests", "stubs", "loopback_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"],
                           stderr=subprocess.DEVNULL)
     d = _one_line(_run(["--gpus", "3", "--single-process", "--frames", "35100", "--steps", "4", "--warmup", "1", "--ramp-ms", "10"],
                        {"UC_BENCH_REHEARSE": "1", "UC_TUNING": "1", "UC_RCCL_LIB": so, "UC_GROUP_SHARE_DEVICES": "1"}))
     assert d["n_gpus"] == 3 and "rehearsal" in d and d["gates_failed"] == []
     assert d["transmissions"] == 3 * 35100 // 117 and d["transmissions_decoded_exactly"] == d["transmissions"]
     assert len(d["per_rank"]["kernel_ms_by_rank"]) == 3
+
+
+@pytest.mark.gpu
+def test_gpu_two_ranks_through_the_c_group_rehearsed_on_one_gpu(tmp_path):
+    """`--gpus 2` exactly as the driver's launcher runs it -- two processes, the unique id carried by torch.distributed,
+    uc_group_create_rank in every rank, every step decoded into the rank's slice and gathered through the group -- on the one
+    GPU of this box: both ranks on device 0, gloo as the launcher's backend, the loop-back stand-in as the group's RCCL
+    (shared-memory form).  The code path of the 8-GPU run, minus the real transport."""
+    so = str(tmp_path / "libloopback_rccl.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "stubs", "loopback_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"],
+                          stderr=subprocess.DEVNULL)
+    d = _one_line(_run(["--gpus", "2", "--frames", "65520", "--steps", "4", "--warmup", "1", "--ramp-ms", "10"],
+                       {"UC_BENCH_REHEARSE": "1", "UC_TUNING": "1", "UC_RCCL_LIB": so}))
+    assert d["n_gpus"] == 2 and d["gather_backend"].startswith("uc_group_process_batch") and d["gates_failed"] == []
+    assert d["transmissions"] == 2 * 65520 // 117 and d["transmissions_decoded_exactly"] == d["transmissions"]
+    assert d["decoded_text_first"] == "Hello World!" and len(d["per_rank"]["kernel_ms_by_rank"]) == 2

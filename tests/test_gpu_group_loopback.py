@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_group_logic_at_world_2_to_8_on_one_gpu(tmp_path):
     so = str(tmp_path / "libloopback_rccl.so")
     subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                           os.path.join(ROOT, "tests", "stubs", "loopback_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64"],
+                           os.path.join(ROOT, "tests", "stubs", "loopback_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"],
                           stderr=subprocess.DEVNULL)
     env = dict(os.environ, UC_TUNING="1", UC_RCCL_LIB=so, UC_GROUP_SHARE_DEVICES="1")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "group_loopback_child.py")], env=env, capture_output=True,
