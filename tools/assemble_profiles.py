@@ -17,6 +17,17 @@ with open("%s/%s_kernel_stats.csv" % (dst, tag), "w", newline="") as f:
     w.writerow(rows[0])
     for r in rows[1:16]:
         w.writerow(r)
+if os.path.exists("%s/headline_kernel_stats.csv" % src):   # the contract leg alone (tools/profile_round.sh)
+    hr = list(csv.reader(open("%s/headline_kernel_stats.csv" % src)))
+    with open("%s/%s_headline_kernel_stats.csv" % (dst, tag), "w", newline="") as f:
+        w = csv.writer(f, quoting=csv.QUOTE_ALL)
+        w.writerow(hr[0])
+        for r in hr[1:8]:
+            w.writerow(r)
+    open("%s/%s_headline_bench.json" % (dst, tag), "w").write(open("%s/headline.json" % src).read().strip().splitlines()[-1] + "\n")
+    hb = json.loads(open("%s/%s_headline_bench.json" % (dst, tag)).read())
+    print("headline alone: rocprofv3 average of %s = %.4f ms over %s launches (incl. ramp + warm-up); bench kernel_ms (HIP events, "
+          "timed steps) = %.4f ms" % (hr[1][0][:60], float(hr[1][3]) / 1e6, hr[1][1], hb["roofline"]["kernel_ms"]))
 with open("%s/%s_variants_kernel_stats.csv" % (dst, tag), "w", newline="") as f:
     w = csv.writer(f, quoting=csv.QUOTE_ALL)
     w.writerow(["variant"] + rows[0])

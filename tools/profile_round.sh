@@ -19,6 +19,11 @@ mkdir -p "$out"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/bench" -- python3 bench.py > "$out/bench.json" 2> "$out/bench.err"
 cp "$(find "$out/bench" -name '*kernel_stats.csv' | head -1)" "$out/bench_kernel_stats.csv"
 echo "bench done"; head -c 400 "$out/bench.json"; echo
+# the contract leg ALONE (configs[1]; no side legs: since round 4 the receive leg launches the same band kernel over other
+# batch sizes, which would mix into its average): the rocprofv3 average of band_kernel<0,1,3> here is what bench.py's
+# roofline.kernel_ms (HIP events) must agree with
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/headline" -- python3 bench.py --no-configs --no-hello1 --no-receive --no-cpu-baseline > "$out/headline.json" 2> "$out/headline.err"
+cp "$(find "$out/headline" -name '*kernel_stats.csv' | head -1)" "$out/headline_kernel_stats.csv"
 for v in sync_cplx compress dechirp_down iq iq_bb iq1024 iq1024_bb stream; do
   rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$v" -- python3 bench.py --variant $v > "$out/$v.json" 2> "$out/$v.err"
   cp "$(find "$out/$v" -name '*kernel_stats.csv' | head -1)" "$out/${v}_kernel_stats.csv"
