@@ -526,8 +526,11 @@ def receive_leg(args, device, torch):
            "blocks_per_stream": nb, "real_time_blocks_per_s_per_stream": fs / N}
     L = uchirp.lib()
     stream = torch.cuda.current_stream(device)
-    for ns, var, name in ((4096, uchirp.SYNC_CPLX, "sync_cplx_4096_streams"), (4096, uchirp.RX_REAL, "rx_real_4096_streams"),
-                          (64, uchirp.RX_REAL, "rx_real_64_streams"), (1, uchirp.RX_REAL, "rx_real_1_stream")):
+    # (the complex-reference receiver -- the variant whose state machine decodes the whole text; its DSP launches
+    # are band_kernel<sync_cplx>, so the rocprofv3 average of the HEADLINE kernel over this command stays the contract leg's.
+    # The shipping real-reference receiver runs the same call at twice the rate: profiles/r04_receive_many.txt)
+    for ns, var, name in ((4096, uchirp.SYNC_CPLX, "sync_cplx_4096_streams"), (64, uchirp.SYNC_CPLX, "sync_cplx_64_streams"),
+                          (1, uchirp.SYNC_CPLX, "sync_cplx_1_stream")):
         g = torch.Generator(device=device)
         g.manual_seed(ns)
         x = torch.randn((ns, nb * N), generator=g, device=device) * 50.0
@@ -1186,9 +1189,10 @@ def main():
             t_c = time.perf_counter()
             try:
                 rx = receive_leg(args, device, torch)
-                if rx["sync_cplx_4096_streams"]["streams_decoding_the_text"] != 4096:
-                    gate_failures.append("receive: %d of 4096 streams decode the text (complex reference)"
-                                         % rx["sync_cplx_4096_streams"]["streams_decoding_the_text"])
+                for key in ("sync_cplx_4096_streams", "sync_cplx_64_streams", "sync_cplx_1_stream"):
+                    if rx[key]["streams_decoding_the_text"] != rx[key]["streams"]:
+                        gate_failures.append("receive: %d of %d streams decode the text"
+                                             % (rx[key]["streams_decoding_the_text"], rx[key]["streams"]))
             except Exception as ex:
                 rx = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
                 gate_failures.append("receive failed: %s" % type(ex).__name__)
