@@ -122,7 +122,8 @@ struct uc_ctx {
   bool cic_tickets = false;
   int compress_chunk = 8;   // (env UC_COMPRESS_CHUNK) frame pairs per hand-out chunk of the compress kernel: a power of two >= 2
   int stream_chunk = 2;     // (env UC_STREAM_CHUNK) blocks per hand-out chunk of the stream kernel: a power of two
-  int iq_group = 32;        // (env UC_IQ_GROUP) frames per hand-out group of the IQ kernels: a power of two <= 64
+  int iq_group = 16;        // (env UC_IQ_GROUP) frames per hand-out group of the IQ kernels: a power of two <= 64
+                            // (16: +0.6 ... 1.2 % over 32 on all three IQ kernels, profiles/r04_knob_sweep.txt)
   unsigned iq_stagger = 0;  // (env UC_IQ_STAGGER, MFMA FIR only) start delay of every second wave on a SIMD, x 4096 clocks
   // UC_IQ at n = 1024, env UC_IQ_FIR=mfma: the FIR as v_mfma_f32_16x16x4_f32 Toeplitz tiles instead of packed VALU.
   // Off by default: an f32 MFMA and the partner wave's packed-f32 VALU do not overlap on a SIMD (tools/mfma_valu_probe.hip:
