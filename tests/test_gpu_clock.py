@@ -83,8 +83,10 @@ def test_stamped_twin_of_the_stream_and_sinc5_kernels(uchirp):
     e.clock_probe(True)
     o1 = e.dfsdm(pdm)
     clk = e.clock_read()
+    assert e.clock_stamps().shape[0] == clk["waves"] or e.clock_stamps().shape[0] > clk["waves"]
     e.clock_probe(False)
     torch.cuda.synchronize()
     assert torch.equal(o0, o1)
     _check_clock(clk, "sinc5")
+    assert clk["waves"] % 16 == 0 and clk["waves"] >= 16        # sixteen waves per workgroup stamp (1024 threads)
     e.close()

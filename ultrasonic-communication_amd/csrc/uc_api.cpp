@@ -1103,7 +1103,7 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   if (c->clock_probe) {
     if (c->clk_cic_blocks == 0) c->clk_cic_blocks = uc::clk::sinc5_max_blocks_per_cu();  // (the twin needs the same LDS opt-in)
     if (c->clk_cic_blocks <= 0) return fail(-ENOMEM, "uc_dfsdm_sinc5: the clock-stamped kernel's LDS tables do not fit");
-    if (int crc = clock_buffer(c, grid, 4, stream, &cp.debug)) return crc;
+    if (int crc = clock_buffer(c, grid, uc::clk::sinc5_waves_per_block(), stream, &cp.debug)) return crc;
   }
   int lrc = (c->clock_probe ? uc::clk::launch_sinc5 : uc::launch_sinc5)(cp, (int)grid, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "sinc5 kernel launch");

@@ -259,6 +259,7 @@ int sinc5_max_blocks_per_cu() {
 }
 
 int sinc5_tile_outputs() { return kTileOut * (TC / 64); }
+int sinc5_waves_per_block() { return TC / 64; }
 
 UC_LAUNCH_END
 

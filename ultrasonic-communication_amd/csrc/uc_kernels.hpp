@@ -142,6 +142,7 @@ struct CicParams {
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
 int sinc5_max_blocks_per_cu();
 int sinc5_tile_outputs();
+int sinc5_waves_per_block();
 
 // ---- the clock-stamped twin of every kernel (diagnostic, shipped, costs nothing when off) ----------------------------
 // Every .hip file is compiled TWICE into libuchirp.so: once as it is, once with -DUC_CLOCKSTAMP (Makefile: csrc/*.clk.o),
@@ -168,6 +169,7 @@ int stream_max_blocks_per_cu(int dtype, int decim);
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
 int sinc5_max_blocks_per_cu();
 int sinc5_tile_outputs();
+int sinc5_waves_per_block();
 }  // namespace clk
 
 }  // namespace uc
