@@ -35,7 +35,7 @@ for k in ORDER:
     row = [NAMES[k], "%g" % alg, instr, "%.4f" % e["hbm_over_algorithmic"], fmt(ghz or None, "%.2f GHz"), fmt(rate, "%.3g"),
            fmt(valu, "%.2f"), fmt(hbm, "%.2f"), waves]
     if md:
-        big = 7 if (valu or 0) >= (hbm or 0) else 8
+        big = 6 if (valu or 0) >= (hbm or 0) else 7
         if row[big] != "—":
             row[big] = "**%s**" % row[big]
         print("| " + " | ".join(row) + " |")
