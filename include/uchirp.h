@@ -303,6 +303,24 @@ int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_str
                        uint32_t* n_trace /*nullable*/, void* hip_stream);
 
 /*
+ * Live streams: the firmware does not process recordings -- its ISR appends a block every 26.2 ms and main() makes one pass
+ * of its switch per block, for ever (receiver/Src/main.c:417-578, 659-668).  A uc_rx_state holds, on the device, what n_streams
+ * such receivers carry from one block to the next: the FIFO's last two accepted blocks and main()'s locals (mag_stat[],
+ * history[], state, sync_position, the byte being assembled ...).  uc_receive_streams_next() is uc_receive_streams() for the
+ * NEXT n_samples (whole blocks) of every stream: the chunks of a stream, of any sizes, give exactly the text and trace of the
+ * whole stream in one call (trace records carry stream-global block indices; `text` receives the characters decoded during
+ * THIS call).  busy as in uc_receive_streams (flags of this chunk's blocks).  A state belongs to the context that made it.
+ */
+typedef struct uc_rx_state uc_rx_state;
+int uc_rx_state_create(uc_ctx* ctx, size_t n_streams, uc_rx_state** out);   /* every receiver at power-on */
+int uc_rx_state_reset(uc_rx_state* st, void* hip_stream);                   /* back to power-on */
+void uc_rx_state_destroy(uc_rx_state* st);
+int uc_receive_streams_next(uc_ctx* ctx, uc_rx_state* st, const void* samples, int dtype, size_t n_samples,
+                            size_t stream_stride_elems, const uint8_t* busy /*nullable*/, char* text, size_t text_cap,
+                            uint32_t* n_text /*nullable*/, uc_rx_event* trace /*nullable*/, size_t trace_cap,
+                            uint32_t* n_trace /*nullable*/, void* hip_stream);
+
+/*
  * UC_STREAM -- BASELINE config 4: streaming FIR-LPF decimate front-end + overlap-save
  * frequency-domain chirp compression over ONE continuous real sample stream x[r].
  *

@@ -130,3 +130,58 @@ def test_a_thousand_random_transmissions_with_dropped_blocks_against_the_oracle(
         e.close()
     print("1000 transmissions: %d failures, %d near-threshold divergences, oracle decoded the text in %d" % (bad, soft, decoded))
     assert bad == 0 and soft <= 10 and decoded >= 300
+
+
+@pytest.mark.parametrize("variant", [uco.SYNC_CPLX, uco.RX_REAL])
+def test_live_streams_chunk_after_chunk_equal_the_whole_stream(uchirp, variant):
+    """uc_rx_state / uc_receive_streams_next: the firmware's own mode of operation -- blocks arrive for ever.  A stream cut
+    into chunks of ANY sizes (one block at a time included) gives the text and the trace of the whole stream in one call,
+    bit for bit: the FIFO's last two accepted blocks and main()'s locals travel in the state.  With and without dropped
+    blocks (the packed and the copy-free path), float32 and int32 words, device-resident chunks."""
+    import torch
+    x, busy, msgs = _transmissions(40, seed=31 + variant, blocks=150)
+    e = uchirp.Engine(variant)
+    rng = np.random.default_rng(9)
+    for use_busy, data in ((True, x), (False, x), (False, (np.round(x).astype(np.int64) * 256).astype(np.int32))):
+        bz = busy if use_busy else None
+        whole_t, whole_tr = e.receive_many(data, busy=bz)
+        for sizes in ([1] * 150, [150], [7, 1, 1, 60, 2, 79], list(rng.integers(1, 12, size=60))):
+            sizes = list(sizes)
+            while sum(sizes) > 150:
+                sizes.pop()
+            if sum(sizes) < 150:
+                sizes.append(150 - sum(sizes))
+            live = e.live(data.shape[0])
+            texts = [""] * data.shape[0]
+            traces = [[] for _ in range(data.shape[0])]
+            b0 = 0
+            for k, nb in enumerate(sizes):
+                chunk = np.ascontiguousarray(data[:, b0 * N:(b0 + nb) * N])
+                cb = None if bz is None else np.ascontiguousarray(bz[:, b0:b0 + nb])
+                arg = torch.from_numpy(chunk).to("cuda:0") if (k % 3 == 1) else chunk
+                t, tr = live.next(arg, busy=cb)
+                for s in range(data.shape[0]):
+                    texts[s] += t[s]
+                    traces[s].append(tr[s])
+                b0 += nb
+            for s in range(data.shape[0]):
+                assert texts[s] == whole_t[s], (s, sizes[:6])
+                got = np.concatenate(traces[s]) if traces[s] else np.zeros(0, whole_tr[s].dtype)
+                assert np.array_equal(got.view(np.uint8), whole_tr[s].view(np.uint8)), (s, sizes[:6])
+            live.close()
+    # reset = power-on again; a state is tied to its context and its stream count; partial blocks are refused
+    live = e.live(3)
+    t1, _ = live.next(x[:3, :40 * N])
+    live.reset()
+    t2, tr2 = live.next(x[:3, :40 * N])
+    assert t1 == t2 and tr2[0]["block"][0] == 0
+    with pytest.raises(uchirp.UchirpError):
+        live.next(x[:3, :N + 5])
+    with pytest.raises(ValueError):
+        live.next(x[:4, :N])
+    other = uchirp.Engine(variant)
+    with pytest.raises(uchirp.UchirpError):
+        other.receive_many(x[:3, :N], _state=live)
+    live.close()
+    other.close()
+    e.close()

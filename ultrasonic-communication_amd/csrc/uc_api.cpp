@@ -1374,10 +1374,21 @@ extern "C" int uc_receive_stream(uc_ctx* c, const void* samples, int dtype, size
 // launch over every 256-sample offset of every stream, main()'s switch replayed on the device, one lane per stream
 // (csrc/uc_rx_kernel.hip: include/uchirp_mainloop.hpp compiled for the device).
 // ---------------------------------------------------------------------------
-extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, size_t n_streams, size_t n_samples,
-                                  size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
-                                  uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
-                                  void* hip_stream) {
+// live streams: what n_streams receivers carry from one call to the next, on the device
+struct uc_rx_state {
+  uc_ctx* c = nullptr;
+  size_t n_streams = 0;
+  uint32_t* d_tail = nullptr;  // [n_streams][2 n] words: the last two ACCEPTED blocks of every stream (the FIFO minus the
+                               // block the next call appends); zeros at power-on (fifo_queue, main.c:94)
+  uint32_t* d_loop = nullptr;  // [n_streams][rx_loop_words()]: main()'s locals (main.c:314-339)
+  uint64_t blocks_seen = 0;    // blocks of every stream offered so far
+  int dtype = -1;              // of the words in d_tail (the first call decides)
+};
+
+static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples, int dtype, size_t n_streams, size_t n_samples,
+                                size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
+                                uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
+                                void* hip_stream) {
   if (!c || !text || text_cap == 0) return fail(-EINVAL, "uc_receive_streams: NULL argument");
   if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX)
     return fail(-ENOTSUP, "uc_receive_streams: variant %d has no up/down state machine", (int)c->cfg.variant);
@@ -1390,6 +1401,13 @@ extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, siz
   const size_t nb = n_samples / n;
   if (nb >= ((size_t)1 << 31) / 8 || text_cap >= ((size_t)1 << 31) || trace_cap >= ((size_t)1 << 31))
     return fail(-EINVAL, "uc_receive_streams: stream too long");
+  if (st) {
+    if (n_samples % n != 0) return fail(-EINVAL, "uc_receive_streams_next: %zu samples are not whole blocks of %u", n_samples, n);
+    if (st->dtype >= 0 && st->dtype != dtype && st->blocks_seen)
+      return fail(-EINVAL, "uc_receive_streams_next: the streams began as dtype %d", st->dtype);
+    if (st->blocks_seen + nb >= ((uint64_t)1 << 32)) return fail(-EOVERFLOW, "uc_receive_streams_next: 2^32 blocks per stream");
+  }
+  const void* d_prefix = st ? st->d_tail : nullptr;
   if (trace && trace_cap == 0) trace = nullptr;
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -1475,7 +1493,7 @@ extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, siz
       if (!rc) rc = c->s_rx_mag.ensure((n_frames + nh) * sizeof(float2));
       if (rc) return rc;
       const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
-      int lrc = uc::launch_rx_pack(d_in, in_stride, n, 1u, n_streams, nullptr, nullptr, c->s_rx_pad.p, hp, al16, stream);
+      int lrc = uc::launch_rx_pack(d_in, in_stride, n, 1u, n_streams, nullptr, nullptr, d_prefix, c->s_rx_pad.p, hp, al16, stream);
       if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
       float2* d_mag = (float2*)c->s_rx_mag.p;
       rc = process_batch_impl(c, c->s_rx_pad.p, dtype, nh, 256, nullptr, nullptr, nullptr, d_mag + n_frames, hip_stream);
@@ -1490,7 +1508,8 @@ extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, siz
       if (!rc) rc = c->s_rx_mag.ensure(n_frames * sizeof(float2));
       if (rc) return rc;
       const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
-      int lrc = uc::launch_rx_pack(d_in, in_stride, n, (uint32_t)nb, n_streams, d_acc, d_na, c->s_rx_pad.p, pitch, al16, stream);
+      int lrc = uc::launch_rx_pack(d_in, in_stride, n, (uint32_t)nb, n_streams, d_acc, d_na, d_prefix, c->s_rx_pad.p, pitch, al16,
+                                   stream);
       if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
       rc = process_batch_impl(c, c->s_rx_pad.p, dtype, n_frames, 256, nullptr, nullptr, nullptr, (float2*)c->s_rx_mag.p, hip_stream);
       if (rc) return rc;
@@ -1513,8 +1532,19 @@ extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, siz
     rp.trace = d_trace;
     rp.trace_cap = (uint32_t)trace_cap;
     rp.n_trace = d_ntrace;
+    rp.loop_state = st ? st->d_loop : nullptr;
+    rp.block_base = st ? (uint32_t)st->blocks_seen : 0u;
     lrc = uc::launch_rx_replay(rp, stream);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
+    if (st) {
+      // what the FIFO keeps for the next call: the last two ACCEPTED blocks of every stream
+      if (!direct) lrc = uc::launch_rx_tail(c->s_rx_pad.p, pitch, d_na, (uint32_t)nb, n, n_streams, st->d_tail, stream);
+      else if (nb >= 2) lrc = uc::launch_rx_tail(d_in, in_stride, nullptr, (uint32_t)(nb - 2), n, n_streams, st->d_tail, stream);
+      else lrc = uc::launch_rx_tail(c->s_rx_pad.p, 3 * (size_t)n, nullptr, 1u, n, n_streams, st->d_tail, stream);
+      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx tail kernel launch");
+      st->blocks_seen += nb;
+      st->dtype = dtype;
+    }
   }
   if (host_out) {
     if (d_text != text) e = hipMemcpyAsync(text, d_text, n_streams * text_cap, hipMemcpyDeviceToHost, stream);
@@ -1528,4 +1558,76 @@ extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, siz
     if (e != hipSuccess) return hip_fail(e, "uc_receive_streams: copy back");
   }
   return 0;
+}
+
+extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, size_t n_streams, size_t n_samples,
+                                  size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
+                                  uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
+                                  void* hip_stream) {
+  return receive_streams_impl(c, nullptr, samples, dtype, n_streams, n_samples, stream_stride_elems, busy, text, text_cap, n_text,
+                              trace, trace_cap, n_trace, hip_stream);
+}
+
+// ---- live streams: the same call, chunk after chunk ----------------------------------------------------------------
+extern "C" void uc_rx_state_destroy(uc_rx_state* st) {
+  if (!st) return;
+  if (st->c) (void)hipSetDevice(st->c->device);
+  if (st->d_tail) (void)hipFree(st->d_tail);
+  if (st->d_loop) (void)hipFree(st->d_loop);
+  delete st;
+}
+
+extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
+  if (!st) return fail(-EINVAL, "uc_rx_state_reset: NULL state");
+  uc_ctx* c = st->c;
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  e = hipMemsetAsync(st->d_tail, 0, st->n_streams * 2 * (size_t)c->cfg.n * 4, stream);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(FIFO tails)");
+  const int lrc = uc::launch_rx_state_init(st->d_loop, st->n_streams, c->cfg.n, c->cfg.snr_threshold, stream);
+  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx state init kernel launch");
+  st->blocks_seen = 0;
+  st->dtype = -1;
+  return 0;
+}
+
+extern "C" int uc_rx_state_create(uc_ctx* c, size_t n_streams, uc_rx_state** out) {
+  if (!c || !out) return fail(-EINVAL, "uc_rx_state_create: NULL argument");
+  *out = nullptr;
+  if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX)
+    return fail(-ENOTSUP, "uc_rx_state_create: variant %d has no up/down state machine", (int)c->cfg.variant);
+  if (n_streams == 0) return fail(-EINVAL, "uc_rx_state_create: no streams");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  uc_rx_state* st = new (std::nothrow) uc_rx_state();
+  if (!st) return fail(-ENOMEM, "uc_rx_state_create: out of memory");
+  st->c = c;
+  st->n_streams = n_streams;
+  e = hipMalloc((void**)&st->d_tail, n_streams * 2 * (size_t)c->cfg.n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&st->d_loop, n_streams * (size_t)uc::rx_loop_words() * 4);
+  if (e != hipSuccess) {
+    uc_rx_state_destroy(st);
+    return hip_fail(e, "hipMalloc(rx state)");
+  }
+  int rc = uc_rx_state_reset(st, nullptr);
+  if (!rc) {
+    e = hipStreamSynchronize(nullptr);
+    if (e != hipSuccess) rc = hip_fail(e, "hipStreamSynchronize");
+  }
+  if (rc) {
+    uc_rx_state_destroy(st);
+    return rc;
+  }
+  *out = st;
+  return 0;
+}
+
+extern "C" int uc_receive_streams_next(uc_ctx* c, uc_rx_state* st, const void* samples, int dtype, size_t n_samples,
+                                       size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
+                                       uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
+                                       void* hip_stream) {
+  if (!st || st->c != c) return fail(-EINVAL, "uc_receive_streams_next: the state belongs to another context");
+  return receive_streams_impl(c, st, samples, dtype, st->n_streams, n_samples, stream_stride_elems, busy, text, text_cap, n_text,
+                              trace, trace_cap, n_trace, hip_stream);
 }

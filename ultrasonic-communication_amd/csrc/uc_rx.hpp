@@ -56,11 +56,23 @@ struct RxParams {
   uc_rx_event* trace;    // device or nullptr: [n_streams][trace_cap]
   uint32_t trace_cap;
   uint32_t* n_trace;     // device or nullptr
+  // live streams (uc_rx_state): main()'s locals of every stream between calls, rx_loop_words() words each -- loaded at the
+  // start of the replay and stored back at its end; nullptr = a recorded stream (the locals start as at power-on)
+  uint32_t* loop_state;
+  uint32_t block_base;   // blocks of every stream the earlier calls have seen (trace records carry stream-global indices)
 };
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);
+// prefix: device or nullptr -- what the first 2 n words of every packed stream are (2 n words per stream: the FIFO's tail
+// of the previous call); nullptr = zeros (a stream that starts here)
 int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, size_t n_streams, const uint32_t* acc,
-                   const uint32_t* na, void* dst, size_t pitch, bool aligned16, hipStream_t stream);
+                   const uint32_t* na, const void* prefix, void* dst, size_t pitch, bool aligned16, hipStream_t stream);
 int launch_rx_replay(const RxParams& p, hipStream_t stream);
+// live streams: words of main()'s locals per stream; their power-on image; the FIFO tail a call leaves behind --
+// tail[s] = 2 n words of `base` at s * pitch + (na ? na[s] : off_blocks) * n
+int rx_loop_words();
+int launch_rx_state_init(uint32_t* loop_state, size_t n_streams, uint32_t n, float snr_threshold, hipStream_t stream);
+int launch_rx_tail(const void* base, size_t pitch, const uint32_t* na, uint32_t off_blocks, uint32_t n, size_t n_streams,
+                   void* tail, hipStream_t stream);
 
 }  // namespace uc

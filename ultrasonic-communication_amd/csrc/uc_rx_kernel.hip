@@ -51,8 +51,8 @@ __global__ __launch_bounds__(64) void accept_kernel(const uint8_t* busy, uint32_
 // 16-byte aligned, else 1)
 template <int VEC>
 __global__ __launch_bounds__(kPackThreads) void pack_kernel(const uint32_t* src, size_t src_stride, uint32_t n, uint32_t nb,
-                                                            const uint32_t* acc, const uint32_t* na, uint32_t* dst,
-                                                            size_t pitch) {
+                                                            const uint32_t* acc, const uint32_t* na, const uint32_t* prefix,
+                                                            uint32_t* dst, size_t pitch) {
   // (a flat grid: neither the streams nor the blocks of one stream are bounded by the 65 535 of gridDim.y)
   const size_t s = blockIdx.x / (nb + 2u);
   const uint32_t j = blockIdx.x % (nb + 2u);  // slot: 0, 1 = the zero prefix, 2 + k = k-th accepted block
@@ -62,6 +62,8 @@ __global__ __launch_bounds__(kPackThreads) void pack_kernel(const uint32_t* src,
     const uint32_t k = j - 2;
     const uint32_t count = na ? na[s] : nb;
     if (k < count) from = src + s * src_stride + (size_t)(acc ? acc[s * nb + k] : k) * n;
+  } else if (prefix) {
+    from = prefix + s * 2 * (size_t)n + (size_t)j * n;  // a live stream: the FIFO as the previous call left it
   }
   if (VEC == 4) {
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
@@ -90,7 +92,11 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   typedef uchirp::MainLoop<RxReplay> Loop;
   constexpr int kLoopWords = (int)((sizeof(Loop) + 3) / 4) | 1;
   __shared__ uint32_t loop_mem[64 * kLoopWords];
-  Loop& loop = *new (loop_mem + threadIdx.x * kLoopWords) Loop(p.n, p.snr_threshold);
+  uint32_t* mine = loop_mem + threadIdx.x * kLoopWords;
+  Loop& loop = *new (mine) Loop(p.n, p.snr_threshold);
+  constexpr int kStateWords = (int)((sizeof(Loop) + 3) / 4);
+  if (p.loop_state)  // a live stream: main()'s locals as the previous call left them
+    for (int w = 0; w < kStateWords; w++) mine[w] = p.loop_state[s * kStateWords + w];
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
   uint32_t ntext = 0, nt = 0;
@@ -102,7 +108,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
     const uchirp::loop_event le = loop.step(rx, put);
     if (trace && nt < p.trace_cap) {
       uc_rx_event ev;
-      ev.block = p.acc ? p.acc[s * p.nb + i] : i;
+      ev.block = p.block_base + (p.acc ? p.acc[s * p.nb + i] : i);
       ev.sync_position = le.sync_position;
       ev.state_before = (uint8_t)le.state_before;
       ev.state_after = (uint8_t)le.state_after;
@@ -117,6 +123,8 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   text[ntext] = '\0';
   if (p.n_text) p.n_text[s] = ntext;
   if (p.n_trace) p.n_trace[s] = nt;
+  if (p.loop_state)
+    for (int w = 0; w < kStateWords; w++) p.loop_state[s * kStateWords + w] = mine[w];
 }
 
 // The same loop, ONE WAVE PER STREAM (up to a few thousand streams: a lane per stream would leave the chip empty and pay a
@@ -169,7 +177,13 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
   typedef uchirp::MainLoop<RxWindow> Loop;
   __shared__ uint32_t loop_mem[(sizeof(Loop) + 3) / 4];
   Loop* loopp = reinterpret_cast<Loop*>(loop_mem);
-  if (lane == 0) new (loop_mem) Loop(p.n, p.snr_threshold);
+  constexpr int kStateWords = (int)((sizeof(Loop) + 3) / 4);
+  if (p.loop_state) {  // a live stream: main()'s locals as the previous call left them
+    if (lane < kStateWords) loop_mem[lane] = p.loop_state[s * kStateWords + lane];
+  } else if (lane == 0) {
+    new (loop_mem) Loop(p.n, p.snr_threshold);
+  }
+  static_assert(kStateWords <= 64, "one lane per word of main()'s locals");
   __syncthreads();
   Loop& loop = *loopp;
   char* text = p.text + s * p.text_cap;
@@ -186,7 +200,7 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
         const uchirp::loop_event le = loop.step(w, put);
         if (trace && nt < p.trace_cap) {
           uc_rx_event ev;
-          ev.block = p.acc ? p.acc[s * p.nb + i] : i;
+          ev.block = p.block_base + (p.acc ? p.acc[s * p.nb + i] : i);
           ev.sync_position = le.sync_position;
           ev.state_before = (uint8_t)le.state_before;
           ev.state_after = (uint8_t)le.state_after;
@@ -214,6 +228,31 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
     if (p.n_text) p.n_text[s] = ntext;
     if (p.n_trace) p.n_trace[s] = nt;
   }
+  __syncthreads();
+  if (p.loop_state && lane < kStateWords) p.loop_state[s * kStateWords + lane] = loop_mem[lane];
+}
+
+// live streams: main()'s locals at power-on (receiver/Src/main.c:314-339), one image per stream
+__global__ __launch_bounds__(64) void state_init_kernel(uint32_t* loop_state, size_t n_streams, uint32_t n, float thr) {
+  typedef uchirp::MainLoop<RxReplay> Loop;
+  constexpr int kStateWords = (int)((sizeof(Loop) + 3) / 4);
+  __shared__ uint32_t img[kStateWords];
+  if (threadIdx.x == 0) {
+    for (int w = 0; w < kStateWords; w++) img[w] = 0u;  // (padding bytes too: the images compare equal word for word)
+    new (img) Loop(n, thr);
+  }
+  __syncthreads();
+  for (size_t i = (size_t)blockIdx.x * 64 + threadIdx.x; i < n_streams * kStateWords; i += (size_t)gridDim.x * 64)
+    loop_state[i] = img[i % kStateWords];
+}
+
+// the FIFO tail a call leaves behind: 2 n words per stream
+__global__ __launch_bounds__(kPackThreads) void tail_kernel(const uint32_t* base, size_t pitch, const uint32_t* na,
+                                                            uint32_t off_blocks, uint32_t n, uint32_t* tail) {
+  const size_t s = blockIdx.x;
+  const uint32_t* from = base + s * pitch + (size_t)(na ? na[s] : off_blocks) * n;
+  uint32_t* d = tail + s * 2 * (size_t)n;
+  for (uint32_t i = threadIdx.x; i < 2 * n; i += kPackThreads) d[i] = from[i];
 }
 
 }  // namespace
@@ -224,16 +263,37 @@ int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_
   return (int)hipGetLastError();
 }
 
+int rx_loop_words() {
+  static_assert(sizeof(uchirp::MainLoop<RxReplay>) == sizeof(uchirp::MainLoop<RxWindow>), "one image for both replay kernels");
+  return (int)((sizeof(uchirp::MainLoop<RxReplay>) + 3) / 4);
+}
+
+int launch_rx_state_init(uint32_t* loop_state, size_t n_streams, uint32_t n, float snr_threshold, hipStream_t stream) {
+  if (n_streams == 0) return (int)hipSuccess;
+  const size_t words = n_streams * (size_t)rx_loop_words();
+  const unsigned grid = (unsigned)((words + 63) / 64 < 4096 ? (words + 63) / 64 : 4096);
+  hipLaunchKernelGGL(state_init_kernel, dim3(grid), dim3(64), 0, stream, loop_state, n_streams, n, snr_threshold);
+  return (int)hipGetLastError();
+}
+
+int launch_rx_tail(const void* base, size_t pitch, const uint32_t* na, uint32_t off_blocks, uint32_t n, size_t n_streams,
+                   void* tail, hipStream_t stream) {
+  if (n_streams == 0) return (int)hipSuccess;
+  hipLaunchKernelGGL(tail_kernel, dim3((unsigned)n_streams), dim3(kPackThreads), 0, stream, (const uint32_t*)base, pitch, na,
+                     off_blocks, n, (uint32_t*)tail);
+  return (int)hipGetLastError();
+}
+
 int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, size_t n_streams, const uint32_t* acc,
-                   const uint32_t* na, void* dst, size_t pitch, bool aligned16, hipStream_t stream) {
+                   const uint32_t* na, const void* prefix, void* dst, size_t pitch, bool aligned16, hipStream_t stream) {
   if (n_streams == 0) return (int)hipSuccess;
   const dim3 grid((unsigned)((size_t)(nb + 2) * n_streams));  // < 2^28: the frame count of the launch behind it is 8 x this
   if (aligned16)
     hipLaunchKernelGGL(pack_kernel<4>, grid, dim3(kPackThreads), 0, stream, (const uint32_t*)src, src_stride, n, nb, acc, na,
-                       (uint32_t*)dst, pitch);
+                       (const uint32_t*)prefix, (uint32_t*)dst, pitch);
   else
     hipLaunchKernelGGL(pack_kernel<1>, grid, dim3(kPackThreads), 0, stream, (const uint32_t*)src, src_stride, n, nb, acc, na,
-                       (uint32_t*)dst, pitch);
+                       (const uint32_t*)prefix, (uint32_t*)dst, pitch);
   return (int)hipGetLastError();
 }
 

@@ -35,7 +35,8 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_partition", "uc_frame_span", "uc_stream_span", "uc_group_unique_id", "uc_group_create", "uc_group_create_rank",
            "uc_group_destroy", "uc_group_world", "uc_group_local_count", "uc_group_first_rank", "uc_group_ctx",
            "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
-           "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters"]
+           "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters",
+           "uc_rx_state_create", "uc_rx_state_reset", "uc_rx_state_destroy", "uc_receive_streams_next"]
 GROUP_ID_BYTES = 128
 
 
@@ -142,6 +143,12 @@ def lib():
     L.uc_receive_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p,
                                      C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.uc_debug_busy_counters.argtypes = [C.c_void_p]
+    L.uc_rx_state_create.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.uc_rx_state_reset.argtypes = [C.c_void_p, C.c_void_p]
+    L.uc_rx_state_destroy.argtypes = [C.c_void_p]
+    L.uc_rx_state_destroy.restype = None
+    L.uc_receive_streams_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
+                                          C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.uc_clock_probe.argtypes = [C.c_void_p, C.c_int]
     L.uc_clock_read.argtypes = [C.c_void_p, C.POINTER(Clock)]
     L.uc_clock_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]
@@ -303,7 +310,11 @@ class Engine:
         # (the returned count, not the C string: a decoded byte may be 0)
         return text.raw[:nch].decode("latin-1"), trace[:nt.value]
 
-    def receive_many(self, samples, busy=None, text_cap=64, want_trace=True, stream=None):
+    def live(self, n_streams):
+        """uc_rx_state_create: n_streams live receivers at power-on; feed them chunk after chunk with LiveStreams.next()."""
+        return LiveStreams(self, n_streams)
+
+    def receive_many(self, samples, busy=None, text_cap=64, want_trace=True, stream=None, _state=None):
         """uc_receive_streams: samples [n_streams, n_samples] (numpy int32 / float32, or a contiguous torch device tensor);
         busy [n_streams, n_samples // n] or None.  Returns (texts: list of str, traces: list of RX_EVENT_DTYPE arrays or
         None).  Host results either way (the call waits)."""
@@ -334,11 +345,15 @@ class Engine:
         ntext = np.zeros(ns, np.uint32)
         trace = np.zeros((ns, max(nb, 1)), RX_EVENT_DTYPE) if want_trace else None
         ntrace = np.zeros(ns, np.uint32)
-        _check(lib().uc_receive_streams(self._h, ptr, dt, ns, nsmp, 0, bz.ctypes.data_as(C.c_void_p) if bz is not None else None,
-                                        text.ctypes.data_as(C.c_void_p), text_cap, ntext.ctypes.data_as(C.c_void_p),
-                                        trace.ctypes.data_as(C.c_void_p) if trace is not None else None, max(nb, 1),
-                                        ntrace.ctypes.data_as(C.c_void_p), C.c_void_p(stream) if stream else None),
-               "uc_receive_streams")
+        tail = (bz.ctypes.data_as(C.c_void_p) if bz is not None else None, text.ctypes.data_as(C.c_void_p), text_cap,
+                ntext.ctypes.data_as(C.c_void_p), trace.ctypes.data_as(C.c_void_p) if trace is not None else None, max(nb, 1),
+                ntrace.ctypes.data_as(C.c_void_p), C.c_void_p(stream) if stream else None)
+        if _state is None:
+            _check(lib().uc_receive_streams(self._h, ptr, dt, ns, nsmp, 0, *tail), "uc_receive_streams")
+        else:
+            if ns != _state.n_streams:
+                raise ValueError("this state holds %d streams" % _state.n_streams)
+            _check(lib().uc_receive_streams_next(self._h, _state._h, ptr, dt, nsmp, 0, *tail), "uc_receive_streams_next")
         texts = [bytes(text[i, :ntext[i]]).decode("latin-1") for i in range(ns)]
         traces = [trace[i, :ntrace[i]] for i in range(ns)] if want_trace else None
         return texts, traces
@@ -606,3 +621,31 @@ class Group:
 
     def synchronize(self):
         _check(lib().uc_group_synchronize(self._h), "uc_group_synchronize")
+
+
+class LiveStreams:
+    """uc_rx_state: n_streams receivers between calls (the FIFO's tail and main()'s locals of every stream, on the device)."""
+
+    def __init__(self, engine, n_streams):
+        self.engine, self.n_streams = engine, int(n_streams)
+        h = C.c_void_p()
+        _check(lib().uc_rx_state_create(engine._h, self.n_streams, C.byref(h)), "uc_rx_state_create")
+        self._h = h
+
+    def next(self, samples, busy=None, text_cap=64, want_trace=True, stream=None):
+        """uc_receive_streams_next: the next whole blocks of every stream, [n_streams, k * n] -> (texts, traces) of this chunk."""
+        return self.engine.receive_many(samples, busy=busy, text_cap=text_cap, want_trace=want_trace, stream=stream, _state=self)
+
+    def reset(self):
+        _check(lib().uc_rx_state_reset(self._h, None), "uc_rx_state_reset")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uc_rx_state_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
