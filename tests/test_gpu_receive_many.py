@@ -169,6 +169,15 @@ def test_live_streams_chunk_after_chunk_equal_the_whole_stream(uchirp, variant):
                 got = np.concatenate(traces[s]) if traces[s] else np.zeros(0, whole_tr[s].dtype)
                 assert np.array_equal(got.view(np.uint8), whole_tr[s].view(np.uint8)), (s, sizes[:6])
             live.close()
+    # the lane-per-stream replay (more than 16 Ki streams) carries its state the same way
+    many = np.tile(x[:8, 30 * N:42 * N], (2500, 1))                   # 20 000 streams of 12 blocks
+    w_t, w_tr = e.receive_many(many)
+    live = e.live(many.shape[0])
+    parts = [live.next(np.ascontiguousarray(many[:, a * N:b * N])) for a, b in ((0, 5), (5, 6), (6, 12))]
+    for s in range(0, many.shape[0], 997):
+        got = np.concatenate([p[1][s] for p in parts])
+        assert np.array_equal(got.view(np.uint8), w_tr[s].view(np.uint8)) and "".join(p[0][s] for p in parts) == w_t[s]
+    live.close()
     # reset = power-on again; a state is tied to its context and its stream count; partial blocks are refused
     live = e.live(3)
     t1, _ = live.next(x[:3, :40 * N])
