@@ -93,10 +93,14 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   constexpr int kLoopWords = (int)((sizeof(Loop) + 3) / 4) | 1;
   __shared__ uint32_t loop_mem[64 * kLoopWords];
   uint32_t* mine = loop_mem + threadIdx.x * kLoopWords;
-  Loop& loop = *new (mine) Loop(p.n, p.snr_threshold);
   constexpr int kStateWords = (int)((sizeof(Loop) + 3) / 4);
-  if (p.loop_state)  // a live stream: main()'s locals as the previous call left them
-    for (int w = 0; w < kStateWords; w++) mine[w] = p.loop_state[s * kStateWords + w];
+  // a live stream: main()'s locals as the previous call left them -- their bytes go into the storage BEFORE the object is
+  // looked at (memcpy + launder: copying words into an object the compiler has just seen constructed lets it keep the
+  // constructor's values of the float members in registers -- it did)
+  if (p.loop_state) __builtin_memcpy(mine, p.loop_state + s * kStateWords, sizeof(Loop));
+  else new (mine) Loop(p.n, p.snr_threshold);
+  asm volatile("" ::: "memory");
+  Loop& loop = *__builtin_launder(reinterpret_cast<Loop*>(mine));
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
   uint32_t ntext = 0, nt = 0;
@@ -123,8 +127,8 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   text[ntext] = '\0';
   if (p.n_text) p.n_text[s] = ntext;
   if (p.n_trace) p.n_trace[s] = nt;
-  if (p.loop_state)
-    for (int w = 0; w < kStateWords; w++) p.loop_state[s * kStateWords + w] = mine[w];
+  asm volatile("" ::: "memory");
+  if (p.loop_state) __builtin_memcpy(p.loop_state + s * kStateWords, mine, sizeof(Loop));
 }
 
 // The same loop, ONE WAVE PER STREAM (up to a few thousand streams: a lane per stream would leave the chip empty and pay a
@@ -184,8 +188,9 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
     new (loop_mem) Loop(p.n, p.snr_threshold);
   }
   static_assert(kStateWords <= 64, "one lane per word of main()'s locals");
+  static_assert(sizeof(Loop) % 4 == 0, "main()'s locals are whole words");
   __syncthreads();
-  Loop& loop = *loopp;
+  Loop& loop = *__builtin_launder(loopp);
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
   uint32_t ntext = 0, nt = 0;
