@@ -6,6 +6,9 @@ recorded streams in one call -- pack kernel, one batched launch, the switch repl
   * against the oracle's literal sequential loop on 1000 random transmissions with dropped blocks -- random text, amplitude,
     noise, lead, skew, busy masks (the cases of tools/fuzz_receive.py): every trace equal, except where the ORACLE's own
     snrs show the diverging decision within round-off of a threshold or of a tie."""
+import os
+import subprocess
+
 import numpy as np
 import pytest
 
@@ -203,3 +206,20 @@ def test_live_streams_chunk_after_chunk_equal_the_whole_stream(uchirp, variant):
     live.close()
     other.close()
     e.close()
+
+
+def test_plain_c_host_runs_live_microphones(tmp_path):
+    """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
+    call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream
+    receives its own message."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "host_live")
+    libdir = os.path.join(root, "ultrasonic-communication_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c", "host_live.c"), "-o", exe, "-L" + libdir, "-luchirp", "-lm",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    for s, m in enumerate(("Hello World!", "uchirp", "MI355X", "0123456789")):
+        assert ('stream %d received "%s"' % (s, m)) in out.stdout
+    print(out.stdout.strip().splitlines()[-4:])
