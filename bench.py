@@ -561,6 +561,34 @@ def receive_leg(args, device, torch):
         out[name] = {"streams": ns, "ms_per_call": dt * 1e3, "blocks_per_s": ns * nb / dt,
                      "dsp_frames_per_s": ns * (nb + 2) * 8 / dt, "x_real_time": ns * nb / dt / (fs / N),
                      "streams_decoding_the_text": sum(1 for t in texts if MSG in t), "first_text": texts[0]}
+        if ns == 4096:
+            # the same microphones LIVE: one new block of every stream per call (uc_rx_state / uc_receive_streams_next), the
+            # firmware's own mode of operation; the texts of the chunks must add up to the recorded-stream call's
+            live = eng.live(ns)
+            chunks = [x[:, b * N:(b + 1) * N].contiguous() for b in range(nb)]
+            acc = [bytearray() for _ in range(ns)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for ch in chunks:
+                rc = L.uc_receive_streams_next(eng._h, live._h, C.c_void_p(ch.data_ptr()), uchirp.DTYPE_F32, N, 0, None,
+                                               C.c_void_p(text.data_ptr()), cap, C.c_void_p(ntext.data_ptr()), None, 0, None,
+                                               C.c_void_p(stream.cuda_stream))
+                if rc != 0:
+                    raise RuntimeError(L.uc_last_error().decode())
+                nt = ntext.cpu().numpy()                       # (a live host reads its characters after every block)
+                if nt.any():
+                    tt = text.cpu().numpy()
+                    for si in np.nonzero(nt)[0]:
+                        acc[si] += bytes(tt[si, :nt[si]])
+            torch.cuda.synchronize()
+            dt_live = (time.perf_counter() - t0) / nb
+            live.close()
+            same = sum(1 for si in range(ns) if acc[si].decode("latin-1") == texts[si])
+            out["live_4096_streams"] = {"streams": ns, "blocks_per_call": 1, "calls": nb, "ms_per_call": dt_live * 1e3,
+                                        "real_time_ms_per_call": N / fs * 1e3, "headroom_x_real_time": N / fs / dt_live,
+                                        "microphones_served_in_real_time": int(ns * N / fs / dt_live),
+                                        "streams_whose_chunks_add_up_to_the_recorded_call": same}
+            del chunks
         eng.close()
         del x, text, ntext
     return out
@@ -1193,6 +1221,9 @@ def main():
                     if rx[key]["streams_decoding_the_text"] != rx[key]["streams"]:
                         gate_failures.append("receive: %d of %d streams decode the text"
                                              % (rx[key]["streams_decoding_the_text"], rx[key]["streams"]))
+                if rx["live_4096_streams"]["streams_whose_chunks_add_up_to_the_recorded_call"] != 4096:
+                    gate_failures.append("receive: live chunks differ from the recorded-stream call on %d streams"
+                                         % (4096 - rx["live_4096_streams"]["streams_whose_chunks_add_up_to_the_recorded_call"]))
             except Exception as ex:
                 rx = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
                 gate_failures.append("receive failed: %s" % type(ex).__name__)
