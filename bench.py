@@ -231,6 +231,63 @@ def live_traffic(frames_log2=19, timeout_s=150):
                       % frames_log2}
 
 
+class PowerSampler:
+    """Socket power and SMU-reported shader clock of the GPU this process drives, read from the amdgpu hwmon files
+    (power1_input in microwatts, freq1_input in Hz, power1_cap) every millisecond by a thread while the timed region runs.
+    Evidence for WHY the clock under these kernels is what uc_clock_read measures: the socket sits at its power cap."""
+
+    def __init__(self, torch, device):
+        import glob
+        import threading
+        self.dir, self.samples, self._stop, self._thread = None, [], threading.Event(), None
+        try:
+            bus = torch.cuda.get_device_properties(device).pci_bus_id
+            if isinstance(bus, int):                      # (older torch: domain / bus / device numbers)
+                p = torch.cuda.get_device_properties(device)
+                bus = "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+            for d in glob.glob("/sys/class/drm/card*/device"):
+                if os.path.basename(os.path.realpath(d)).lower() == str(bus).lower():
+                    hw = glob.glob(os.path.join(d, "hwmon", "hwmon*"))
+                    if hw and os.path.exists(os.path.join(hw[0], "power1_input")):
+                        self.dir = hw[0]
+        except Exception:
+            self.dir = None
+
+    def _read(self, name):
+        try:
+            return int(open(os.path.join(self.dir, name)).read())
+        except (OSError, ValueError):
+            return None
+
+    def start(self):
+        import threading
+        if not self.dir:
+            return
+
+        def run():
+            while not self._stop.is_set():
+                self.samples.append((time.perf_counter(), self._read("power1_input"), self._read("freq1_input")))
+                time.sleep(0.001)
+        self._thread = threading.Thread(target=run, daemon=True)
+        self._thread.start()
+
+    def stop(self, t0, t1):
+        """-> record of the samples taken inside [t0, t1] (perf_counter), or None."""
+        if not self._thread:
+            return None
+        self._stop.set()
+        self._thread.join()
+        inside = [(p, f) for t, p, f in self.samples if t0 <= t <= t1 and p is not None]
+        if not inside:
+            return None
+        pw = [p / 1e6 for p, _ in inside]
+        fq = [f / 1e6 for _, f in inside if f]
+        cap = self._read("power1_cap")
+        return {"socket_W_mean": float(np.mean(pw)), "socket_W_max": float(np.max(pw)), "cap_W": cap / 1e6 if cap else None,
+                "sclk_MHz_smu_mean": float(np.mean(fq)) if fq else None, "samples": len(inside),
+                "source": "%s/power1_input, freq1_input sampled every ms over the timed region" % self.dir}
+
+
 _NUM_CU = {}
 
 
@@ -1028,6 +1085,9 @@ def main():
     # per-launch kernel time: HIP events on the stream the kernel is launched on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if have_gpu else (None, None)
           for _ in range(args.steps)]
+    power = PowerSampler(torch, device) if have_gpu and rank == 0 else None
+    if power:
+        power.start()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, ev[k][0], ev[k][1])
@@ -1037,6 +1097,7 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    power_rec = power.stop(t0, t0 + elapsed) if power else None
     elapsed_local = elapsed
     if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
@@ -1129,6 +1190,7 @@ def main():
             out["roofline"] = roofline("band_rx_real_f32", "band_kernel<rx_real,f32>", nf, BYTES_PER_FRAME, kern_ms,
                                        num_cus(torch, device), clk_live)
             out["roofline"]["bytes_per_frame"] = BYTES_PER_FRAME
+            out["roofline"]["power"] = power_rec    # socket power / cap / SMU clock over the timed region (null: no hwmon access)
             if not multi and not args.no_live_traffic:
                 t_c = time.perf_counter()
                 lt = live_traffic()
