@@ -285,7 +285,7 @@ class PowerSampler:
         cap = self._read("power1_cap")
         return {"socket_W_mean": float(np.mean(pw)), "socket_W_max": float(np.max(pw)), "cap_W": cap / 1e6 if cap else None,
                 "sclk_MHz_smu_mean": float(np.mean(fq)) if fq else None, "samples": len(inside),
-                "source": "%s/power1_input, freq1_input sampled every ms over the timed region" % self.dir}
+                "source": "%s/power1_input, freq1_input sampled every ms" % self.dir}
 
 
 _NUM_CU = {}
@@ -728,6 +728,9 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="N = 1: skip the configs[2] / configs[3] block")
     ap.add_argument("--no-hello1", action="store_true", help="N = 1: skip the configs[4] leg at world size 1")
     ap.add_argument("--no-receive", action="store_true", help="N = 1: skip the multi-stream receiver leg")
+    ap.add_argument("--sustain-s", type=float, default=1.5,
+                    help="N = 1: seconds of untimed back-to-back launches behind the timed region during which socket power and "
+                         "the SMU clock are sampled (hwmon); 0 = none")
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1: do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE); roofline.traffic then "
                          "comes from the committed record and says so")
@@ -1085,9 +1088,6 @@ def main():
     # per-launch kernel time: HIP events on the stream the kernel is launched on
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if have_gpu else (None, None)
           for _ in range(args.steps)]
-    power = PowerSampler(torch, device) if have_gpu and rank == 0 else None
-    if power:
-        power.start()
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, ev[k][0], ev[k][1])
@@ -1097,7 +1097,25 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    power_rec = power.stop(t0, t0 + elapsed) if power else None
+    # Sustained run behind the timed region (untimed, N = 1 only): the SMU's power figure is a moving average over about a
+    # second, so the 40 ms of the timed region cannot show it; 1.5 s of back-to-back launches can.  Reports the socket power
+    # and the SMU's clock over the last 0.5 s, and the rate the kernel holds meanwhile.
+    power_rec = None
+    if eng is not None and not multi and rank == 0 and args.sustain_s > 0:
+        power = PowerSampler(torch, device)
+        power.start()
+        t_s = time.perf_counter()
+        n_s = 0
+        while time.perf_counter() - t_s < args.sustain_s:
+            for _ in range(16):
+                eng.process(frames, want_stats=False, symbols_out=sym2[0], stream=stream.cuda_stream)
+            torch.cuda.synchronize()
+            n_s += 16
+        t_e = time.perf_counter()
+        power_rec = power.stop(t_e - 0.5, t_e)
+        if power_rec:
+            power_rec["sustained_frames_per_s"] = nf * n_s / (t_e - t_s)
+            power_rec["sustained_s"] = t_e - t_s
     elapsed_local = elapsed
     if multi:
         tt = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearse else device)
@@ -1190,7 +1208,9 @@ def main():
             out["roofline"] = roofline("band_rx_real_f32", "band_kernel<rx_real,f32>", nf, BYTES_PER_FRAME, kern_ms,
                                        num_cus(torch, device), clk_live)
             out["roofline"]["bytes_per_frame"] = BYTES_PER_FRAME
-            out["roofline"]["power"] = power_rec    # socket power / cap / SMU clock over the timed region (null: no hwmon access)
+            # socket power / cap / SMU clock over the last 0.5 s of a 1.5 s sustained run behind the timed region (null: multi-GPU
+            # run, --sustain-s 0, or no hwmon access)
+            out["roofline"]["power"] = power_rec
             if not multi and not args.no_live_traffic:
                 t_c = time.perf_counter()
                 lt = live_traffic()
