@@ -120,6 +120,8 @@ def test_gpu_default_line_carries_every_single_gpu_config():
     # HBM traffic from the PMC counters, collected in this run (two rocprofv3 child passes): no wasted re-reads
     assert d["roofline"]["bound"] in ("hbm", "valu") and d["roofline"]["traffic_source"].startswith("measured in this run")
     assert 0.99 < d["roofline"]["traffic_over_algorithmic"] < 1.05
+    pw = d["roofline"]["power"]                            # hwmon telemetry of a sustained run (null without sysfs access)
+    assert pw is None or (pw["cap_W"] > 0 and 100 < pw["socket_W_mean"] <= pw["cap_W"] * 1.02 and pw["sustained_frames_per_s"] > 0)
     c2, c3 = d["configs"]["configs[2]"], d["configs"]["configs[3]"]
     assert c2["baseband"]["symbols_equal_oracle_head4096_clear"] == 1.0 and c2["baseband"]["bit_error_rate_vs_transmitted"] < 0.03
     assert c2["baseband"]["roofline"]["kernel"].startswith("iq1024_kernel") and c2["firmware_windows"]["value"] > 0
