@@ -29,6 +29,9 @@
 #include "uc_kernels.hpp"
 #include "uc_xform.hpp"
 
+#ifndef UC_STREAM_STORE_CPOL
+#define UC_STREAM_STORE_CPOL UC_STREAM_CPOL  // cache policy of the |y| stores (2 = nt; 0 = default, for A/B)
+#endif
 #ifndef UC_STREAM_KNOCK
 #define UC_STREAM_KNOCK 0  // diagnostic builds only: 1 no loads in the loop, 2 no FIR arithmetic, 4 no transforms, 8 no stores,
                            // 16 / 32 the round-2 nt mix / every load nt, 64 a whole block of loads in flight,
@@ -307,7 +310,7 @@ __global__ __launch_bounds__(T, 2) void stream_kernel(const StreamParams p) {
       const float m2 = y.x * y.x + y.y * y.y;
       const int o = j + T * t - (L - 1);  // offset inside the block's hop
 #if !(UC_STREAM_KNOCK & 8)
-      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_sqrtf(m2)), ro, o * 4, 0, UC_STREAM_CPOL);
+      __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(__builtin_amdgcn_sqrtf(m2)), ro, o * 4, 0, UC_STREAM_STORE_CPOL);
 #endif
       const bool take = (unsigned)o < (unsigned)valid && m2 > best;  // ascending offset: first maximum
       best = take ? m2 : best;
