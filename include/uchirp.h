@@ -315,6 +315,7 @@ typedef struct uc_rx_state uc_rx_state;
 int uc_rx_state_create(uc_ctx* ctx, size_t n_streams, uc_rx_state** out);   /* every receiver at power-on */
 int uc_rx_state_reset(uc_rx_state* st, void* hip_stream);                   /* back to power-on */
 void uc_rx_state_destroy(uc_rx_state* st);
+size_t uc_rx_state_streams(const uc_rx_state* st);                          /* how many receivers it holds (0 for NULL) */
 int uc_receive_streams_next(uc_ctx* ctx, uc_rx_state* st, const void* samples, int dtype, size_t n_samples,
                             size_t stream_stride_elems, const uint8_t* busy /*nullable*/, char* text, size_t text_cap,
                             uint32_t* n_text /*nullable*/, uc_rx_event* trace /*nullable*/, size_t trace_cap,
@@ -447,6 +448,29 @@ int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, si
 int uc_group_wait_gather(uc_group* g, int local, const uint8_t* gathered, void* hip_stream);
 /* wait for everything the group has enqueued on every local device */
 int uc_group_synchronize(uc_group* g);
+
+/*
+ * The multi-stream receiver over the GPUs of a node -- SURVEY.md section 8e: the sequential state machine of ONE stream does
+ * not shard, so "run one independent stream per GPU (replicas across streams)"; here thousands per GPU.  The n_streams_total
+ * streams are block-partitioned over the ranks (uc_partition), every local device runs uc_receive_streams() over its share
+ * (the ISR FIFO, dsp() at every 256-sample offset, main()'s switch replayed on the device: receiver/Src/main.c:417-554,
+ * 243-273, 659-668) and writes into its slice of the gathered arrays, which are then all-gathered in place on the gather
+ * stream, behind an event, exactly as uc_group_process_batch gathers the symbol stream (same hazard guard, same rules):
+ *   samples[l]  stream 0 of the share rank (first + l) owns: count x n_samples words, stream_stride_elems apart, on that
+ *               device (or host); busy (nullable array, nullable entries): count x (n_samples / n) flags of that share
+ *   text[l]     n_streams_total x text_cap bytes on that device (or host): receives the text of EVERY stream of the node
+ *   n_text      (nullable; all ranks alike) n_text[l]: n_streams_total uint32 on that device (or host), characters per stream
+ * A stream's text is the one uc_receive_stream[_isr] gives for it alone, bit for bit, wherever it ran.
+ * uc_group_receive_streams_next is the LIVE form (uc_receive_streams_next): states[l] = uc_rx_state_create(uc_group_ctx(g, l),
+ * count of rank first + l) holds that share's receivers between calls; text receives what was decoded during THIS call.
+ */
+int uc_group_receive_streams(uc_group* g, const void* const* samples, int dtype, size_t n_streams_total, size_t n_samples,
+                             size_t stream_stride_elems, const uint8_t* const* busy /*nullable*/, char* const* text,
+                             size_t text_cap, uint32_t* const* n_text /*nullable*/, void* const* hip_streams /*nullable*/);
+int uc_group_receive_streams_next(uc_group* g, uc_rx_state* const* states, const void* const* samples, int dtype,
+                                  size_t n_streams_total, size_t n_samples, size_t stream_stride_elems,
+                                  const uint8_t* const* busy /*nullable*/, char* const* text, size_t text_cap,
+                                  uint32_t* const* n_text /*nullable*/, void* const* hip_streams /*nullable*/);
 
 /* Plain-C hosts without the HIP headers: device memory by ordinal.  uc_device_copy: either side may be host or device
  * memory (hipMemcpyDefault), synchronous. */

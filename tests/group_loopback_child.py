@@ -12,6 +12,7 @@ import numpy as np
 import torch
 import uchirp
 from uchirp import synth
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 dev = torch.device("cuda", 0)
 N = 2048
@@ -76,4 +77,56 @@ for world in (2, 4):
 # int32 DFSDM words
 fi = (synth.device_frames(333, dev, seed=2, snr_db=0.0)[0].round().to(torch.int64) * 256).to(torch.int32).reshape(-1)
 run(uchirp.RX_REAL, dict(mag_mean=256000.0, time_frame=N / 78125.0), fi, 333, 0, 0, 3, dtype=uchirp.DTYPE_I32)
+
+# ---- uc_group_receive_streams: the streams of a node, block-partitioned over the ranks ("replicas across streams") ----------
+from test_gpu_receive_many import _transmissions
+
+
+def run_receive(variant, world, ns, blocks=150, cap=24):
+    global checks
+    x, busy, msgs = _transmissions(ns, seed=1000 + world + ns, blocks=blocks)
+    eng = uchirp.Engine(variant)
+    want, _ = eng.receive_many(x, busy=busy, text_cap=cap, want_trace=False)
+    eng.close()
+    g = uchirp.Group(variant, devices=[0] * world)
+    shares = [uchirp.partition(ns, world, r) for r in range(world)]
+    # every rank holds ITS streams only
+    xs = [torch.from_numpy(np.ascontiguousarray(x[f:f + c])).to(dev) if c else torch.zeros(1, device=dev) for f, c in shares]
+    bs = [torch.from_numpy(np.ascontiguousarray(busy[f:f + c])).to(dev) if c else None for f, c in shares]
+    text = [torch.full((ns, cap), 0x33, dtype=torch.uint8, device=dev) for _ in range(world)]
+    cnt = [torch.full((ns,), -1, dtype=torch.int32, device=dev) for _ in range(world)]
+    for _ in range(2):                                      # twice into the same buffers: the hazard guard
+        g.receive_streams(xs, ns, blocks * N, text, cap, n_text=cnt, busy=bs)
+    g.synchronize()
+    for r in range(world):
+        t, c = text[r].cpu().numpy(), cnt[r].cpu().numpy()
+        got = [bytes(t[i, :c[i]]).decode("latin-1") for i in range(ns)]
+        assert got == want, (variant, world, ns, r)
+        checks += 1
+    # live, in chunks of unequal sizes: every rank's share keeps its receivers between the calls
+    states = [g.rx_state(r, c) if c else None for r, (f, c) in enumerate(shares)]
+    if all(s is not None for s in states):
+        acc = [""] * ns
+        at = 0
+        for nb in (3, 1, 40, blocks - 44):
+            ch = [torch.from_numpy(np.ascontiguousarray(x[f:f + c, at * N:(at + nb) * N])).to(dev) for f, c in shares]
+            bz = [torch.from_numpy(np.ascontiguousarray(busy[f:f + c, at:at + nb])).to(dev) for f, c in shares]
+            g.receive_streams(ch, ns, nb * N, text, cap, n_text=cnt, busy=bz, states=states)
+            g.synchronize()
+            t, c = text[world - 1].cpu().numpy(), cnt[world - 1].cpu().numpy()
+            acc = [a + bytes(t[i, :c[i]]).decode("latin-1") for i, a in enumerate(acc)]
+            for r in range(world - 1):
+                assert torch.equal(cnt[r], cnt[world - 1])
+            at += nb
+        assert acc == want, (variant, world, ns)
+        checks += 1
+        for s in states:
+            g.rx_state_destroy(s)
+    g.close()
+    return sum(m in t for m, t in zip(msgs, want))
+
+
+decoded = run_receive(uchirp.RX_REAL, 2, 24) + run_receive(uchirp.SYNC_CPLX, 3, 25) + run_receive(uchirp.SYNC_CPLX, 4, 24)
+run_receive(uchirp.RX_REAL, 8, 5)                           # more ranks than streams
+assert decoded >= 25
 print("loopback ok: %d gathered buffers checked" % checks)

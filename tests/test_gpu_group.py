@@ -174,3 +174,87 @@ def test_plain_c_host_drives_the_group_and_decodes_hello_world(uchirp, tmp_path)
     assert ("sha256 of the gathered symbol stream: " + digest) in out.stdout, out.stdout
     assert "transmissions decoded exactly: 70 of 70" in out.stdout
     eng.close()
+
+
+def _texts(text, ntext):
+    text, ntext = np.asarray(text), np.asarray(ntext)
+    assert all(text[i, ntext[i]] == 0 for i in range(len(ntext)))           # NUL-terminated
+    return [bytes(text[i, :ntext[i]]).decode("latin-1") for i in range(len(ntext))]
+
+
+@pytest.mark.parametrize("mode", ["devices", "rank"])
+def test_group_receive_streams_of_one_device_equals_the_engine(uchirp, mode):
+    """uc_group_receive_streams / _next at world size 1 (the whole code path of a rank: the share's receivers write into the
+    rank's slice of the gathered texts and counts, two in-place gathers behind an event): the texts uc_receive_streams gives,
+    from device and from host buffers, with dropped blocks, and LIVE in chunks of unequal sizes."""
+    import torch
+    from test_gpu_receive_many import _transmissions
+    x, busy, msgs = _transmissions(48, seed=77, blocks=150)
+    cap = 32
+    for variant in (uchirp.RX_REAL, uchirp.SYNC_CPLX):
+        eng = uchirp.Engine(variant)
+        want, _ = eng.receive_many(x, busy=busy, text_cap=cap, want_trace=False)
+        want_nb, _ = eng.receive_many(x, text_cap=cap, want_trace=False)
+        assert sum(m in t for m, t in zip(msgs, want_nb)) >= 30
+        if mode == "devices":
+            g = uchirp.Group(variant, devices=[0])
+        else:
+            g = uchirp.Group(variant, world=1, rank=0, unique_id=uchirp.Group.unique_id(), device=0)
+        ns, nsmp = x.shape
+        xd = torch.from_numpy(x).to("cuda:0")
+        bd = torch.from_numpy(busy).to("cuda:0")
+        # device buffers, asynchronous; three text buffers in rotation, then the same one again (the hazard guard)
+        tb = [torch.full((ns, cap), 0x55, dtype=torch.uint8, device="cuda:0") for _ in range(3)]
+        nt = [torch.full((ns,), 9999, dtype=torch.int32, device="cuda:0") for _ in range(3)]
+        for k in range(5):
+            g.receive_streams([xd], ns, nsmp, [tb[k % 3]], cap, n_text=[nt[k % 3]], busy=[bd] if k % 2 == 0 else None)
+        g.synchronize()
+        assert _texts(tb[0].cpu().numpy(), nt[0].cpu().numpy()) == want_nb        # k = 3: no mask
+        assert _texts(tb[1].cpu().numpy(), nt[1].cpu().numpy()) == want           # k = 4: masked
+        assert _texts(tb[2].cpu().numpy(), nt[2].cpu().numpy()) == want           # k = 2
+        # host buffers: complete when the call returns
+        th, nh = np.zeros((ns, cap), np.uint8), np.zeros(ns, np.uint32)
+        g.receive_streams([x], ns, nsmp, [th], cap, n_text=[nh], busy=[busy])
+        assert _texts(th, nh) == want
+        # without counts
+        th2 = np.zeros((ns, cap), np.uint8)
+        g.receive_streams([x], ns, nsmp, [th2], cap)
+        assert [bytes(r).split(b"\0")[0].decode("latin-1") for r in th2] == want_nb
+        # live: chunks of 1, 7, 30, 112 blocks add up to the recorded call
+        st = g.rx_state(0, ns)
+        acc = [""] * ns
+        at = 0
+        for nb in (1, 7, 30, 112):
+            chunk = np.ascontiguousarray(x[:, at * N:(at + nb) * N])
+            bz = np.ascontiguousarray(busy[:, at:at + nb])
+            g.receive_streams([chunk], ns, nb * N, [th], cap, n_text=[nh], busy=[bz], states=[st])
+            acc = [a + t for a, t in zip(acc, _texts(th, nh))]
+            at += nb
+        assert acc == want
+        with pytest.raises(uchirp.UchirpError):                          # a state of the wrong size
+            g.receive_streams([x[:5]], 5, nsmp, [th], cap, states=[st])
+        g.rx_state_destroy(st)
+        g.close()
+        eng.close()
+    with pytest.raises(uchirp.UchirpError):                              # no state machine in that variant
+        gg = uchirp.Group(uchirp.COMPRESS, devices=[0])
+        try:
+            gg.receive_streams([x], x.shape[0], x.shape[1], [np.zeros((x.shape[0], cap), np.uint8)], cap)
+        finally:
+            gg.close()
+
+
+def test_plain_c_host_serves_the_microphones_of_a_node(tmp_path):
+    """tests/c/host_node_live.c (C99 -pedantic -Werror, libuchirp.so only): live microphones block-partitioned over the
+    devices of a group (one here), one new block each per call of uc_group_receive_streams_next, the characters of every
+    stream gathered into every device's arrays; each stream receives its own message."""
+    exe = str(tmp_path / "host_node_live")
+    libdir = os.path.join(ROOT, "ultrasonic-communication_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c", "host_node_live.c"), "-o", exe, "-L" + libdir, "-luchirp", "-lm",
+                           "-Wl,-rpath," + libdir])
+    out = subprocess.run([exe, "6", "1"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    for s, m in enumerate(("Hello World!", "uchirp", "MI355X", "0123456789", "Hello World!", "uchirp")):
+        assert ('stream %d received "%s"' % (s, m)) in out.stdout
+    print(out.stdout.strip().splitlines()[-3:])

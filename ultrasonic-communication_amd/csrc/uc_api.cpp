@@ -1577,6 +1577,8 @@ extern "C" void uc_rx_state_destroy(uc_rx_state* st) {
   delete st;
 }
 
+extern "C" size_t uc_rx_state_streams(const uc_rx_state* st) { return st ? st->n_streams : 0; }
+
 extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   if (!st) return fail(-EINVAL, "uc_rx_state_reset: NULL state");
   uc_ctx* c = st->c;

@@ -132,9 +132,71 @@ struct Local {
   size_t hz_bytes[kHazardRing] = {};
   hipEvent_t hz_ev[kHazardRing] = {};
   unsigned hz_next = 0;
-  void* d_gathered = nullptr;  // host-pointer calls: the stream is gathered here, then copied out
-  size_t d_gathered_cap = 0;
+  // host-pointer calls: the stream (slot 0; the texts of uc_group_receive_streams) and the per-stream counts (slot 1) are
+  // gathered here, then copied out
+  void* d_stage[2] = {};
+  size_t d_stage_cap[2] = {};
 };
+
+// a device buffer of at least `bytes` for a host-pointer call (kept, grown on demand)
+int stage_buffer(Local& L, int slot, size_t bytes, uint8_t** out) {
+  if (L.d_stage_cap[slot] < bytes) {
+    if (L.d_stage[slot]) (void)hipFree(L.d_stage[slot]);
+    L.d_stage[slot] = nullptr;
+    L.d_stage_cap[slot] = 0;
+    const hipError_t e = hipMalloc(&L.d_stage[slot], bytes);
+    if (e != hipSuccess) return hip_fail(e, "hipMalloc(gathered)");
+    L.d_stage_cap[slot] = bytes;
+  }
+  *out = (uint8_t*)L.d_stage[slot];
+  return 0;
+}
+
+bool overlaps(const uint8_t* a, size_t na, const uint8_t* b, size_t nb) { return a < b + nb && b < a + na; }
+
+// write-after-gather: an earlier gather that still reads or writes [d, d + bytes) must be done before a kernel on `cs`
+// overwrites the rank's slice of it (device-side wait, nothing blocks here) ... and the `n_new` ring slots this step will
+// recycle: a gather that drops out of the ring must be complete before anything newer runs, or a caller rotating more than
+// kHazardRing buffers could overwrite one behind the guard's back
+int hazard_wait(Local& L, hipStream_t cs, const uint8_t* d, size_t bytes, unsigned n_new) {
+  for (int k = 0; k < kHazardRing; k++) {
+    if (!L.hz_buf[k]) continue;
+    const bool recycled = (unsigned)(k + kHazardRing - (int)(L.hz_next % kHazardRing)) % kHazardRing < n_new;
+    if (recycled || overlaps(L.hz_buf[k], L.hz_bytes[k], d, bytes)) {
+      const hipError_t e = hipStreamWaitEvent(cs, L.hz_ev[k], 0);
+      if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(gather -> kernel)");
+    }
+  }
+  return 0;
+}
+
+// remember a gather into [d, d + bytes) that was just enqueued on the device's gather stream
+int hazard_record(Local& L, const uint8_t* d, size_t bytes) {
+  const unsigned k = L.hz_next++ % kHazardRing;
+  const hipError_t e = hipEventRecord(L.hz_ev[k], L.gather);
+  if (e != hipSuccess) return hip_fail(e, "hipEventRecord(gather)");
+  L.hz_buf[k] = d;
+  L.hz_bytes[k] = bytes;
+  return 0;
+}
+
+// The in-place all-gather of n_units_total units of unit_bytes each, block-partitioned over the ranks as uc_partition says:
+// ncclAllGather when the shares are even, one broadcast per rank (each slice from its owner) when they are ragged.
+// Call between ncclGroupStart and ncclGroupEnd.
+ncclResult_t gather_in_place(int world, int rank, uint8_t* d, size_t unit_bytes, size_t n_units_total, ncclComm_t comm,
+                             hipStream_t stream) {
+  if (n_units_total % (size_t)world == 0) {
+    const size_t per = n_units_total / (size_t)world * unit_bytes;
+    return g_rccl.AllGather(d + (size_t)rank * per, d, per, ncclUint8, comm, stream);
+  }
+  ncclResult_t r = ncclSuccess;
+  for (int root = 0; root < world && r == ncclSuccess; root++) {
+    size_t first = 0, count = 0;
+    uc_partition(n_units_total, world, root, &first, &count);
+    if (count) r = g_rccl.Broadcast(d + first * unit_bytes, d + first * unit_bytes, count * unit_bytes, ncclUint8, root, comm, stream);
+  }
+  return r;
+}
 
 }  // namespace
 
@@ -228,7 +290,8 @@ void uc_group_destroy(uc_group* g) {
     if (L.kernel_done) (void)hipEventDestroy(L.kernel_done);
     if (L.compute) (void)hipStreamDestroy(L.compute);
     if (L.gather) (void)hipStreamDestroy(L.gather);
-    if (L.d_gathered) (void)hipFree(L.d_gathered);
+    for (void* p : L.d_stage)
+      if (p) (void)hipFree(p);
   }
   (void)hipGetLastError();  // (HIP's last-error slot is sticky: leave nothing of the teardown for the next launch to report)
   delete g;
@@ -330,8 +393,6 @@ uc_ctx* uc_group_ctx(uc_group* g, int local) {
   return g->loc[(size_t)local].ctx;
 }
 
-static bool overlaps(const uint8_t* a, size_t na, const uint8_t* b, size_t nb) { return a < b + nb && b < a + na; }
-
 int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, size_t n_frames_total, size_t stride_elems,
                            uint8_t* const* gathered, void* const* hip_streams) {
   if (!g || !frames || !gathered) return fail(-EINVAL, "uc_group_process_batch: NULL argument");
@@ -354,27 +415,10 @@ int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, si
     uint8_t* d = gathered[l];
     if (!is_device_ptr(d)) {
       any_host = true;
-      if (L.d_gathered_cap < n_frames_total) {
-        if (L.d_gathered) (void)hipFree(L.d_gathered);
-        L.d_gathered = nullptr;
-        L.d_gathered_cap = 0;
-        e = hipMalloc(&L.d_gathered, n_frames_total);
-        if (e != hipSuccess) return hip_fail(e, "hipMalloc(gathered)");
-        L.d_gathered_cap = n_frames_total;
-      }
-      d = (uint8_t*)L.d_gathered;
+      if (const int rc = stage_buffer(L, 0, n_frames_total, &d)) return rc;
     }
     dst[(size_t)l] = d;
-    // write-after-gather: an earlier gather that still reads or writes this buffer must be done before the kernel
-    // overwrites the rank's slice of it (device-side wait, nothing blocks here)
-    // ... and the ring slot this step will recycle: a gather that drops out of the ring must be complete before anything
-    // newer runs, or a caller rotating more than kHazardRing buffers could overwrite one behind the guard's back
-    const unsigned recycle = L.hz_next % kHazardRing;
-    for (int k = 0; k < kHazardRing; k++)
-      if (L.hz_buf[k] && ((unsigned)k == recycle || overlaps(L.hz_buf[k], L.hz_bytes[k], d, n_frames_total))) {
-        e = hipStreamWaitEvent(cs, L.hz_ev[k], 0);
-        if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(gather -> kernel)");
-      }
+    if (const int rc = hazard_wait(L, cs, d, n_frames_total, 1)) return rc;
     if (count) {
       const int rc = uc_process_batch(L.ctx, frames[l], dtype, count, stride_elems, nullptr, d + first, nullptr, cs);
       if (rc) return rc;
@@ -389,18 +433,7 @@ int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, si
   if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
   for (int l = 0; l < nl && r == ncclSuccess; l++) {
     Local& L = g->loc[(size_t)l];
-    uint8_t* d = dst[(size_t)l];
-    if (even) {
-      const size_t per = n_frames_total / (size_t)g->world;
-      r = g_rccl.AllGather(d + (size_t)(g->first_rank + l) * per, d, per, ncclUint8, L.comm, L.gather);
-    } else {
-      // ragged shares: one broadcast per rank, each slice from its owner
-      for (int root = 0; root < g->world && r == ncclSuccess; root++) {
-        size_t first = 0, count = 0;
-        uc_partition(n_frames_total, g->world, root, &first, &count);
-        if (count) r = g_rccl.Broadcast(d + first, d + first, count, ncclUint8, root, L.comm, L.gather);
-      }
-    }
+    r = gather_in_place(g->world, g->first_rank + l, dst[(size_t)l], 1, n_frames_total, L.comm, L.gather);
   }
   const ncclResult_t r2 = g_rccl.GroupEnd();
   if (r != ncclSuccess) return nccl_fail(r, even ? "ncclAllGather" : "ncclBroadcast");
@@ -411,11 +444,7 @@ int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, si
     Local& L = g->loc[(size_t)l];
     hipError_t e = hipSetDevice(L.device);
     if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-    const unsigned k = L.hz_next++ % kHazardRing;
-    e = hipEventRecord(L.hz_ev[k], L.gather);
-    if (e != hipSuccess) return hip_fail(e, "hipEventRecord(gather)");
-    L.hz_buf[k] = dst[(size_t)l];
-    L.hz_bytes[k] = n_frames_total;
+    if (const int rc = hazard_record(L, dst[(size_t)l], n_frames_total)) return rc;
     if (dst[(size_t)l] != gathered[l]) {
       e = hipMemcpyAsync(gathered[l], dst[(size_t)l], n_frames_total, hipMemcpyDeviceToHost, L.gather);
       if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(gathered)");
@@ -423,6 +452,114 @@ int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, si
   }
   if (any_host) return uc_group_synchronize(g);
   return 0;
+}
+
+// uc_group_receive_streams / _next: "replicas across streams"  -- the streams are block-partitioned over
+// the ranks, every local device runs the multi-stream receiver (ISR FIFO, dsp() at every 256-sample offset, main()'s switch
+// replayed on the device: receiver/Src/main.c:417-554, 243-273, 659-668) over its share and writes texts and counts into
+// its slice of the gathered arrays; both arrays are then all-gathered in place behind an event, as the symbol stream is.
+static int group_receive(uc_group* g, uc_rx_state* const* states, const void* const* samples, int dtype, size_t n_streams_total,
+                         size_t n_samples, size_t stream_stride_elems, const uint8_t* const* busy, char* const* text,
+                         size_t text_cap, uint32_t* const* n_text, void* const* hip_streams, const char* who) {
+  if (!g || !samples || !text) return fail(-EINVAL, "%s: NULL argument", who);
+  if (text_cap == 0) return fail(-EINVAL, "%s: text_cap is 0", who);
+  if (n_streams_total == 0) return 0;
+  const int nl = (int)g->loc.size();
+  const size_t text_bytes = n_streams_total * text_cap, cnt_bytes = n_streams_total * sizeof(uint32_t);
+  std::vector<uint8_t*> dtext((size_t)nl, nullptr), dcnt((size_t)nl, nullptr);
+  bool any_host = false;
+
+  for (int l = 0; l < nl; l++) {
+    Local& L = g->loc[(size_t)l];
+    size_t first = 0, count = 0;
+    uc_partition(n_streams_total, g->world, g->first_rank + l, &first, &count);
+    if (!text[l]) return fail(-EINVAL, "%s: text[%d] is NULL", who, l);
+    if (states) {
+      if (!states[l]) return fail(-EINVAL, "%s: states[%d] is NULL", who, l);
+      if (uc_rx_state_streams(states[l]) != count)
+        return fail(-EINVAL, "%s: states[%d] holds %zu streams, rank %d owns %zu of %zu", who, l, uc_rx_state_streams(states[l]),
+                    g->first_rank + l, count, n_streams_total);
+    }
+    hipError_t e = hipSetDevice(L.device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipStream_t cs = (hip_streams && hip_streams[l]) ? (hipStream_t)hip_streams[l] : L.compute;
+    uint8_t* dt = (uint8_t*)text[l];
+    if (!is_device_ptr(dt)) {
+      any_host = true;
+      if (const int rc = stage_buffer(L, 0, text_bytes, &dt)) return rc;
+    }
+    uint8_t* dc = nullptr;
+    if (n_text) {
+      if (!n_text[l]) return fail(-EINVAL, "%s: n_text[%d] is NULL", who, l);
+      dc = (uint8_t*)n_text[l];
+      if (!is_device_ptr(dc)) {
+        any_host = true;
+        if (const int rc = stage_buffer(L, 1, cnt_bytes, &dc)) return rc;
+      }
+    }
+    dtext[(size_t)l] = dt;
+    dcnt[(size_t)l] = dc;
+    const unsigned n_new = dc ? 2u : 1u;
+    if (const int rc = hazard_wait(L, cs, dt, text_bytes, n_new)) return rc;
+    if (dc)
+      if (const int rc = hazard_wait(L, cs, dc, cnt_bytes, 0)) return rc;
+    if (count) {
+      char* t = (char*)dt + first * text_cap;
+      uint32_t* c = dc ? (uint32_t*)dc + first : nullptr;
+      const uint8_t* b = (busy && busy[l]) ? busy[l] : nullptr;
+      const int rc = states ? uc_receive_streams_next(L.ctx, states[l], samples[l], dtype, n_samples, stream_stride_elems, b, t,
+                                                      text_cap, c, nullptr, 0, nullptr, cs)
+                            : uc_receive_streams(L.ctx, samples[l], dtype, count, n_samples, stream_stride_elems, b, t, text_cap,
+                                                 c, nullptr, 0, nullptr, cs);
+      if (rc) return rc;
+    }
+    e = hipEventRecord(L.kernel_done, cs);
+    if (e == hipSuccess) e = hipStreamWaitEvent(L.gather, L.kernel_done, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipEventRecord / hipStreamWaitEvent(receiver -> gather)");
+  }
+
+  ncclResult_t r = g_rccl.GroupStart();
+  if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
+  for (int l = 0; l < nl && r == ncclSuccess; l++) {
+    Local& L = g->loc[(size_t)l];
+    r = gather_in_place(g->world, g->first_rank + l, dtext[(size_t)l], text_cap, n_streams_total, L.comm, L.gather);
+    if (r == ncclSuccess && dcnt[(size_t)l])
+      r = gather_in_place(g->world, g->first_rank + l, dcnt[(size_t)l], sizeof(uint32_t), n_streams_total, L.comm, L.gather);
+  }
+  const ncclResult_t r2 = g_rccl.GroupEnd();
+  if (r != ncclSuccess) return nccl_fail(r, "ncclAllGather / ncclBroadcast (texts)");
+  if (r2 != ncclSuccess) return nccl_fail(r2, "ncclGroupEnd");
+
+  for (int l = 0; l < nl; l++) {
+    Local& L = g->loc[(size_t)l];
+    hipError_t e = hipSetDevice(L.device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (const int rc = hazard_record(L, dtext[(size_t)l], text_bytes)) return rc;
+    if (dcnt[(size_t)l])
+      if (const int rc = hazard_record(L, dcnt[(size_t)l], cnt_bytes)) return rc;
+    if (dtext[(size_t)l] != (uint8_t*)text[l]) e = hipMemcpyAsync(text[l], dtext[(size_t)l], text_bytes, hipMemcpyDeviceToHost, L.gather);
+    if (e == hipSuccess && dcnt[(size_t)l] && dcnt[(size_t)l] != (uint8_t*)n_text[l])
+      e = hipMemcpyAsync(n_text[l], dcnt[(size_t)l], cnt_bytes, hipMemcpyDeviceToHost, L.gather);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(gathered texts)");
+  }
+  if (any_host) return uc_group_synchronize(g);
+  return 0;
+}
+
+int uc_group_receive_streams(uc_group* g, const void* const* samples, int dtype, size_t n_streams_total, size_t n_samples,
+                             size_t stream_stride_elems, const uint8_t* const* busy, char* const* text, size_t text_cap,
+                             uint32_t* const* n_text, void* const* hip_streams) {
+  return group_receive(g, nullptr, samples, dtype, n_streams_total, n_samples, stream_stride_elems, busy, text, text_cap, n_text,
+                       hip_streams, "uc_group_receive_streams");
+}
+
+int uc_group_receive_streams_next(uc_group* g, uc_rx_state* const* states, const void* const* samples, int dtype,
+                                  size_t n_streams_total, size_t n_samples, size_t stream_stride_elems,
+                                  const uint8_t* const* busy, char* const* text, size_t text_cap, uint32_t* const* n_text,
+                                  void* const* hip_streams) {
+  if (!states) return fail(-EINVAL, "uc_group_receive_streams_next: states is NULL");
+  return group_receive(g, states, samples, dtype, n_streams_total, n_samples, stream_stride_elems, busy, text, text_cap, n_text,
+                       hip_streams, "uc_group_receive_streams_next");
 }
 
 int uc_group_wait_gather(uc_group* g, int local, const uint8_t* gathered, void* hip_stream) {

@@ -36,7 +36,8 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_group_destroy", "uc_group_world", "uc_group_local_count", "uc_group_first_rank", "uc_group_ctx",
            "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
            "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters",
-           "uc_rx_state_create", "uc_rx_state_reset", "uc_rx_state_destroy", "uc_receive_streams_next"]
+           "uc_rx_state_create", "uc_rx_state_reset", "uc_rx_state_destroy", "uc_receive_streams_next",
+           "uc_rx_state_streams", "uc_group_receive_streams", "uc_group_receive_streams_next"]
 GROUP_ID_BYTES = 128
 
 
@@ -147,6 +148,13 @@ def lib():
     L.uc_rx_state_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.uc_rx_state_destroy.argtypes = [C.c_void_p]
     L.uc_rx_state_destroy.restype = None
+    L.uc_rx_state_streams.argtypes = [C.c_void_p]
+    L.uc_rx_state_streams.restype = C.c_size_t
+    VPP = C.POINTER(C.c_void_p)
+    L.uc_group_receive_streams.argtypes = [C.c_void_p, VPP, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, VPP, VPP, C.c_size_t,
+                                           VPP, VPP]
+    L.uc_group_receive_streams_next.argtypes = [C.c_void_p, VPP, VPP, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, VPP, VPP,
+                                                C.c_size_t, VPP, VPP]
     L.uc_receive_streams_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
                                           C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
     L.uc_clock_probe.argtypes = [C.c_void_p, C.c_int]
@@ -614,6 +622,39 @@ class Group:
             sa = (C.c_void_p * nl)(*[int(s) if s else None for s in streams])
         _check(lib().uc_group_process_batch(self._h, fa, dtype, int(n_frames_total), int(stride), ga, sa),
                "uc_group_process_batch")
+
+    def receive_streams(self, samples, n_streams_total, n_samples, text, text_cap, n_text=None, busy=None, stride=0,
+                        streams=None, dtype=DTYPE_F32, states=None):
+        """uc_group_receive_streams (states=None) / uc_group_receive_streams_next (states = one rx-state handle per local
+        device): samples / text / n_text / busy: one tensor / array / address per LOCAL device (the share's first stream;
+        the gathered n_streams_total x text_cap bytes; the gathered n_streams_total uint32)."""
+        nl = self.n_local
+        if len(samples) != nl or len(text) != nl:
+            raise ValueError("one samples / text entry per local device (%d)" % nl)
+        arr = lambda xs: (C.c_void_p * nl)(*[self._ptr(x) for x in xs]) if xs is not None else None
+        sa = None
+        if streams is not None:
+            sa = (C.c_void_p * nl)(*[int(s) if s else None for s in streams])
+        if states is None:
+            _check(lib().uc_group_receive_streams(self._h, arr(samples), dtype, int(n_streams_total), int(n_samples), int(stride),
+                                                  arr(busy), arr(text), int(text_cap), arr(n_text), sa),
+                   "uc_group_receive_streams")
+        else:
+            st = (C.c_void_p * nl)(*[x._h if hasattr(x, "_h") else x for x in states])
+            _check(lib().uc_group_receive_streams_next(self._h, st, arr(samples), dtype, int(n_streams_total), int(n_samples),
+                                                       int(stride), arr(busy), arr(text), int(text_cap), arr(n_text), sa),
+                   "uc_group_receive_streams_next")
+
+    def rx_state(self, local, n_streams):
+        """uc_rx_state_create on the context of local device `local` -> a raw handle (free with rx_state_destroy)."""
+        h = C.c_void_p()
+        _check(lib().uc_rx_state_create(C.c_void_p(lib().uc_group_ctx(self._h, int(local))), int(n_streams), C.byref(h)),
+               "uc_rx_state_create")
+        return h
+
+    @staticmethod
+    def rx_state_destroy(h):
+        lib().uc_rx_state_destroy(h)
 
     def wait_gather(self, local, gathered, stream):
         _check(lib().uc_group_wait_gather(self._h, int(local), C.c_void_p(self._ptr(gathered)), C.c_void_p(int(stream) if stream else None)),
