@@ -383,6 +383,8 @@ int uc_dfsdm_sinc5(uc_ctx* ctx, const uint32_t* pdm_words, size_t n_words, int32
  * data-path collective) and the only exchange is the all-gather of the decoded symbol stream, 1 byte per frame, over
  * RCCL / xGMI.  A uc_group is that arrangement behind this C-ABI: one uc_ctx per device, one RCCL communicator, one
  * gather stream per device.  Two ways to build one:
+ * (Frames: uc_group_process_batch.  Whole microphone streams: uc_group_receive_streams[_next].  The blocks of ONE long
+ * UC_STREAM stream: uc_group_process_stream.)
  *   uc_group_create        ONE process drives n_devices GPUs (ncclCommInitAll); rank r = devices[r]
  *   uc_group_create_rank   one process per GPU (how bench.py is launched): rank `rank` of `world`, device cfg->device;
  *                          rank 0 calls uc_group_unique_id and hands the 128 bytes to the others by any means it has
@@ -471,6 +473,20 @@ int uc_group_receive_streams_next(uc_group* g, uc_rx_state* const* states, const
                                   size_t n_streams_total, size_t n_samples, size_t stream_stride_elems,
                                   const uint8_t* const* busy /*nullable*/, char* const* text, size_t text_cap,
                                   uint32_t* const* n_text /*nullable*/, void* const* hip_streams /*nullable*/);
+
+/*
+ * UC_STREAM over the GPUs of a node (a group made from a UC_STREAM config).  The overlap-save blocks of the stream are
+ * independent: rank r processes the samples uc_stream_span() names (its first `halo` samples are history it shares, read-only,
+ * with the previous rank -- no exchange) and the block boundaries are those of the one-GPU run, so every value is the one
+ * uc_process_stream gives for the whole stream.
+ *   samples[l]     the shard of rank (first + l): sample *first_sample of the stream, *n_shard samples (uc_stream_span)
+ *   compressed     (nullable array, nullable entries) compressed[l]: the rank's OWN *n_out outputs -- outputs *first_out ... of
+ *                  the stream; the envelope stays where it was computed (4 / D bytes per input sample)
+ *   peaks[l]       n_blocks records (uc_stream_geometry of n_samples_total): the peak record of EVERY block of the stream,
+ *                  all-gathered in place (8 bytes per block) as uc_group_process_batch gathers symbols; same rules
+ */
+int uc_group_process_stream(uc_group* g, const void* const* samples, int dtype, size_t n_samples_total,
+                            float* const* compressed /*nullable*/, uc_peak* const* peaks, void* const* hip_streams /*nullable*/);
 
 /* Plain-C hosts without the HIP headers: device memory by ordinal.  uc_device_copy: either side may be host or device
  * memory (hipMemcpyDefault), synchronous. */

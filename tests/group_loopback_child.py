@@ -126,6 +126,41 @@ def run_receive(variant, world, ns, blocks=150, cap=24):
     return sum(m in t for m, t in zip(msgs, want))
 
 
+
+# ---- uc_group_process_stream: the overlap-save blocks of ONE stream over the ranks, peak records gathered -------------------
+def run_stream(world, n_dec, dtype_i32=False):
+    global checks
+    eng = uchirp.Engine(uchirp.STREAM)
+    halo = eng.stream_geometry(0)[0]
+    x = (np.random.default_rng(world + n_dec).standard_normal(halo + 8 * n_dec) * 1000).astype(np.float32)
+    if dtype_i32:
+        x = (np.round(x).astype(np.int64) * 256).astype(np.int32)
+    _, n_out, n_blocks, hop = eng.stream_geometry(x.size)
+    want, want_pk = eng.process_stream(x)
+    eng.close()
+    g = uchirp.Group(uchirp.STREAM, devices=[0] * world)
+    spans = [g.stream_span(x.size, r) for r in range(world)]
+    # every rank holds ITS shard only (16-byte aligned copies)
+    xs = [torch.from_numpy(np.ascontiguousarray(x[s0:s0 + ns])).to(dev) if ns else torch.zeros(4, device=dev) for s0, ns, q0, nq in spans]
+    comp = [torch.zeros(max(nq, 1), dtype=torch.float32, device=dev) for s0, ns, q0, nq in spans]
+    pk = [torch.full((n_blocks, 2), -1, dtype=torch.int32, device=dev) for _ in range(world)]
+    for _ in range(3):
+        g.process_stream(xs, x.size, pk, compressed=comp, dtype=uchirp.DTYPE_I32 if dtype_i32 else uchirp.DTYPE_F32)
+    g.synchronize()
+    got = np.zeros_like(want)
+    for r, (s0, ns, q0, nq) in enumerate(spans):
+        got[q0:q0 + nq] = comp[r].cpu().numpy()[:nq]
+        assert np.array_equal(uchirp.peaks_from_tensor(pk[r]).view(np.uint8), want_pk.view(np.uint8)), (world, n_dec, r)
+        checks += 1
+    assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (world, n_dec)
+    g.close()
+
+
+run_stream(2, 60000)
+run_stream(3, 61000)            # ragged: the blocks do not divide by three
+run_stream(8, 9000)             # fewer blocks than ranks
+run_stream(4, 40000, dtype_i32=True)
+
 decoded = run_receive(uchirp.RX_REAL, 2, 24) + run_receive(uchirp.SYNC_CPLX, 3, 25) + run_receive(uchirp.SYNC_CPLX, 4, 24)
 run_receive(uchirp.RX_REAL, 8, 5)                           # more ranks than streams
 assert decoded >= 25

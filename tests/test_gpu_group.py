@@ -99,8 +99,14 @@ def test_group_host_pointers_and_int32_words(uchirp):
 def test_group_error_paths(uchirp):
     with pytest.raises(uchirp.UchirpError):
         uchirp.Group(uchirp.RX_REAL, devices=[0, 0])
+    gs = uchirp.Group(uchirp.STREAM, devices=[0])                      # a UC_STREAM group has no frames ...
     with pytest.raises(uchirp.UchirpError):
-        uchirp.Group(uchirp.STREAM, devices=[0])
+        gs.process([np.zeros(4096, np.float32)], 2, [np.zeros(2, np.uint8)])
+    gs.close()
+    g0 = uchirp.Group(uchirp.RX_REAL, devices=[0])                     # ... and a frame group no overlap-save blocks
+    with pytest.raises(uchirp.UchirpError):
+        g0.process_stream([np.zeros(40000, np.float32)], 40000, [np.zeros((8, 2), np.uint32)])
+    g0.close()
     with pytest.raises(uchirp.UchirpError):
         uchirp.Group(uchirp.RX_REAL, devices=[7])                      # no such device on this box
     with pytest.raises(ValueError):
@@ -258,3 +264,33 @@ def test_plain_c_host_serves_the_microphones_of_a_node(tmp_path):
     for s, m in enumerate(("Hello World!", "uchirp", "MI355X", "0123456789", "Hello World!", "uchirp")):
         assert ('stream %d received "%s"' % (s, m)) in out.stdout
     print(out.stdout.strip().splitlines()[-3:])
+
+
+def test_group_process_stream_of_one_device_equals_the_engine(uchirp):
+    """uc_group_process_stream at world size 1: the compressed envelope and the gathered peak records are the engine's, bit for
+    bit, from device buffers (asynchronous, rotating and reused peak buffers) and from host buffers."""
+    import torch
+    eng = uchirp.Engine(uchirp.STREAM)
+    halo = eng.stream_geometry(0)[0]
+    x = (np.random.default_rng(3).standard_normal(halo + 8 * 50000) * 1000).astype(np.float32)
+    _, n_out, n_blocks, hop = eng.stream_geometry(x.size)
+    want, want_pk = eng.process_stream(x)
+    g = uchirp.Group(uchirp.STREAM, devices=[0])
+    assert g.stream_span(x.size, 0) == (0, x.size, 0, n_out)
+    xd = torch.from_numpy(x).to("cuda:0")
+    comp = torch.zeros(n_out, dtype=torch.float32, device="cuda:0")
+    pk = [torch.zeros((n_blocks, 2), dtype=torch.int32, device="cuda:0") for _ in range(2)]
+    for k in range(5):
+        g.process_stream([xd], x.size, [pk[k % 2]], compressed=[comp])
+    g.synchronize()
+    assert np.array_equal(comp.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    for b in pk:
+        assert np.array_equal(uchirp.peaks_from_tensor(b).view(np.uint8), want_pk.view(np.uint8))
+    ph = np.zeros(n_blocks, uchirp.PEAK_DTYPE)
+    ch = np.zeros(n_out, np.float32)
+    g.process_stream([x], x.size, [ph], compressed=[ch])
+    assert np.array_equal(ph.view(np.uint8), want_pk.view(np.uint8)) and np.array_equal(ch.view(np.uint32), want.view(np.uint32))
+    g.process_stream([x], x.size, [ph])                                # peaks only
+    assert np.array_equal(ph.view(np.uint8), want_pk.view(np.uint8))
+    g.close()
+    eng.close()

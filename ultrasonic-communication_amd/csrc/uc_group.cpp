@@ -326,7 +326,6 @@ int uc_group_create(const uc_config* cfg, const int32_t* devices, int n_devices,
   for (int a = 0; a < n_devices && !share; a++)
     for (int b = a + 1; b < n_devices; b++)
       if (devices[a] == devices[b]) return fail(-EINVAL, "uc_group_create: device %d named twice", (int)devices[a]);
-  if (cfg->variant == UC_STREAM) return fail(-ENOTSUP, "uc_group_create: UC_STREAM has no frames (shard it with uc_stream_span)");
   int rc = load_rccl();
   if (rc) return rc;
   uc_group* g = new (std::nothrow) uc_group();
@@ -354,7 +353,6 @@ int uc_group_create_rank(const uc_config* cfg, const void* id, int world, int ra
   if (!cfg || !id || !out) return fail(-EINVAL, "uc_group_create_rank: NULL argument");
   *out = nullptr;
   if (world <= 0 || rank < 0 || rank >= world) return fail(-EINVAL, "uc_group_create_rank: rank %d of %d", rank, world);
-  if (cfg->variant == UC_STREAM) return fail(-ENOTSUP, "uc_group_create_rank: UC_STREAM has no frames (shard it with uc_stream_span)");
   int rc = load_rccl();
   if (rc) return rc;
   uc_group* g = new (std::nothrow) uc_group();
@@ -560,6 +558,71 @@ int uc_group_receive_streams_next(uc_group* g, uc_rx_state* const* states, const
   if (!states) return fail(-EINVAL, "uc_group_receive_streams_next: states is NULL");
   return group_receive(g, states, samples, dtype, n_streams_total, n_samples, stream_stride_elems, busy, text, text_cap, n_text,
                        hip_streams, "uc_group_receive_streams_next");
+}
+
+// uc_group_process_stream: UC_STREAM over the GPUs of a node.  The overlap-save BLOCKS of a stream are independent, so the
+// stream shards by whole blocks (uc_stream_span: block boundaries as in the one-GPU run, every shard re-reads the `halo`
+// samples in front of it -- read-only duplication, no exchange); the compressed envelope stays where it was computed
+// (4 / D bytes per input sample: nothing anybody wants on every GPU), the per-block peak records (8 bytes per block) are
+// all-gathered in place like the symbol stream.
+int uc_group_process_stream(uc_group* g, const void* const* samples, int dtype, size_t n_samples_total, float* const* compressed,
+                            uc_peak* const* peaks, void* const* hip_streams) {
+  if (!g || !samples || !peaks) return fail(-EINVAL, "uc_group_process_stream: NULL argument");
+  const int nl = (int)g->loc.size();
+  size_t n_out_total = 0, n_blocks = 0, hop = 0;
+  if (const int rc = uc_stream_geometry(g->loc[0].ctx, n_samples_total, nullptr, &n_out_total, &n_blocks, &hop)) return rc;
+  if (n_blocks == 0) return 0;
+  const size_t peak_bytes = n_blocks * sizeof(uc_peak);
+  std::vector<uint8_t*> dst((size_t)nl, nullptr);
+  bool any_host = false;
+  for (int l = 0; l < nl; l++) {
+    Local& L = g->loc[(size_t)l];
+    size_t first_sample = 0, n_shard = 0, first_out = 0, n_out = 0;
+    if (const int rc = uc_stream_span(L.ctx, n_samples_total, g->world, g->first_rank + l, &first_sample, &n_shard, &first_out, &n_out))
+      return rc;
+    if (!peaks[l]) return fail(-EINVAL, "uc_group_process_stream: peaks[%d] is NULL", l);
+    if (n_out && !samples[l]) return fail(-EINVAL, "uc_group_process_stream: samples[%d] is NULL", l);
+    hipError_t e = hipSetDevice(L.device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    hipStream_t cs = (hip_streams && hip_streams[l]) ? (hipStream_t)hip_streams[l] : L.compute;
+    uint8_t* d = (uint8_t*)peaks[l];
+    if (!is_device_ptr(d)) {
+      any_host = true;
+      if (const int rc = stage_buffer(L, 0, peak_bytes, &d)) return rc;
+    }
+    dst[(size_t)l] = d;
+    if (const int rc = hazard_wait(L, cs, d, peak_bytes, 1)) return rc;
+    if (n_out) {
+      // (uc_stream_span cuts at multiples of the hop: the shard's first block is block first_out / hop of the stream)
+      uc_peak* mine = (uc_peak*)d + first_out / hop;
+      float* comp = (compressed && compressed[l]) ? compressed[l] : nullptr;
+      if (const int rc = uc_process_stream(L.ctx, samples[l], dtype, n_shard, comp, mine, cs)) return rc;
+    }
+    e = hipEventRecord(L.kernel_done, cs);
+    if (e == hipSuccess) e = hipStreamWaitEvent(L.gather, L.kernel_done, 0);
+    if (e != hipSuccess) return hip_fail(e, "hipEventRecord / hipStreamWaitEvent(stream kernel -> gather)");
+  }
+  ncclResult_t r = g_rccl.GroupStart();
+  if (r != ncclSuccess) return nccl_fail(r, "ncclGroupStart");
+  for (int l = 0; l < nl && r == ncclSuccess; l++) {
+    Local& L = g->loc[(size_t)l];
+    r = gather_in_place(g->world, g->first_rank + l, dst[(size_t)l], sizeof(uc_peak), n_blocks, L.comm, L.gather);
+  }
+  const ncclResult_t r2 = g_rccl.GroupEnd();
+  if (r != ncclSuccess) return nccl_fail(r, "ncclAllGather / ncclBroadcast (peaks)");
+  if (r2 != ncclSuccess) return nccl_fail(r2, "ncclGroupEnd");
+  for (int l = 0; l < nl; l++) {
+    Local& L = g->loc[(size_t)l];
+    hipError_t e = hipSetDevice(L.device);
+    if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+    if (const int rc = hazard_record(L, dst[(size_t)l], peak_bytes)) return rc;
+    if (dst[(size_t)l] != (uint8_t*)peaks[l]) {
+      e = hipMemcpyAsync(peaks[l], dst[(size_t)l], peak_bytes, hipMemcpyDeviceToHost, L.gather);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(gathered peaks)");
+    }
+  }
+  if (any_host) return uc_group_synchronize(g);
+  return 0;
 }
 
 int uc_group_wait_gather(uc_group* g, int local, const uint8_t* gathered, void* hip_stream) {

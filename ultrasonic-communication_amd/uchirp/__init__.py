@@ -37,7 +37,7 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
            "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters",
            "uc_rx_state_create", "uc_rx_state_reset", "uc_rx_state_destroy", "uc_receive_streams_next",
-           "uc_rx_state_streams", "uc_group_receive_streams", "uc_group_receive_streams_next"]
+           "uc_rx_state_streams", "uc_group_receive_streams", "uc_group_receive_streams_next", "uc_group_process_stream"]
 GROUP_ID_BYTES = 128
 
 
@@ -153,6 +153,7 @@ def lib():
     VPP = C.POINTER(C.c_void_p)
     L.uc_group_receive_streams.argtypes = [C.c_void_p, VPP, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, VPP, VPP, C.c_size_t,
                                            VPP, VPP]
+    L.uc_group_process_stream.argtypes = [C.c_void_p, VPP, C.c_int, C.c_size_t, VPP, VPP, VPP]
     L.uc_group_receive_streams_next.argtypes = [C.c_void_p, VPP, VPP, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, VPP, VPP,
                                                 C.c_size_t, VPP, VPP]
     L.uc_receive_streams_next.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p,
@@ -644,6 +645,26 @@ class Group:
             _check(lib().uc_group_receive_streams_next(self._h, st, arr(samples), dtype, int(n_streams_total), int(n_samples),
                                                        int(stride), arr(busy), arr(text), int(text_cap), arr(n_text), sa),
                    "uc_group_receive_streams_next")
+
+    def process_stream(self, samples, n_samples_total, peaks, compressed=None, streams=None, dtype=DTYPE_F32):
+        """uc_group_process_stream: samples / peaks / compressed: one tensor / array / address per LOCAL device (the shard
+        uc_stream_span names; the gathered n_blocks x 8 bytes of peak records; the rank's own outputs or None)."""
+        nl = self.n_local
+        if len(samples) != nl or len(peaks) != nl:
+            raise ValueError("one samples / peaks entry per local device (%d)" % nl)
+        arr = lambda xs: (C.c_void_p * nl)(*[self._ptr(x) for x in xs]) if xs is not None else None
+        sa = None
+        if streams is not None:
+            sa = (C.c_void_p * nl)(*[int(s) if s else None for s in streams])
+        _check(lib().uc_group_process_stream(self._h, arr(samples), dtype, int(n_samples_total), arr(compressed), arr(peaks), sa),
+               "uc_group_process_stream")
+
+    def stream_span(self, n_samples_total, rank):
+        """uc_stream_span on the group's first context -> (first_sample, n_shard, first_out, n_out) of `rank`."""
+        v = [C.c_size_t() for _ in range(4)]
+        _check(lib().uc_stream_span(C.c_void_p(lib().uc_group_ctx(self._h, 0)), int(n_samples_total), self.world, int(rank),
+                                    *[C.byref(x) for x in v]), "uc_stream_span")
+        return tuple(x.value for x in v)
 
     def rx_state(self, local, n_streams):
         """uc_rx_state_create on the context of local device `local` -> a raw handle (free with rx_state_destroy)."""
