@@ -164,4 +164,25 @@ run_stream(4, 40000, dtype_i32=True)
 decoded = run_receive(uchirp.RX_REAL, 2, 24) + run_receive(uchirp.SYNC_CPLX, 3, 25) + run_receive(uchirp.SYNC_CPLX, 4, 24)
 run_receive(uchirp.RX_REAL, 8, 5)                           # more ranks than streams
 assert decoded >= 25
+
+# ---- random draws (tools/fuzz_round.sh: UC_LOOPBACK_FUZZ="<cases> <seed>"; the pytest run makes none) ---------------------
+fz = os.environ.get("UC_LOOPBACK_FUZZ", "").split()
+if fz:
+    rng = np.random.default_rng(int(fz[1]))
+    for case in range(int(fz[0])):
+        world = int(rng.integers(1, 9))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:      # frames: any count (fewer than ranks included), contiguous or overlapping FIFO reads, either reference
+            nf = int(rng.choice([1, 3, world - 1 or 1, world + 1, 117, 1000, 4099]))
+            variant = [uchirp.RX_REAL, uchirp.SYNC_CPLX][int(rng.integers(0, 2))]   # (not DECHIRP_DOWN: its frame PAIRS are
+            # formed inside a shard, and a frame's round-off depends on its partner)
+            stride = int(rng.choice([0, 256, 512]))
+            fr = synth.device_frames(nf, dev, seed=int(rng.integers(1 << 30)), snr_db=float(rng.choice([-10.0, 0.0])))[0].reshape(-1)
+            nfr = nf if stride == 0 else (fr.numel() - N) // stride + 1
+            run(variant, dict(mag_mean=1000.0), fr, nfr, stride, 0, world, steps=int(rng.integers(3, 12)))       # (>= 3: the check reads all three rotating buffers)
+        elif kind == 1:    # whole microphone streams
+            run_receive([uchirp.RX_REAL, uchirp.SYNC_CPLX][int(rng.integers(0, 2))], world, int(rng.integers(1, 20)))
+        else:              # the blocks of one UC_STREAM stream
+            run_stream(world, int(rng.integers(1, 40000)), dtype_i32=bool(rng.integers(0, 2)))
+    print("loopback fuzz: %d random cases, 0 failures" % int(fz[0]))
 print("loopback ok: %d gathered buffers checked" % checks)
