@@ -6,6 +6,6 @@ for cmd in "tools/fuzz_parity.py 600 41" "tools/fuzz_strides.py 400 43" "tools/f
 done
 echo "== group logic at random world sizes (loop-back stand-in for RCCL): tests/group_loopback_child.py, UC_LOOPBACK_FUZZ"
 g++ -std=c++17 -O2 -fPIC -shared -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/stubs/loopback_rccl.cpp -o /tmp/libloopback_rccl.so -L/opt/rocm/lib -lamdhip64 -lrt 2>/dev/null
-UC_TUNING=1 UC_RCCL_LIB=/tmp/libloopback_rccl.so UC_GROUP_SHARE_DEVICES=1 UC_LOOPBACK_FUZZ="120 53" timeout -k 10 900 python tests/group_loopback_child.py 2>&1 | tail -2
+UC_TUNING=1 UC_RCCL_LIB=/tmp/libloopback_rccl.so UC_GROUP_SHARE_DEVICES=1 UC_LOOPBACK_FUZZ="150 53" timeout -k 10 900 python tests/group_loopback_child.py 2>&1 | tail -2
 echo "== python tools/soak.py"
 timeout -k 10 600 python tools/soak.py 2>&1 | tail -12
