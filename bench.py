@@ -317,7 +317,8 @@ def live_clock(eng, launch, launches=12):
 
 def roofline(kernel_key, kernel_name, units, bytes_per_unit, kern_ms, num_cu=256, clock=None):
     """Both roofs of one launch: HBM (algorithmic bytes / kernel time / 8 TB/s) and VALU issue (wave-instructions x 4
-    cycles / (4 SIMDs x CUs x in-kernel clock x kernel time)); `bound` = the larger fraction.
+    cycles / (4 SIMDs x CUs x in-kernel clock x kernel time)).  `bound`, `achieved`, `peak`, `unit`, `frac` are the HBM roof's
+    (the one BASELINE.json's metric names: "% HBM roofline"); `limiter` says which of the two measured fractions is the larger.
     clock: live_clock()'s record of this run; without it the clock of the committed counter pass is used and labelled so."""
     achieved = units * bytes_per_unit / (kern_ms * 1e-3) / 1e9
     r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -337,8 +338,7 @@ def roofline(kernel_key, kernel_name, units, bytes_per_unit, kern_ms, num_cu=256
             r["valu"]["wave_loop_cycles_median"] = clock["wave_cycles"]
         if "lds_insts_per_unit" in v:
             r["valu"]["lds_insts_per_unit"] = v["lds_insts_per_unit"]
-        if frac > r["frac"]:
-            r["bound"] = "valu"
+        r["limiter"] = "valu" if frac > r["frac"] else "hbm"
     return r
 
 

@@ -118,7 +118,7 @@ def test_gpu_default_line_carries_every_single_gpu_config():
     d = _one_line(_run(["--frames", "65536", "--steps", "3", "--warmup", "1", "--ramp-ms", "20"], {}))
     assert d["n_gpus"] == 1 and d["config"]["workload"].startswith("configs[1]") and d["gates_failed"] == []
     # HBM traffic from the PMC counters, collected in this run (two rocprofv3 child passes): no wasted re-reads
-    assert d["roofline"]["bound"] in ("hbm", "valu") and d["roofline"]["traffic_source"].startswith("measured in this run")
+    assert d["roofline"]["bound"] == "hbm" and d["roofline"]["limiter"] in ("hbm", "valu") and d["roofline"]["traffic_source"].startswith("measured in this run")
     assert 0.99 < d["roofline"]["traffic_over_algorithmic"] < 1.05
     pw = d["roofline"]["power"]                            # hwmon telemetry of a sustained run (null without sysfs access)
     assert pw is None or (pw["cap_W"] > 0 and 100 < pw["socket_W_mean"] <= pw["cap_W"] * 1.02 and pw["sustained_frames_per_s"] > 0)

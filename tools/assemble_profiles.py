@@ -66,7 +66,7 @@ if len(sys.argv) > 2:
                   open("%s/%s_hbm_traffic.json" % (dst, tag), "w"), indent=1)
 b = json.loads(open("%s/%s_bench.json" % (dst, tag)).read())
 print("bench: %.4g frames/s, frac %.3f (%s-bound, valu %.3f), kernel %.3f ms, cpu %.3g frames/s on %d threads"
-      % (b["value"], b["roofline"]["frac"], b["roofline"]["bound"], b["roofline"].get("valu", {}).get("frac", float("nan")),
+      % (b["value"], b["roofline"]["frac"], b["roofline"].get("limiter", b["roofline"]["bound"]), b["roofline"].get("valu", {}).get("frac", float("nan")),
          b["roofline"]["kernel_ms"], b["cpu_baseline"]["value"], b["cpu_baseline"]["cores"]))
 c2, c3 = b["configs"]["configs[2]"], b["configs"]["configs[3]"]
 print("  configs[2] base band %.4g frames/s (%.3f of firmware windows %.4g)" % (c2["baseband"]["value"], c2["baseband_over_firmware_windows"], c2["firmware_windows"]["value"]))
