@@ -7,7 +7,7 @@ cd "$(dirname "$0")/.."
 for v in $variants; do
   for rep in $(seq $reps); do
     for L in $libs; do
-      if [ "$v" = rx_real ]; then args="--no-configs --no-hello1 --no-cpu-baseline"; else args="--variant $v"; fi
+      if [ "$v" = rx_real ]; then args="--no-configs --no-hello1 --no-cpu-baseline --no-receive --no-live-traffic --sustain-s 0"; else args="--variant $v"; fi
       UCHIRP_LIB=$PWD/ultrasonic-communication_amd/$L python3 bench.py $args 2>/dev/null | python3 -c "
 import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])

@@ -27,7 +27,8 @@
 #ifndef UC_BAND_KNOCK
 // diagnostic builds only (tools/band_knock.sh; results WRONG by construction, timing only), default build of RX_REAL:
 // 2 no pass-1 arithmetic, 4 no pass-2 arithmetic, 8 no pruned-pass arithmetic, 16 no exchange 1 (stores + reads),
-// 32 no exchange-2 stores, 64 no pruned-pass reads, 128 no window search
+// 32 no exchange-2 stores, 64 no pruned-pass reads, 128 no window search, 256 exchange 1 as 30 DPP row rotations (no B1, B2),
+// 512 the lane -> sample map those rotations would need (profiles/r04_dpp_exchange.txt)
 #define UC_BAND_KNOCK 0
 #endif
 #ifndef UC_CPLX_RES3
@@ -295,6 +296,16 @@ __device__ __forceinline__ void merge_window(float v0, int k0, float v1, int k1,
   }
 }
 
+// rotate a complex value S lanes to the right inside its row of 16 lanes (lane i of a row receives lane (i - S) & 15's)
+template <int S>
+__device__ __forceinline__ v2f row_ror(v2f a) {
+  v2f r;
+  // (old = the value itself: every lane of a rotation has a source, and the move then happens in place)
+  r.x = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a.x), __float_as_int(a.x), 0x120 + S, 0xf, 0xf, false));
+  r.y = __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(a.y), __float_as_int(a.y), 0x120 + S, 0xf, 0xf, false));
+  return r;
+}
+
 __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
   const float2 w = tw[idx & (kN - 1)];
   return mkv(w.x, w.y);
@@ -370,7 +381,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // ---- per-thread constants, resident for the whole batch -----------------
   const __amdgpu_buffer_rsrc_t rs_tab0 = make_rsrc(p.tab0, kN * 8);
   const __amdgpu_buffer_rsrc_t rs_tab1 = make_rsrc(p.tab1, kN * 8);
+#if UC_BAND_KNOCK & 512  // (pricing only: the lane -> sample map of the DPP exchange, lane = n1 + 16 n0 reads sample n0 + 8 n1)
+  const int voff4 = 4 * ((j >> 4) + 8 * (j & 15)), voff8 = 2 * voff4;
+#else
   const int voff8 = j * 8, voff4 = j * 4;
+#endif
   v2f wt[16];  // RX_REAL only: window*chirp table entries of this thread's samples
   if (MODE == kModeRxReal) {
 #pragma unroll
@@ -677,6 +692,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       // (wave priority: low while it issues a burst of LDS stores, raised otherwise -- the SIMD's other waves get their
       // arithmetic issued ahead of the store burst; measured +0.5-0.7 %, the opposite assignment -1.5 %)
+#if UC_BAND_KNOCK & 256  // (pricing only: exchange 1 as 30 row rotations instead of LDS stores + B1 + LDS reads + B2)
+#define UC_ROR(S) v[pk_slot16(S)] = row_ror<S>(v[pk_slot16(S)]);
+      UC_ROR(1) UC_ROR(2) UC_ROR(3) UC_ROR(4) UC_ROR(5) UC_ROR(6) UC_ROR(7) UC_ROR(8) UC_ROR(9) UC_ROR(10) UC_ROR(11)
+      UC_ROR(12) UC_ROR(13) UC_ROR(14) UC_ROR(15)
+#undef UC_ROR
+#else
       __builtin_amdgcn_s_setprio(0);
 #if !(UC_BAND_KNOCK & 16)
 #pragma unroll
@@ -687,11 +708,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       UC_STAMP(1);
       __syncthreads();  // B1
       UC_STAMP(2);
+#endif
 
       // ---- pass 2: radix-16, Ns = 16 ----------------------------------------
       // all 16 reads are issued back to back (the fence keeps hipcc from sinking them
       // next to their uses, which serialises four load->wait round trips)
-#if !(UC_BAND_KNOCK & 16)
+#if !(UC_BAND_KNOCK & (16 | 256))
 #pragma unroll
       for (int t = 0; t < 16; t++) v[t] = lds_ld(lds, rd1 + 128 * t);
 #endif
@@ -702,7 +724,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       pk_dft16(v, K, H);
 #endif
       UC_STAMP(3);
+#if !(UC_BAND_KNOCK & 256)
       __syncthreads();  // B2: every pass-2 read is done before the tile is overwritten
+#endif
       UC_STAMP(4);
       __builtin_amdgcn_s_setprio(0);
 #if !(UC_BAND_KNOCK & 32)
