@@ -28,7 +28,8 @@
 // diagnostic builds only (tools/band_knock.sh; results WRONG by construction, timing only), default build of RX_REAL:
 // 2 no pass-1 arithmetic, 4 no pass-2 arithmetic, 8 no pruned-pass arithmetic, 16 no exchange 1 (stores + reads),
 // 32 no exchange-2 stores, 64 no pruned-pass reads, 128 no window search, 256 exchange 1 as 30 DPP row rotations (no B1, B2),
-// 512 the lane -> sample map those rotations would need (profiles/r04_dpp_exchange.txt)
+// 512 the lane -> sample map those rotations would need, 1024 the raw samples through LDS in front of pass 1, 2048 (with 1024) B4
+// dropped (profiles/r04_dpp_exchange.txt)
 #define UC_BAND_KNOCK 0
 #endif
 #ifndef UC_CPLX_RES3
@@ -630,6 +631,25 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     for (int run = 0; run < kRuns; run++) {
       v2f v[16];
       // ---- pass 1: window*chirp multiply, radix-16, Ns = 1 ------------------
+#if UC_BAND_KNOCK & 1024  // (pricing only: the raw samples through LDS in front of pass 1 -- 4 b128 stores, a barrier, 4 b128 loads)
+      if (MODE == kModeRxReal) {
+        __syncthreads();
+        v4f* st4 = reinterpret_cast<v4f*>(lds);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          v4f w4;
+          w4.x = xp[2 * q].x; w4.y = xp[2 * q].y; w4.z = xp[2 * q + 1].x; w4.w = xp[2 * q + 1].y;
+          st4[j + T * q] = w4;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const v4f w4 = st4[(j ^ 1) + T * q];
+          xp[2 * q] = mkv(w4.x, w4.y);
+          xp[2 * q + 1] = mkv(w4.z, w4.w);
+        }
+      }
+#endif
       if (MODE == kModeRxReal && (UC_BAND_KNOCK & 2)) {
 #pragma unroll
         for (int t = 0; t < 16; t++) v[t] = cvt_pair<DTYPE>(xp[t >> 1]);
@@ -683,7 +703,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // B4, placed AFTER the register-only part of pass 1: the wave that finished the previous
       // frame first computes ahead instead of idling (wave 1 carries the extra pruned round).
       // It frees the tile (all pruned-pass reads done) and publishes the ring entry.
+#if !(UC_BAND_KNOCK & 2048)  // (pricing only, with 1024: the staging barrier at the loop top has taken its place)
       __syncthreads();
+#endif
       UC_STAMP(7);
       if (run == 0 && ring_n > 0 && (f & gmask) == 0) {  // a new group starts: drain the last one
         if (wave == 0) finalise(ring_f0, ring_n);
