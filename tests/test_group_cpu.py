@@ -86,3 +86,25 @@ def test_c_host_of_the_group_api_is_c99_and_runs_without_a_gpu(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "uc_group_create: -19" in out.stdout
+
+
+def test_group_entry_points_reject_bad_arguments_without_a_gpu():
+    """Every uc_group_* call checks its arguments before it touches a device: NULL groups and NULL arrays come back as -EINVAL
+    (never a crash, never a CPU path), and uc_rx_state_streams(NULL) is 0."""
+    import ctypes as C
+    L = uchirp.lib()
+    EINVAL = -22
+    null = C.c_void_p(None)
+    one = (C.c_void_p * 1)(None)
+    assert L.uc_group_process_batch(null, one, uchirp.DTYPE_F32, 10, 0, one, None) == EINVAL
+    assert L.uc_group_receive_streams(null, one, uchirp.DTYPE_F32, 4, 2048, 0, None, one, 8, None, None) == EINVAL
+    assert L.uc_group_receive_streams_next(null, one, one, uchirp.DTYPE_F32, 4, 2048, 0, None, one, 8, None, None) == EINVAL
+    assert L.uc_group_process_stream(null, one, uchirp.DTYPE_F32, 100000, None, one, None) == EINVAL
+    assert b"NULL" in L.uc_last_error()
+    assert L.uc_group_synchronize(null) == EINVAL and L.uc_group_world(null) == EINVAL
+    assert L.uc_rx_state_streams(null) == 0
+    cfg = uchirp.default_config(uchirp.RX_REAL)
+    h = C.c_void_p()
+    dev = (C.c_int32 * 2)(0, 0)
+    assert L.uc_group_create(C.byref(cfg), dev, 0, C.byref(h)) == EINVAL and not h.value          # no devices
+    assert L.uc_group_create(C.byref(cfg), dev, 2, C.byref(h)) == EINVAL and not h.value          # one device named twice
