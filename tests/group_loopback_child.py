@@ -103,6 +103,15 @@ def run_receive(variant, world, ns, blocks=150, cap=24):
         got = [bytes(t[i, :c[i]]).decode("latin-1") for i in range(ns)]
         assert got == want, (variant, world, ns, r)
         checks += 1
+    # host buffers on every rank (staged through the group, complete when the call returns)
+    th = [np.zeros((ns, cap), np.uint8) for _ in range(world)]
+    ch = [np.zeros(ns, np.uint32) for _ in range(world)]
+    xh = [np.ascontiguousarray(x[f:f + c]) if c else np.zeros(1, np.float32) for f, c in shares]
+    bh = [np.ascontiguousarray(busy[f:f + c]) if c else None for f, c in shares]
+    g.receive_streams(xh, ns, blocks * N, th, cap, n_text=ch, busy=bh)
+    for r in range(world):
+        assert [bytes(th[r][i, :ch[r][i]]).decode("latin-1") for i in range(ns)] == want, (variant, world, ns, r, "host")
+        checks += 1
     # live, in chunks of unequal sizes: every rank's share keeps its receivers between the calls
     states = [g.rx_state(r, c) if c else None for r, (f, c) in enumerate(shares)]
     if all(s is not None for s in states):
@@ -153,6 +162,13 @@ def run_stream(world, n_dec, dtype_i32=False):
         assert np.array_equal(uchirp.peaks_from_tensor(pk[r]).view(np.uint8), want_pk.view(np.uint8)), (world, n_dec, r)
         checks += 1
     assert np.array_equal(got.view(np.uint32), want.view(np.uint32)), (world, n_dec)
+    # host buffers on every rank
+    ph = [np.zeros(n_blocks, uchirp.PEAK_DTYPE) for _ in range(world)]
+    xh = [np.ascontiguousarray(x[s0:s0 + ns]) if ns else np.zeros(4, x.dtype) for s0, ns, q0, nq in spans]
+    g.process_stream(xh, x.size, ph, dtype=uchirp.DTYPE_I32 if dtype_i32 else uchirp.DTYPE_F32)
+    for r in range(world):
+        assert np.array_equal(ph[r].view(np.uint8), want_pk.view(np.uint8)), (world, n_dec, r, "host")
+        checks += 1
     g.close()
 
 
