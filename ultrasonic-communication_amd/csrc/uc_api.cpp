@@ -73,6 +73,17 @@ bool is_device_ptr(const void* p) {
   return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
 }
 
+// what one uc_receive_streams[_next] call parks on the device between its kernels: staged host inputs, the accepted-block
+// lists and the packed copy of a busy-masked call, the new (up, down) records, staged host outputs.  A live state owns a set
+// of its own (calls on different states never share scratch); calls without a state use the context's, one stream at a time
+// (rx_guard below).
+struct RxScratch {
+  DevBuf in, busy, acc, na, pad, rec, text, ntext, trace, ntrace;
+  void release() {
+    for (DevBuf* b : {&in, &busy, &acc, &na, &pad, &rec, &text, &ntext, &trace, &ntrace}) b->release();
+  }
+};
+
 }  // namespace
 
 namespace uc {
@@ -106,13 +117,18 @@ struct uc_ctx {
   DevBuf s_cic_in, s_cic_out;
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
-  int band_blocks_per_cu[3][3][2] = {};  // [default / wide / default + spectrum stores][mode][dtype]: the instantiations differ in registers
+  int band_blocks_per_cu[5][3][2] = {};  // [default / wide / default + spectrum stores / rows / rows + wide][mode][dtype]: the instantiations differ in registers
   int full_blocks_per_cu[2] = {0, 0};    // [dtype]: the int32 / f32 instantiations differ in registers
   int iq_blocks_per_cu[2] = {0, 0};
   int stream_blocks_per_cu[2] = {0, 0};
   DevBuf s_comp, s_peaks, s_spec;
-  DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream[s]: zero-prefixed stream(s), (up, down) mag_max per frame
-  DevBuf s_rx_in, s_rx_busy, s_rx_acc, s_rx_na, s_rx_text, s_rx_ntext, s_rx_trace, s_rx_ntrace;  // uc_receive_streams staging
+  DevBuf s_rx_pad, s_rx_mag;        // uc_receive_stream: the zero-prefixed stream, (up, down) mag_max per frame
+  RxScratch rx;                     // uc_receive_streams (no live state): scratch of the call in flight
+  void* d_zero_block = nullptr;     // n zero words: the block "in front of" a stream that starts (fifo_queue at power-on,
+                                    // main.c:94) and the zero records such a stream carries in
+  hipEvent_t rx_ev = nullptr;       // recorded behind the last uc_receive_streams call that used `rx`: a call on ANOTHER
+  hipStream_t rx_stream = nullptr;  // stream waits for it (on the device) before it overwrites the scratch
+  bool rx_used = false;
   std::vector<float2> h_rx_mag;
   int band_waves = 3;     // tuning knobs (env UC_BAND_WAVES / UC_GRID / UC_BAND_GROUP / UC_STATIC_DEAL): not part of the ABI
   bool band_waves_set = false;  // UC_BAND_WAVES given: use it for every mode (default: 3, SYNC_CPLX 2 -- see process_batch_impl)
@@ -400,6 +416,12 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     }
   }
   if (!rc) rc = upload_device_tables(c);
+  if (!rc && (cfg->variant == UC_RX_REAL || cfg->variant == UC_SYNC_CPLX)) {
+    e = hipMalloc(&c->d_zero_block, (size_t)n * 4);
+    if (e == hipSuccess) e = hipMemset(c->d_zero_block, 0, (size_t)n * 4);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->rx_ev, hipEventDisableTiming);
+    if (e != hipSuccess) rc = hip_fail(e, "uc_create: receiver scratch");
+  }
   if (!rc && cfg->variant == UC_IQ) {
     // the taps as the A operand of v_mfma_f32_16x16x4_f32: lane l = (k = l >> 4, i = l & 15) of k-step s holds
     // T[i][4 s + k] = fir[i + 26 - (4 s + k)] (0 outside the taps): output i of a 16-output block sees the
@@ -454,9 +476,9 @@ void uc_destroy(uc_ctx* c) {
   c->s_spec.release();
   c->s_rx_pad.release();
   c->s_rx_mag.release();
-  for (DevBuf* b : {&c->s_rx_in, &c->s_rx_busy, &c->s_rx_acc, &c->s_rx_na, &c->s_rx_text, &c->s_rx_ntext, &c->s_rx_trace,
-                    &c->s_rx_ntrace})
-    b->release();
+  c->rx.release();
+  if (c->d_zero_block) (void)hipFree(c->d_zero_block);
+  if (c->rx_ev) (void)hipEventDestroy(c->rx_ev);
   c->s_clock.release();
   delete c;
 }
@@ -640,6 +662,70 @@ static int clock_buffer(uc_ctx* c, size_t grid, int waves_per_wg, hipStream_t st
   return 0;
 }
 
+// The launch of the band kernel (RX_REAL, SYNC_CPLX, DECHIRP_DOWN): the caller has filled in where the frames are and
+// which outputs it wants (p.frames / n_frames / stride -- or the ROWS fields -- mag_mean, symbols, stats, magmax, spectrum,
+// device pointers all); tables, window geometry, grid, group size and the hand-out counter are decided here.
+static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stream) {
+  const int variant = c->cfg.variant;
+  const size_t n_frames = p.n_frames;
+  p.tab0 = c->d_tab0;
+  p.tab1 = c->d_tab1;
+  p.tw = c->d_tw;
+  p.wide = c->tab.bandwidth2 > (uint32_t)uc::kBandNarrowMax ? 1u : 0u;
+  p.mag_mean_scalar = c->cfg.mag_mean;
+  p.snr_threshold = c->cfg.snr_threshold;
+  p.bw2 = c->tab.bandwidth2;
+  p.ifs = (uint32_t)(int32_t)c->cfg.fs;
+  p.true_dc = (c->cfg.flags & UC_FLAG_TRUE_DC) ? 1u : 0u;
+  p.debug = nullptr;
+#if defined(UC_STAMPS)
+  // diagnostic build only (libuchirp_stamps.so): where the per-phase stamps go
+  if (const char* d = getenv("UC_DEBUG_PTR")) p.debug = (unsigned long long*)strtoull(d, nullptr, 0);
+#endif
+  const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
+                   : (variant == UC_DECHIRP_DOWN) ? uc::kModePair : uc::kModeRxReal;
+  const bool rows = p.row_blocks != 0;
+  // SYNC_CPLX runs two transforms per frame off two complex tables: at 2 waves/SIMD both tables stay in registers (at 3
+  // the second one is loaded inside the loop, behind the frame prefetch in the in-order vector-memory queue):
+  // 2.59e8 against 2.45e8 frames/s (profiles/r03_sync_cplx_waves.txt)
+  const int waves = rows ? (mode == uc::kModeCplx ? 2 : 3)  // (the ROWS build exists at each mode's default occupancy)
+                         : (mode == uc::kModeCplx && !c->band_waves_set) ? 2 : c->band_waves;
+  // uc_window_spectrum runs the SAME two-round build as the statistics path when the windows fit it (bandwidth2 <= 191): the
+  // instantiation that also stores the window bins (uc_band_kernel.hip: SPEC), so that what the device captures are
+  // compared with is the arithmetic of the throughput kernel
+  const bool spec = p.spectrum != nullptr && !p.wide;
+  int& bpc = c->band_blocks_per_cu[rows ? (p.wide ? 4 : 3) : (p.wide ? 1 : (spec ? 2 : 0))][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
+  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0, spec, rows);
+  size_t grid = (size_t)c->num_cu * (size_t)bpc;
+  // DECHIRP_DOWN (frame pairs, the HBM-bound one) runs at the loads-only floor of this kernel structure, and that floor is
+  // lower with fewer concurrent streams: 5 workgroups per CU instead of the 6 that fit: 7.69 against 7.54e8 frames/s,
+  // 4 per CU 7.57, 3 per CU 6.86 (profiles/r03_band_knock.txt)
+  if (mode == uc::kModePair && !p.wide && bpc > 5) grid = (size_t)c->num_cu * 5;
+  if (c->grid_override > 0) grid = (size_t)c->grid_override;
+  // units of work: frames, or frame pairs (DECHIRP_DOWN).  Groups of `band_group` units; smaller ones when the batch
+  // would not give every workgroup a few (a small batch then still spreads over the whole chip)
+  p.unpaired = (mode == uc::kModePair && (c->cfg.flags & UC_FLAG_NO_FRAME_PAIRS)) ? 1u : 0u;
+  const size_t units = (mode == uc::kModePair && !p.unpaired) ? (n_frames + 1) / 2 : n_frames;
+  uint32_t group = (uint32_t)c->band_group;
+  if (waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
+  while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;
+  const size_t ngroups = (units + group - 1) / group;
+  if (grid > ngroups) grid = ngroups;
+  p.group_log2 = 0;
+  while ((1u << p.group_log2) < group) p.group_log2++;
+  p.work_ctr = nullptr;
+  int wslot = -1;
+  if (!c->static_deal && group >= 2 && ngroups > grid) {
+    const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
+    if (wrc) return wrc;
+  }
+  if (c->clock_probe)
+    if (int crc = clock_buffer(c, grid, 2, stream, &p.debug)) return crc;
+  int lrc = (c->clock_probe ? uc::clk::launch_band : uc::launch_band)(mode, dtype, waves, p, (int)grid, stream);
+  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
+  return work_counter_launched(c, stream, wslot);
+}
+
 static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n_frames, size_t stride_elems,
                               const float* mag_mean, uint8_t* symbols, uc_stats* stats, float2* d_magmax, void* hip_stream,
                               bool mapped = false, float* d_spectrum = nullptr);
@@ -807,70 +893,17 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     goto copy_back;
   }
   {
-  uc::BandParams p;
-  memset(&p, 0, sizeof(p));
-  p.frames = d_frames;
-  p.n_frames = n_frames;
-  p.stride = stride_elems;
-  p.tab0 = c->d_tab0;
-  p.tab1 = c->d_tab1;
-  p.tw = c->d_tw;
-  p.mag_mean = d_mm;
-  p.symbols = d_sym;
-  p.stats = d_stats;
-  p.magmax = d_magmax;
-  p.spectrum = d_spectrum;
-  p.wide = c->tab.bandwidth2 > (uint32_t)uc::kBandNarrowMax ? 1u : 0u;
-  p.mag_mean_scalar = c->cfg.mag_mean;
-  p.snr_threshold = c->cfg.snr_threshold;
-  p.bw2 = c->tab.bandwidth2;
-  p.ifs = (uint32_t)(int32_t)c->cfg.fs;
-  p.true_dc = (c->cfg.flags & UC_FLAG_TRUE_DC) ? 1u : 0u;
-  p.debug = nullptr;
-#if defined(UC_STAMPS)
-  // diagnostic build only (libuchirp_stamps.so): where the per-phase stamps go
-  if (const char* d = getenv("UC_DEBUG_PTR")) p.debug = (unsigned long long*)strtoull(d, nullptr, 0);
-#endif
-  const int mode = (variant == UC_SYNC_CPLX) ? uc::kModeCplx
-                   : (variant == UC_DECHIRP_DOWN) ? uc::kModePair : uc::kModeRxReal;
-  // SYNC_CPLX runs two transforms per frame off two complex tables: at 2 waves/SIMD both tables stay in registers (at 3
-  // the second one is loaded inside the loop, behind the frame prefetch in the in-order vector-memory queue):
-  // 2.59e8 against 2.45e8 frames/s (profiles/r03_sync_cplx_waves.txt)
-  const int waves = (mode == uc::kModeCplx && !c->band_waves_set) ? 2 : c->band_waves;
-  // uc_window_spectrum runs the SAME two-round build as the statistics path when the windows fit it (bandwidth2 <= 191): the
-  // instantiation that also stores the window bins (uc_band_kernel.hip: SPEC), so that what the device captures are
-  // compared with is the arithmetic of the throughput kernel
-  const bool spec = d_spectrum != nullptr && !p.wide;
-  int& bpc = c->band_blocks_per_cu[p.wide ? 1 : (spec ? 2 : 0)][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
-  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0, spec);
-  size_t grid = (size_t)c->num_cu * (size_t)bpc;
-  // DECHIRP_DOWN (frame pairs, the HBM-bound one) runs at the loads-only floor of this kernel structure, and that floor is
-  // lower with fewer concurrent streams: 5 workgroups per CU instead of the 6 that fit: 7.69 against 7.54e8 frames/s,
-  // 4 per CU 7.57, 3 per CU 6.86 (profiles/r03_band_knock.txt)
-  if (mode == uc::kModePair && !p.wide && bpc > 5) grid = (size_t)c->num_cu * 5;
-  if (c->grid_override > 0) grid = (size_t)c->grid_override;
-  // units of work: frames, or frame pairs (DECHIRP_DOWN).  Groups of `band_group` units; smaller ones when the batch
-  // would not give every workgroup a few (a small batch then still spreads over the whole chip)
-  p.unpaired = (mode == uc::kModePair && (c->cfg.flags & UC_FLAG_NO_FRAME_PAIRS)) ? 1u : 0u;
-  const size_t units = (mode == uc::kModePair && !p.unpaired) ? (n_frames + 1) / 2 : n_frames;
-  uint32_t group = (uint32_t)c->band_group;
-  if (waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
-  while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;
-  const size_t ngroups = (units + group - 1) / group;
-  if (grid > ngroups) grid = ngroups;
-  p.group_log2 = 0;
-  while ((1u << p.group_log2) < group) p.group_log2++;
-  p.work_ctr = nullptr;
-  int wslot = -1;
-  if (!c->static_deal && group >= 2 && ngroups > grid) {
-    const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
-    if (wrc) return wrc;
-  }
-  if (c->clock_probe)
-    if (int crc = clock_buffer(c, grid, 2, stream, &p.debug)) return crc;
-  int lrc = (c->clock_probe ? uc::clk::launch_band : uc::launch_band)(mode, dtype, waves, p, (int)grid, stream);
-  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "band kernel launch");
-  if (int erc = work_counter_launched(c, stream, wslot)) return erc;
+    uc::BandParams p;
+    memset(&p, 0, sizeof(p));
+    p.frames = d_frames;
+    p.n_frames = n_frames;
+    p.stride = stride_elems;
+    p.mag_mean = d_mm;
+    p.symbols = d_sym;
+    p.stats = d_stats;
+    p.magmax = d_magmax;
+    p.spectrum = d_spectrum;
+    if (int brc = band_launch(c, p, dtype, stream)) return brc;
   }
 copy_back:
 
@@ -1370,19 +1403,24 @@ extern "C" int uc_receive_stream(uc_ctx* c, const void* samples, int dtype, size
 }
 
 // ---------------------------------------------------------------------------
-// uc_receive_streams: the same receiver for MANY recorded streams at once -- pack (zero prefix, drop-on-busy), ONE batched
-// launch over every 256-sample offset of every stream, main()'s switch replayed on the device, one lane per stream
-// (csrc/uc_rx_kernel.hip: include/uchirp_mainloop.hpp compiled for the device).
+// uc_receive_streams[_next]: the same receiver for MANY streams at once, recorded or live.  Per call: (busy mask only:
+// accept + pack) -> ONE launch of the band kernel's ROWS build over the 8 FIFO offsets every accepted block adds (it reads
+// the caller's buffer as it lies) -> main()'s switch replayed on the device, one wave or one lane per stream
+// (csrc/uc_rx_kernel.hip: include/uchirp_mainloop.hpp compiled for the device) -> (live: the stream's newest block is kept).
 // ---------------------------------------------------------------------------
-// live streams: what n_streams receivers carry from one call to the next, on the device
+// live streams: what n_streams receivers carry from one call to the next, all of it on the device
 struct uc_rx_state {
   uc_ctx* c = nullptr;
+  int device = 0;
   size_t n_streams = 0;
-  uint32_t* d_tail = nullptr;  // [n_streams][2 n] words: the last two ACCEPTED blocks of every stream (the FIFO minus the
-                               // block the next call appends); zeros at power-on (fifo_queue, main.c:94)
-  uint32_t* d_loop = nullptr;  // [n_streams][rx_loop_words()]: main()'s locals (main.c:314-339)
-  uint64_t blocks_seen = 0;    // blocks of every stream offered so far
-  int dtype = -1;              // of the words in d_tail (the first call decides)
+  uint32_t* d_last = nullptr;   // [n_streams][n] words: the newest ACCEPTED block of every stream -- the part of the FIFO the
+                                // next block's new offsets still read; zeros at power-on (fifo_queue, main.c:94)
+  float2* d_carry = nullptr;    // [n_streams][9]: (up, down) mag_max of the 9 FIFO offsets that survive the ISR's shift
+                                // (main.c:662): offsets n .. 2 n of the FIFO become 0 .. n of the next one; zeros at power-on
+  uint32_t* d_loop = nullptr;   // [n_streams][rx_loop_words()]: main()'s locals (main.c:314-339) + blocks offered so far
+  RxScratch rx;                 // scratch of the call in flight
+  uint64_t blocks_seen = 0;     // host mirror of the block count (the overflow check only; a replayed graph does not bump it)
+  int dtype = -1;               // of the words in d_last (the first call decides)
 };
 
 static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples, int dtype, size_t n_streams, size_t n_samples,
@@ -1395,6 +1433,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return fail(-EINVAL, "uc_receive_streams: bad dtype %d", dtype);
   if (n_streams == 0) return 0;
   const uint32_t n = c->cfg.n;
+  const uint32_t per_block = n / 256;  // new FIFO offsets per accepted block
   if (stream_stride_elems == 0) stream_stride_elems = n_samples;
   if (stream_stride_elems < n_samples) return fail(-EINVAL, "uc_receive_streams: streams overlap (stride %zu < %zu samples)",
                                                    stream_stride_elems, n_samples);
@@ -1407,36 +1446,47 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       return fail(-EINVAL, "uc_receive_streams_next: the streams began as dtype %d", st->dtype);
     if (st->blocks_seen + nb >= ((uint64_t)1 << 32)) return fail(-EOVERFLOW, "uc_receive_streams_next: 2^32 blocks per stream");
   }
-  const void* d_prefix = st ? st->d_tail : nullptr;
   if (trace && trace_cap == 0) trace = nullptr;
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   hipStream_t stream = (hipStream_t)hip_stream;
   bool host_out = false;
+  RxScratch& sc = st ? st->rx : c->rx;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  if (!st && !capturing) {
+    // the context's scratch serves one call at a time: a call on another stream than the last one waits, ON THE DEVICE, for
+    // that one's kernels (a live state has scratch of its own and needs none of this)
+    if (c->rx_used && c->rx_stream != stream) {
+      const RelaxedCapture relaxed;
+      e = hipStreamWaitEvent(stream, c->rx_ev, 0);
+      if (e != hipSuccess) return hip_fail(e, "hipStreamWaitEvent(receiver scratch)");
+    }
+  }
 
   // outputs: straight into device buffers of the caller, else through staging
   char* d_text = text;
   if (!is_device_ptr(text)) {
-    if (int rc = c->s_rx_text.ensure(n_streams * text_cap)) return rc;
-    d_text = (char*)c->s_rx_text.p;
+    if (int rc = sc.text.ensure(n_streams * text_cap)) return rc;
+    d_text = (char*)sc.text.p;
     host_out = true;
   }
   uint32_t* d_ntext = n_text;
   if (n_text && !is_device_ptr(n_text)) {
-    if (int rc = c->s_rx_ntext.ensure(n_streams * sizeof(uint32_t))) return rc;
-    d_ntext = (uint32_t*)c->s_rx_ntext.p;
+    if (int rc = sc.ntext.ensure(n_streams * sizeof(uint32_t))) return rc;
+    d_ntext = (uint32_t*)sc.ntext.p;
     host_out = true;
   }
   uc_rx_event* d_trace = trace;
   if (trace && !is_device_ptr(trace)) {
-    if (int rc = c->s_rx_trace.ensure(n_streams * trace_cap * sizeof(uc_rx_event))) return rc;
-    d_trace = (uc_rx_event*)c->s_rx_trace.p;
+    if (int rc = sc.trace.ensure(n_streams * trace_cap * sizeof(uc_rx_event))) return rc;
+    d_trace = (uc_rx_event*)sc.trace.p;
     host_out = true;
   }
   uint32_t* d_ntrace = n_trace;
   if (n_trace && !is_device_ptr(n_trace)) {
-    if (int rc = c->s_rx_ntrace.ensure(n_streams * sizeof(uint32_t))) return rc;
-    d_ntrace = (uint32_t*)c->s_rx_ntrace.p;
+    if (int rc = sc.ntrace.ensure(n_streams * sizeof(uint32_t))) return rc;
+    d_ntrace = (uint32_t*)sc.ntrace.p;
     host_out = true;
   }
   if (nb == 0) {  // nothing to process: empty texts, zero counts
@@ -1446,81 +1496,77 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(empty streams)");
   }
 
-  // inputs
-  const void* d_in = samples;
-  size_t in_stride = stream_stride_elems;
   if (nb) {
     if (!samples) return fail(-EINVAL, "uc_receive_streams: samples is NULL");
+    const size_t n_frames = n_streams * nb * per_block;
+    if (n_frames >= ((size_t)1 << 31))
+      return fail(-EINVAL, "uc_receive_streams: %zu new FIFO offsets in one call (at most 2^31 - 1)", n_frames);
+    // inputs
+    const void* d_in = samples;
     if (!is_device_ptr(samples)) {
       const size_t span = (n_streams - 1) * stream_stride_elems + nb * (size_t)n;
-      if (int rc = c->s_rx_in.ensure(span * 4)) return rc;
-      e = hipMemcpyAsync(c->s_rx_in.p, samples, span * 4, hipMemcpyHostToDevice, stream);
+      if (int rc = sc.in.ensure(span * 4)) return rc;
+      e = hipMemcpyAsync(sc.in.p, samples, span * 4, hipMemcpyHostToDevice, stream);
       if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(streams)");
-      d_in = c->s_rx_in.p;
+      d_in = sc.in.p;
     }
+    // The ISR (main.c:659-668) appends a block only when the main loop has consumed the previous one; a block that arrives
+    // while it is busy is DROPPED, the FIFO is not shifted.  The FIFO therefore only ever holds ACCEPTED blocks: with a busy
+    // mask they are first laid out one behind the other; without one the caller's buffer is read as it lies.
+    const void* rows = d_in;
+    size_t row_pitch = stream_stride_elems;
     const uint32_t* d_acc = nullptr;
     const uint32_t* d_na = nullptr;
     if (busy) {
       const uint8_t* d_busy = busy;
       if (!is_device_ptr(busy)) {
-        if (int rc = c->s_rx_busy.ensure(n_streams * nb)) return rc;
-        e = hipMemcpyAsync(c->s_rx_busy.p, busy, n_streams * nb, hipMemcpyHostToDevice, stream);
+        if (int rc = sc.busy.ensure(n_streams * nb)) return rc;
+        e = hipMemcpyAsync(sc.busy.p, busy, n_streams * nb, hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(busy)");
-        d_busy = (const uint8_t*)c->s_rx_busy.p;
+        d_busy = (const uint8_t*)sc.busy.p;
       }
-      int rc = c->s_rx_acc.ensure(n_streams * nb * sizeof(uint32_t));
-      if (!rc) rc = c->s_rx_na.ensure(n_streams * sizeof(uint32_t));
+      int rc = sc.acc.ensure(n_streams * nb * sizeof(uint32_t));
+      if (!rc) rc = sc.na.ensure(n_streams * sizeof(uint32_t));
+      if (!rc) rc = sc.pad.ensure(n_streams * nb * (size_t)n * 4);
       if (rc) return rc;
-      const int lrc = uc::launch_rx_accept(d_busy, n_streams, (uint32_t)nb, (uint32_t*)c->s_rx_acc.p, (uint32_t*)c->s_rx_na.p, stream);
+      int lrc = uc::launch_rx_accept(d_busy, n_streams, (uint32_t)nb, (uint32_t*)sc.acc.p, (uint32_t*)sc.na.p, stream);
       if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx accept kernel launch");
-      d_acc = (const uint32_t*)c->s_rx_acc.p;
-      d_na = (const uint32_t*)c->s_rx_na.p;
-    }
-    // No busy mask and streams a multiple of 256 samples apart: NO packed copy.  The band kernel runs over the caller's
-    // buffer as it lies (every 256-sample offset; the frames that straddle two streams are never looked at), and the 16
-    // offsets per stream that reach into the FIFO's 2 n initial zeros come from a second, small launch over
-    // [2 n zeros | first block] of every stream (the pack kernel with ONE block: 3 n words per stream).
-    const bool direct = !busy && (in_stride % 256u) == 0;
-    size_t pitch, n_frames;
-    const float2* d_head = nullptr;
-    if (direct) {
-      const size_t hp = 3 * (size_t)n, nh = (n_streams * hp - n) / 256 + 1;
-      const size_t span = (n_streams - 1) * in_stride + nb * (size_t)n;
-      pitch = in_stride;
-      n_frames = (span - n) / 256 + 1;
-      if (n_frames >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_receive_streams: %zu frames in one launch (at most 2^31 - 1)", n_frames);
-      int rc = c->s_rx_pad.ensure(n_streams * hp * 4);
-      if (!rc) rc = c->s_rx_mag.ensure((n_frames + nh) * sizeof(float2));
-      if (rc) return rc;
-      const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
-      int lrc = uc::launch_rx_pack(d_in, in_stride, n, 1u, n_streams, nullptr, nullptr, d_prefix, c->s_rx_pad.p, hp, al16, stream);
+      d_acc = (const uint32_t*)sc.acc.p;
+      d_na = (const uint32_t*)sc.na.p;
+      const bool al16 = (((uintptr_t)d_in | (uintptr_t)sc.pad.p) & 15u) == 0 && (stream_stride_elems & 3u) == 0 && (n & 3u) == 0;
+      lrc = uc::launch_rx_pack(d_in, stream_stride_elems, n, (uint32_t)nb, n_streams, d_acc, d_na, sc.pad.p, nb * (size_t)n, al16,
+                               stream);
       if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
-      float2* d_mag = (float2*)c->s_rx_mag.p;
-      rc = process_batch_impl(c, c->s_rx_pad.p, dtype, nh, 256, nullptr, nullptr, nullptr, d_mag + n_frames, hip_stream);
-      if (!rc) rc = process_batch_impl(c, d_in, dtype, n_frames, 256, nullptr, nullptr, nullptr, d_mag, hip_stream);
-      if (rc) return rc;
-      d_head = d_mag + n_frames;
-    } else {
-      pitch = (2 + nb) * (size_t)n;
-      n_frames = (n_streams * pitch - n) / 256 + 1;
-      if (n_frames >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_receive_streams: %zu frames in one launch (at most 2^31 - 1)", n_frames);
-      int rc = c->s_rx_pad.ensure(n_streams * pitch * 4);
-      if (!rc) rc = c->s_rx_mag.ensure(n_frames * sizeof(float2));
-      if (rc) return rc;
-      const bool al16 = (((uintptr_t)d_in | (uintptr_t)c->s_rx_pad.p) & 15u) == 0 && (in_stride & 3u) == 0 && (n & 3u) == 0;
-      int lrc = uc::launch_rx_pack(d_in, in_stride, n, (uint32_t)nb, n_streams, d_acc, d_na, d_prefix, c->s_rx_pad.p, pitch, al16,
-                                   stream);
-      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx pack kernel launch");
-      rc = process_batch_impl(c, c->s_rx_pad.p, dtype, n_frames, 256, nullptr, nullptr, nullptr, (float2*)c->s_rx_mag.p, hip_stream);
-      if (rc) return rc;
+      rows = sc.pad.p;
+      row_pitch = nb * (size_t)n;
     }
-    int lrc;
+    if (int rc = sc.rec.ensure(n_frames * sizeof(float2))) return rc;
+    // dsp() at the 8 FIFO offsets every accepted block ADDS (the other 9 of its FIFO were evaluated when the block before
+    // it arrived, main.c:662): frame (s, k, m) = the last n - 256 m samples of the block in front of the stream's k-th
+    // block followed by the first 256 m of that block -- in front of block 0: the newest block of the previous call (a
+    // live state) or zeros (power-on).  (Rows of a busy-masked call beyond na[s] hold stale words: evaluated, never read.)
+    {
+      uc::BandParams bp;
+      memset(&bp, 0, sizeof(bp));
+      bp.frames = rows;
+      bp.n_frames = n_frames;
+      bp.stride = 256;
+      bp.magmax = (float2*)sc.rec.p;
+      bp.prev = st ? (const void*)st->d_last : (const void*)c->d_zero_block;
+      bp.prev_pitch = st ? (size_t)n : 0;
+      bp.row_pitch = row_pitch;
+      bp.row_blocks = (uint32_t)nb;
+      uc::rows_divisor((uint32_t)nb, &bp.div_magic, &bp.div_shift);
+      if (int rc = band_launch(c, bp, dtype, stream)) return rc;
+    }
     uc::RxParams rp;
     memset(&rp, 0, sizeof(rp));
-    rp.magmax = (const float2*)c->s_rx_mag.p;
-    rp.head = d_head;
+    rp.rec = (const float2*)sc.rec.p;
+    rp.rec_pitch = nb * per_block;
+    rp.carry = st ? st->d_carry : (const float2*)c->d_zero_block;
+    rp.carry_pitch = st ? per_block + 1 : 0;
+    rp.carry_out = st ? st->d_carry : nullptr;
     rp.n_streams = n_streams;
-    rp.pitch = pitch;
     rp.n = n;
     rp.nb = (uint32_t)nb;
     rp.snr_threshold = c->cfg.snr_threshold;
@@ -1533,15 +1579,13 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     rp.trace_cap = (uint32_t)trace_cap;
     rp.n_trace = d_ntrace;
     rp.loop_state = st ? st->d_loop : nullptr;
-    rp.block_base = st ? (uint32_t)st->blocks_seen : 0u;
-    lrc = uc::launch_rx_replay(rp, stream);
+    int lrc = uc::launch_rx_replay(rp, stream);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
     if (st) {
-      // what the FIFO keeps for the next call: the last two ACCEPTED blocks of every stream
-      if (!direct) lrc = uc::launch_rx_tail(c->s_rx_pad.p, pitch, d_na, (uint32_t)nb, n, n_streams, st->d_tail, stream);
-      else if (nb >= 2) lrc = uc::launch_rx_tail(d_in, in_stride, nullptr, (uint32_t)(nb - 2), n, n_streams, st->d_tail, stream);
-      else lrc = uc::launch_rx_tail(c->s_rx_pad.p, 3 * (size_t)n, nullptr, 1u, n, n_streams, st->d_tail, stream);
-      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx tail kernel launch");
+      // what the next call's new offsets still read of this one: every stream's newest ACCEPTED block
+      const bool al16 = (((uintptr_t)rows | (uintptr_t)st->d_last) & 15u) == 0 && (row_pitch & 3u) == 0 && (n & 3u) == 0;
+      lrc = uc::launch_rx_last(rows, row_pitch, d_na, (uint32_t)nb, n, n_streams, st->d_last, al16, stream);
+      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx last-block kernel launch");
       st->blocks_seen += nb;
       st->dtype = dtype;
     }
@@ -1557,6 +1601,18 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
     if (e != hipSuccess) return hip_fail(e, "uc_receive_streams: copy back");
   }
+  if (!st && !capturing) {
+    const RelaxedCapture relaxed;
+    if (hipEventRecord(c->rx_ev, stream) == hipSuccess) {
+      c->rx_used = true;
+      c->rx_stream = stream;
+    } else {
+      // (a capture elsewhere on this thread forbids the call): nothing can be waited for later -- drain now
+      (void)hipGetLastError();
+      (void)hipStreamSynchronize(stream);
+      c->rx_used = false;
+    }
+  }
   return 0;
 }
 
@@ -1571,9 +1627,11 @@ extern "C" int uc_receive_streams(uc_ctx* c, const void* samples, int dtype, siz
 // ---- live streams: the same call, chunk after chunk ----------------------------------------------------------------
 extern "C" void uc_rx_state_destroy(uc_rx_state* st) {
   if (!st) return;
-  if (st->c) (void)hipSetDevice(st->c->device);
-  if (st->d_tail) (void)hipFree(st->d_tail);
+  (void)hipSetDevice(st->device);  // (not through st->c: a state may outlive its context by mistake; its memory is its own)
+  if (st->d_last) (void)hipFree(st->d_last);
+  if (st->d_carry) (void)hipFree(st->d_carry);
   if (st->d_loop) (void)hipFree(st->d_loop);
+  st->rx.release();
   delete st;
 }
 
@@ -1582,12 +1640,14 @@ extern "C" size_t uc_rx_state_streams(const uc_rx_state* st) { return st ? st->n
 extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   if (!st) return fail(-EINVAL, "uc_rx_state_reset: NULL state");
   uc_ctx* c = st->c;
-  hipError_t e = hipSetDevice(c->device);
+  hipError_t e = hipSetDevice(st->device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   hipStream_t stream = (hipStream_t)hip_stream;
-  e = hipMemsetAsync(st->d_tail, 0, st->n_streams * 2 * (size_t)c->cfg.n * 4, stream);
-  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(FIFO tails)");
-  const int lrc = uc::launch_rx_state_init(st->d_loop, st->n_streams, c->cfg.n, c->cfg.snr_threshold, stream);
+  const uint32_t n = c->cfg.n;
+  e = hipMemsetAsync(st->d_last, 0, st->n_streams * (size_t)n * 4, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(st->d_carry, 0, st->n_streams * (size_t)(n / 256 + 1) * sizeof(float2), stream);
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(FIFO state)");
+  const int lrc = uc::launch_rx_state_init(st->d_loop, st->n_streams, n, c->cfg.snr_threshold, stream);
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx state init kernel launch");
   st->blocks_seen = 0;
   st->dtype = -1;
@@ -1605,8 +1665,11 @@ extern "C" int uc_rx_state_create(uc_ctx* c, size_t n_streams, uc_rx_state** out
   uc_rx_state* st = new (std::nothrow) uc_rx_state();
   if (!st) return fail(-ENOMEM, "uc_rx_state_create: out of memory");
   st->c = c;
+  st->device = c->device;
   st->n_streams = n_streams;
-  e = hipMalloc((void**)&st->d_tail, n_streams * 2 * (size_t)c->cfg.n * 4);
+  const uint32_t n = c->cfg.n;
+  e = hipMalloc((void**)&st->d_last, n_streams * (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&st->d_carry, n_streams * (size_t)(n / 256 + 1) * sizeof(float2));
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_loop, n_streams * (size_t)uc::rx_loop_words() * 4);
   if (e != hipSuccess) {
     uc_rx_state_destroy(st);

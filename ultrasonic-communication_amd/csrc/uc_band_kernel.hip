@@ -330,7 +330,12 @@ __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
 // SPEC: the same build with the window bins' magnitudes stored as well (uc_window_spectrum; p.spectrum).  A separate
 // instantiation, so that the throughput builds carry neither the branch nor the stores: band_kernel<.., false, false> is
 // instruction for instruction what it was (tools/isa_hist.sh).  The WIDE build tests p.spectrum at run time.
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false>
+// ROWS: the frames are the FIFO offsets a new block adds to a live receiver (uc_receive_streams[_next]; BandParams: `prev`,
+// row_pitch ...): every frame is the tail of one block followed by the head of the next, two base addresses, the split a
+// multiple of 256 samples -- which is a whole number of this kernel's 128-sample load instructions, so each load takes one
+// of two buffer resources by a SCALAR select and nothing is ever copied together.  A separate instantiation again: the
+// batch builds carry none of it.
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, bool ROWS = false>
 __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #ifdef UC_STAMPS
   unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -462,6 +467,22 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           reinterpret_cast<const char*>(p.frames) + (fa + (has_b ? 1 : 0)) * p.stride * 4, has_b ? kN * 4 : 0);
 #pragma unroll
       for (int t = 0; t < NX; t++) xp[t] = mkv(buf_ld32_stream(ra, voff4, T * 4 * t), buf_ld32_stream(rb, voff4, T * 4 * t));
+    } else if (ROWS) {
+      // unit u = (row s, block jb, m): samples [256 m, n) of the block in front of block jb, then [0, 256 m) of block jb
+      const unsigned g8 = (unsigned)u >> 3, m8 = ((unsigned)u & 7u) + 1u;
+      const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
+      const unsigned jb = g8 - s * p.row_blocks;
+      const char* blk = reinterpret_cast<const char*>(p.frames) + ((size_t)s * p.row_pitch + (size_t)jb * kN) * 4;
+      const char* before = jb ? blk - kN * 4 : reinterpret_cast<const char*>(p.prev) + (size_t)s * p.prev_pitch * 4;
+      // sample 0 of the frame as if the whole frame lay in the one block / in the other; load t covers samples
+      // [128 t, 128 t + 128): the first 16 - 2 m loads belong to the block in front
+      const __amdgpu_buffer_rsrc_t ra = make_rsrc(before + 1024 * m8, kN * 4);
+      const __amdgpu_buffer_rsrc_t rb = make_rsrc(blk - (kN * 4 - 1024 * (int)m8), kN * 4);
+      const int tsplit = 16 - 2 * (int)m8;
+#pragma unroll
+      for (int m = 0; m < 8; m++)
+        xp[m] = mkv(buf_ld32_stream(2 * m < tsplit ? ra : rb, voff4, T * 4 * (2 * m)),
+                    buf_ld32_stream(2 * m + 1 < tsplit ? ra : rb, voff4, T * 4 * (2 * m + 1)));
     } else {
       const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + u * p.stride * 4, kN * 4);
 #pragma unroll
@@ -1006,16 +1027,16 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   UC_CLOCK_END(p.debug, 2);
 }
 
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, bool ROWS = false>
 static int launch_one(const BandParams& p, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC, ROWS>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
   return (int)hipGetLastError();
 }
 
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, bool ROWS = false>
 static int occupancy_one() {
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC>, T, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC, ROWS>, T, 0);
   if (e != hipSuccess || nb <= 0) nb = 2 * WAVES;
   return nb;
 }
@@ -1025,6 +1046,23 @@ static int occupancy_one() {
 UC_LAUNCH_BEGIN
 #define UC_DISPATCH(FN, ...)                                                              \
   do {                                                                                    \
+    if (rows) { /* the FIFO offsets of live receivers (RX_REAL, SYNC_CPLX): each mode's default occupancy, or WIDE */ \
+      if (mode == kModePair || spec) return (int)hipErrorInvalidValue;                    \
+      if (mode == kModeRxReal) {                                                          \
+        if (wide) {                                                                       \
+          if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 2, true, false, true>(__VA_ARGS__);   \
+          return FN<kModeRxReal, UC_DTYPE_F32, 2, true, false, true>(__VA_ARGS__);        \
+        }                                                                                 \
+        if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 3, false, false, true>(__VA_ARGS__);    \
+        return FN<kModeRxReal, UC_DTYPE_F32, 3, false, false, true>(__VA_ARGS__);         \
+      }                                                                                   \
+      if (wide) {                                                                         \
+        if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, true, false, true>(__VA_ARGS__);       \
+        return FN<kModeCplx, UC_DTYPE_F32, 2, true, false, true>(__VA_ARGS__);            \
+      }                                                                                   \
+      if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, false, false, true>(__VA_ARGS__);        \
+      return FN<kModeCplx, UC_DTYPE_F32, 2, false, false, true>(__VA_ARGS__);             \
+    }                                                                                     \
     if (spec && !wide) { /* uc_window_spectrum on the default two-round build, at each mode's default occupancy */ \
       if (mode == kModePair) {                                                            \
         if (dtype == UC_DTYPE_I32) return FN<kModePair, UC_DTYPE_I32, 3, false, true>(__VA_ARGS__);   \
@@ -1075,11 +1113,11 @@ UC_LAUNCH_BEGIN
 
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream) {
   if (grid <= 0) return (int)hipSuccess;
-  const bool wide = p.wide != 0, spec = p.spectrum != nullptr;
+  const bool wide = p.wide != 0, spec = p.spectrum != nullptr, rows = p.row_blocks != 0;
   UC_DISPATCH(launch_one, p, grid, stream);
 }
 
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec) {
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec, bool rows) {
   UC_DISPATCH(occupancy_one);
 }
 

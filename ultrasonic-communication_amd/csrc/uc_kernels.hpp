@@ -40,7 +40,30 @@ struct BandParams {
   unsigned int* work_ctr; // two device words, zero at launch and left at zero: groups beyond the first one of each workgroup are handed out
                           // by atomic increments (the workgroups run at different speeds); nullptr = static round robin
   unsigned long long* debug;  // diagnostic builds only (UC_STAMPS), else nullptr
+  // ---- the ROWS build only (uc_receive_streams[_next]: the FIFO offsets a NEW block adds, receiver/Src/main.c:659-668) ----
+  // `frames` holds rows of row_blocks consecutive blocks of kN samples, row_pitch elements apart: the accepted blocks of
+  // one microphone stream each.  The ISR shifts the FIFO by one block per accepted block (main.c:662), so of the 17
+  // 256-sample offsets dsp() can visit in the new FIFO only 8 are new: unit u = (row s, block jb, m = 1 .. 8) =
+  // ((s * row_blocks + jb) * 8 + m - 1) is the frame that starts 256 m samples into the block IN FRONT of block jb and ends
+  // 256 m samples into block jb.  In front of block 0 of row s lies prev + s * prev_pitch (the newest block the FIFO
+  // held before this call; prev_pitch = 0: one block of zeros for every row, the FIFO at power-on, main.c:94).
+  // n_frames = rows * row_blocks * 8; `stride` is not used.
+  const void* prev;
+  size_t row_pitch, prev_pitch;
+  uint32_t row_blocks;
+  uint32_t div_magic, div_shift;  // u / row_blocks for u < 2^31: (mulhi(u, div_magic) + u) >> div_shift (uc::rows_divisor)
 };
+
+// the (magic, shift) pair of BandParams for a divisor d >= 1: floor(u / d) == (mulhi(u, magic) + u) >> shift for every
+// u < 2^31 (round-up method: shift = ceil(log2 d), magic = ceil(2^(32 + shift) / d) - 2^32)
+inline void rows_divisor(uint32_t d, uint32_t* magic, uint32_t* shift) {
+  uint32_t l = 0;  // (d < 2^31, so 2^(32 + l) fits 64 bits)
+  while (((uint64_t)1 << l) < d) l++;
+  const uint64_t num = (uint64_t)1 << (32 + l);
+  const uint64_t m = (num + d - 1) / d - ((uint64_t)1 << 32);
+  *magic = (uint32_t)m;
+  *shift = l;
+}
 
 // kModePair (DECHIRP_DOWN): ONE real reference, so two frames share a complex transform; one
 // history per frame with raw bin indices, stats[frame], symbols = UC_SYM_NONE
@@ -50,7 +73,8 @@ enum BandMode { kModeRxReal = 0, kModeCplx = 1, kModePair = 2 };
 // `waves` = min waves per SIMD the kernel was compiled for (2, 3 or 4): a tuning knob
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
 // spec: the instantiation that also stores the window bins (p.spectrum != nullptr on the default two-round build)
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false);
+// rows: the ROWS instantiation (p.row_blocks != 0; RX_REAL / SYNC_CPLX at their default occupancy -- `waves` is not looked at)
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false, bool rows = false);
 
 // Full-spectrum pipeline: UC_COMPRESS (FFT x H x IFFT, two frames per complex transform).
 struct FullParams {
@@ -159,7 +183,8 @@ int sinc5_waves_per_block();
 #endif
 namespace clk {
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false);
+// rows: the ROWS instantiation (p.row_blocks != 0; RX_REAL / SYNC_CPLX at their default occupancy -- `waves` is not looked at)
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false, bool rows = false);
 int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream);
 int compress_max_blocks_per_cu(int dtype);
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);

@@ -15,23 +15,19 @@ struct HistLite {  // the members of struct history (receiver/Src/main.c:124-136
   float mag_max = 0.0f, mag_mean = 0.0f, snr = 0.0f;
 };
 
-// dsp() (receiver/Src/main.c:183-231) over a packed stream: the FIFO at accepted block b is packed[b n, b n + 3 n), so the
-// frame at FIFO offset pos is frame (b n + pos) / 256 of the stride-256 launch
+// dsp() (receiver/Src/main.c:183-231) over ONE packed stream (uc_receive_stream, replayed on the host): the FIFO at
+// accepted block b is packed[b n, b n + 3 n), so the frame at FIFO offset pos is frame (b n + pos) / 256 of the
+// stride-256 launch
 struct RxReplay {
   typedef HistLite history_t;
   const float2* magmax;  // (up, down) mag_max of every 256-sample offset of this stream's PACKED form (2 n zeros, then the
                          // accepted blocks): entry g = packed offset 256 g
-  size_t n_frames;       // (host replay only: bound of magmax)
+  size_t n_frames;       // bound of magmax
   uint32_t n;
   size_t block;          // current accepted block index b
-  // uc_receive_streams without a packed copy: the offsets that reach into the zero prefix (g < head_count = 2 n / 256) come
-  // from a small second launch over [2 n zeros | first block] of every stream, all others straight from the caller's
-  // buffer; `magmax` is then biased so that entry g (g >= head_count) is stream offset 256 g - 2 n.  nullptr: packed form.
-  const float2* head = nullptr;
-  uint32_t head_count = 0;
   UC_HD void dsp(uint32_t pos, HistLite* h, float mag_mean, int updown) const {
     const size_t g = (block * (size_t)n + pos) / 256;
-    const float2 mm = (head && g < head_count) ? head[g] : magmax[g];
+    const float2 mm = magmax[g];
     const float m = updown == UC_UP_CHIRP ? mm.x : mm.y;
     h->mag_max = m;
     h->mag_mean = mag_mean;
@@ -39,13 +35,21 @@ struct RxReplay {
   }
 };
 
+// Many streams, on the device.  The ISR shifts the FIFO by ONE block per accepted block (main.c:662): of the 2 n / 256 + 1
+// offsets dsp() can visit in the FIFO (pos = 0 .. 2 n in steps of 256) the first n / 256 + 1 were the LAST n / 256 + 1 of
+// the FIFO before the shift -- evaluated then, carried since -- and only n / 256 are new.  So the (up, down) mag_max records
+// of one stream form ONE sequence, record q = the frame that starts 256 q samples into [2 n zeros | accepted blocks]:
+// accepted block i of the stream (counted from power-on) looks at records 8 i .. 8 i + 16 and adds records 8 i + 9 ..
+// 8 i + 16 (n = 2048).  A call keeps the last 9 records of the sequence for the next one (`carry`: zeros at power-on, the
+// FIFO being zeros, main.c:94) and evaluates 8 per accepted block (`rec`, the ROWS build of the band kernel).
 struct RxParams {
-  const float2* magmax;  // device: (up, down) mag_max of every 256-sample offset of the packed buffer (or, with `head`, of
-                         // the caller's own buffer)
-  const float2* head;    // device or nullptr: the same for [2 n zeros | first block] of every stream, 3 n samples apart
+  const float2* rec;     // device: the new records of this call, [n_streams][rec_pitch]; entry 8 k + m - 1 = offset 256 m
+                         // behind the stream's k-th accepted block of this call (m = 1 .. 8)
+  size_t rec_pitch;      // 8 nb
+  const float2* carry;   // device: the 9 records every stream carries INTO this call, [n_streams][carry_pitch]
+  uint32_t carry_pitch;  // 9 (a live state) or 0 (one set of zero records for all: streams that start here)
+  float2* carry_out;     // device or nullptr: [n_streams][9], the records carried into the NEXT call (may alias carry)
   size_t n_streams;
-  size_t pitch;          // samples between streams in the buffer `magmax` was computed over: (2 + nb) n packed, else the
-                         // caller's stream stride (a multiple of 256)
   uint32_t n, nb;
   float snr_threshold;
   const uint32_t* acc;   // device or nullptr (no busy mask): [n_streams][nb] indices of the accepted blocks
@@ -56,23 +60,23 @@ struct RxParams {
   uc_rx_event* trace;    // device or nullptr: [n_streams][trace_cap]
   uint32_t trace_cap;
   uint32_t* n_trace;     // device or nullptr
-  // live streams (uc_rx_state): main()'s locals of every stream between calls, rx_loop_words() words each -- loaded at the
-  // start of the replay and stored back at its end; nullptr = a recorded stream (the locals start as at power-on)
+  // live streams (uc_rx_state): main()'s locals of every stream between calls and the number of blocks the stream has been
+  // offered so far (trace records carry stream-global block indices), rx_loop_words() words each -- loaded at the start of
+  // the replay and stored back at its end; nullptr = a recorded stream (the locals start as at power-on, block 0)
   uint32_t* loop_state;
-  uint32_t block_base;   // blocks of every stream the earlier calls have seen (trace records carry stream-global indices)
 };
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);
-// prefix: device or nullptr -- what the first 2 n words of every packed stream are (2 n words per stream: the FIFO's tail
-// of the previous call); nullptr = zeros (a stream that starts here)
+// the accepted blocks of every stream laid out one behind the other: dst[s * pitch + k * n ..) = k-th accepted block of
+// stream s (k < na[s]; the rest of the row is left as it is)
 int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, size_t n_streams, const uint32_t* acc,
-                   const uint32_t* na, const void* prefix, void* dst, size_t pitch, bool aligned16, hipStream_t stream);
+                   const uint32_t* na, void* dst, size_t pitch, bool aligned16, hipStream_t stream);
 int launch_rx_replay(const RxParams& p, hipStream_t stream);
-// live streams: words of main()'s locals per stream; their power-on image; the FIFO tail a call leaves behind --
-// tail[s] = 2 n words of `base` at s * pitch + (na ? na[s] : off_blocks) * n
+// live streams: words of main()'s locals (+ the block counter) per stream; their power-on image; the FIFO's newest block a
+// call leaves behind -- last[s] = n words of `base` at s * pitch + ((na ? na[s] : nb) - 1) * n (untouched when na[s] == 0)
 int rx_loop_words();
 int launch_rx_state_init(uint32_t* loop_state, size_t n_streams, uint32_t n, float snr_threshold, hipStream_t stream);
-int launch_rx_tail(const void* base, size_t pitch, const uint32_t* na, uint32_t off_blocks, uint32_t n, size_t n_streams,
-                   void* tail, hipStream_t stream);
+int launch_rx_last(const void* base, size_t pitch, const uint32_t* na, uint32_t nb, uint32_t n, size_t n_streams,
+                   void* last, bool aligned16, hipStream_t stream);
 
 }  // namespace uc
