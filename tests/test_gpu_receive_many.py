@@ -208,6 +208,63 @@ def test_live_streams_chunk_after_chunk_equal_the_whole_stream(uchirp, variant):
     e.close()
 
 
+@pytest.mark.parametrize("variant,busy_mask", [(uco.RX_REAL, False), (uco.SYNC_CPLX, False), (uco.RX_REAL, True)])
+def test_live_step_captured_into_a_graph_and_replayed_block_after_block(uchirp, variant, busy_mask):
+    """One live step -- the new block of every stream in, texts and trace records out -- captured ONCE into a hipGraph and
+    replayed for every block that arrives: everything a step carries (the newest block, the 9 FIFO records that survive the
+    ISR's shift, main()'s locals, the stream's block count) lives on the device, so the replays continue one another.
+    Texts and traces equal the eager chunked calls and the whole-stream call, bit for bit; with a busy mask too."""
+    import torch
+    dev = torch.device("cuda:0")
+    blocks, ns = 120, 24
+    x, busy, msgs = _transmissions(ns, seed=71 + variant, blocks=blocks)
+    if not busy_mask:
+        busy[:] = 0
+    e = uchirp.Engine(variant)
+    whole_t, whole_tr = e.receive_many(x, busy=busy if busy_mask else None)
+    xd = torch.from_numpy(x).to(dev)
+    bd = torch.from_numpy(busy).to(dev)
+    live = e.live(ns)
+    chunk = torch.zeros((ns, N), dtype=torch.float32, device=dev)
+    bz = torch.zeros((ns, 1), dtype=torch.uint8, device=dev) if busy_mask else None
+    text = torch.zeros((ns, 8), dtype=torch.uint8, device=dev)
+    ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
+    trace = torch.zeros((ns, 1, uchirp.RX_EVENT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    ntrace = torch.zeros(ns, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    # one eager step sizes the state's scratch (nothing may be allocated during a capture); then back to power-on
+    live.next_into(chunk, text, ntext, trace=trace, n_trace=ntrace, busy=bz)
+    live.reset()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            live.next_into(chunk, text, ntext, trace=trace, n_trace=ntrace, busy=bz, stream=s.cuda_stream)
+    texts = [b""] * ns
+    traces = [[] for _ in range(ns)]
+    for b in range(blocks):
+        chunk.copy_(xd[:, b * N:(b + 1) * N])
+        if busy_mask:
+            bz.copy_(bd[:, b:b + 1])
+        g.replay()
+        torch.cuda.synchronize()
+        nt, tt = ntext.cpu().numpy(), text.cpu().numpy()
+        ntr = ntrace.cpu().numpy()
+        tr = trace.cpu().numpy().reshape(ns, -1).view(uchirp.RX_EVENT_DTYPE)
+        for k in range(ns):
+            texts[k] += bytes(tt[k, :nt[k]])
+            if ntr[k]:
+                traces[k].append(tr[k, :1].copy())
+    for k in range(ns):
+        assert texts[k].decode("latin-1") == whole_t[k], k
+        got = np.concatenate(traces[k]) if traces[k] else np.zeros(0, whole_tr[k].dtype)
+        assert np.array_equal(got.view(np.uint8), whole_tr[k].view(np.uint8)), k
+    assert sum(m in t for m, t in zip(msgs, whole_t)) >= (4 if busy_mask else 6)
+    live.close()
+    e.close()
+
+
 def test_plain_c_host_runs_live_microphones(tmp_path):
     """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
     call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream

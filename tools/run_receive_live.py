@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Live operation of uc_receive_streams_next: every call brings ONE new 2048-sample block (26.2 ms of microphone signal) of
 every stream, as the firmware's ISR does; ms per call, and how many such microphones one GPU serves in real time.
-Usage: python tools/run_receive_live.py [streams=4096,65536] [blocks_per_call=1]   -> JSON lines"""
+Usage: python tools/run_receive_live.py [streams=4096,65536] [blocks_per_call=1] [rx_real|sync_cplx|both]   -> JSON lines"""
 import ctypes as C
 import json
 import os
@@ -19,10 +19,13 @@ from uchirp import tx
 N, FS, NB = 2048, 78125.0, 176
 counts = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "4096,65536").split(",")]
 per_call = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+only = sys.argv[3] if len(sys.argv) > 3 else "both"
 dev = torch.device("cuda:0")
 L = uchirp.lib()
 tone = torch.from_numpy(tx.render("Hello World!", fs_rx=FS, amplitude=2000.0).astype(np.float32)).to(dev)
 for variant, vname in ((uchirp.SYNC_CPLX, "sync_cplx"), (uchirp.RX_REAL, "rx_real")):
+    if only not in ("both", vname):
+        continue
     eng = uchirp.Engine(variant)
     for ns in counts:
         g = torch.Generator(device=dev)

@@ -708,6 +708,7 @@ static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stre
   const size_t units = (mode == uc::kModePair && !p.unpaired) ? (n_frames + 1) / 2 : n_frames;
   uint32_t group = (uint32_t)c->band_group;
   if (waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
+  const uint32_t group_cap = group;
   while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;
   const size_t ngroups = (units + group - 1) / group;
   if (grid > ngroups) grid = ngroups;
@@ -715,7 +716,11 @@ static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stre
   while ((1u << p.group_log2) < group) p.group_log2++;
   p.work_ctr = nullptr;
   int wslot = -1;
-  if (!c->static_deal && group >= 2 && ngroups > grid) {
+  // Dynamic hand-out only for batches big enough to keep full groups: a launch of a few dozen frames per workgroup is over
+  // before the skew between workgroups that the tickets even out has built up, and pays for them -- 32 768 frames (the new
+  // FIFO offsets of 4096 live streams): 0.101 ms dealt statically, 0.166 ms with tickets; 131 072: 0.309 / 0.322; from
+  // 524 288 on the same (profiles/r05_live_deal.txt)
+  if (!c->static_deal && group >= 2 && group == group_cap && ngroups > grid) {
     const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
     if (wrc) return wrc;
   }
@@ -1413,8 +1418,11 @@ struct uc_rx_state {
   uc_ctx* c = nullptr;
   int device = 0;
   size_t n_streams = 0;
-  uint32_t* d_last = nullptr;   // [n_streams][n] words: the newest ACCEPTED block of every stream -- the part of the FIFO the
-                                // next block's new offsets still read; zeros at power-on (fifo_queue, main.c:94)
+  uint32_t* d_last = nullptr;   // [2][n_streams][n] words: the newest ACCEPTED block of every stream -- the part of the FIFO the
+                                // next block's new offsets still read; zeros at power-on (fifo_queue, main.c:94).  Two
+                                // halves: a call reads half *d_parity and fills the other one (the band kernel stores the
+                                // block on its way through; no copy kernel, no frame reads what another writes)
+  unsigned int* d_parity = nullptr;  // which half is current; flipped by the replay kernel of every call
   float2* d_carry = nullptr;    // [n_streams][9]: (up, down) mag_max of the 9 FIFO offsets that survive the ISR's shift
                                 // (main.c:662): offsets n .. 2 n of the FIFO become 0 .. n of the next one; zeros at power-on
   uint32_t* d_loop = nullptr;   // [n_streams][rx_loop_words()]: main()'s locals (main.c:314-339) + blocks offered so far
@@ -1554,6 +1562,9 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       bp.magmax = (float2*)sc.rec.p;
       bp.prev = st ? (const void*)st->d_last : (const void*)c->d_zero_block;
       bp.prev_pitch = st ? (size_t)n : 0;
+      bp.prev_half = st ? n_streams * (size_t)n : 0;
+      bp.parity = st ? st->d_parity : nullptr;
+      bp.save = (st && !busy) ? 1u : 0u;  // (with a busy mask the last ACCEPTED block differs by stream: launch_rx_last)
       bp.row_pitch = row_pitch;
       bp.row_blocks = (uint32_t)nb;
       uc::rows_divisor((uint32_t)nb, &bp.div_magic, &bp.div_shift);
@@ -1579,13 +1590,17 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     rp.trace_cap = (uint32_t)trace_cap;
     rp.n_trace = d_ntrace;
     rp.loop_state = st ? st->d_loop : nullptr;
-    int lrc = uc::launch_rx_replay(rp, stream);
-    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
-    if (st) {
+    rp.parity = st ? st->d_parity : nullptr;
+    int lrc;
+    if (st && busy) {
       // what the next call's new offsets still read of this one: every stream's newest ACCEPTED block
       const bool al16 = (((uintptr_t)rows | (uintptr_t)st->d_last) & 15u) == 0 && (row_pitch & 3u) == 0 && (n & 3u) == 0;
-      lrc = uc::launch_rx_last(rows, row_pitch, d_na, (uint32_t)nb, n, n_streams, st->d_last, al16, stream);
+      lrc = uc::launch_rx_last(rows, row_pitch, d_na, (uint32_t)nb, n, n_streams, st->d_last, st->d_parity, al16, stream);
       if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx last-block kernel launch");
+    }
+    lrc = uc::launch_rx_replay(rp, stream);
+    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
+    if (st) {
       st->blocks_seen += nb;
       st->dtype = dtype;
     }
@@ -1631,6 +1646,7 @@ extern "C" void uc_rx_state_destroy(uc_rx_state* st) {
   if (st->d_last) (void)hipFree(st->d_last);
   if (st->d_carry) (void)hipFree(st->d_carry);
   if (st->d_loop) (void)hipFree(st->d_loop);
+  if (st->d_parity) (void)hipFree(st->d_parity);
   st->rx.release();
   delete st;
 }
@@ -1644,7 +1660,8 @@ extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   hipStream_t stream = (hipStream_t)hip_stream;
   const uint32_t n = c->cfg.n;
-  e = hipMemsetAsync(st->d_last, 0, st->n_streams * (size_t)n * 4, stream);
+  e = hipMemsetAsync(st->d_last, 0, 2 * st->n_streams * (size_t)n * 4, stream);
+  if (e == hipSuccess) e = hipMemsetAsync(st->d_parity, 0, sizeof(unsigned int), stream);
   if (e == hipSuccess) e = hipMemsetAsync(st->d_carry, 0, st->n_streams * (size_t)(n / 256 + 1) * sizeof(float2), stream);
   if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(FIFO state)");
   const int lrc = uc::launch_rx_state_init(st->d_loop, st->n_streams, n, c->cfg.snr_threshold, stream);
@@ -1668,7 +1685,8 @@ extern "C" int uc_rx_state_create(uc_ctx* c, size_t n_streams, uc_rx_state** out
   st->device = c->device;
   st->n_streams = n_streams;
   const uint32_t n = c->cfg.n;
-  e = hipMalloc((void**)&st->d_last, n_streams * (size_t)n * 4);
+  e = hipMalloc((void**)&st->d_last, 2 * n_streams * (size_t)n * 4);
+  if (e == hipSuccess) e = hipMalloc((void**)&st->d_parity, 256);
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_carry, n_streams * (size_t)(n / 256 + 1) * sizeof(float2));
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_loop, n_streams * (size_t)uc::rx_loop_words() * 4);
   if (e != hipSuccess) {

@@ -458,6 +458,14 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   // single-run modes have; the set is copied over at the end of the frame (8 packed moves).
   constexpr bool kDblX = (MODE == kModeCplx) && WAVES <= 2;
   v2f xq[kDblX ? NX : 1];
+  // ROWS: which half of the state's newest-block store this launch reads (the other one it writes)
+  const char* prev_rd = nullptr;
+  char* prev_wr = nullptr;
+  if (ROWS) {
+    const unsigned par = p.parity ? (unsigned)__builtin_amdgcn_readfirstlane((int)*p.parity) & 1u : 0u;
+    prev_rd = reinterpret_cast<const char*>(p.prev) + (size_t)par * p.prev_half * 4;
+    prev_wr = const_cast<char*>(reinterpret_cast<const char*>(p.prev)) + (size_t)(par ^ 1u) * p.prev_half * 4;
+  }
   auto load_unit = [&](size_t u, v2f (&xp)[NX]) {
     if (kPair) {
       const size_t fa = u << psh;
@@ -473,7 +481,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
       const unsigned jb = g8 - s * p.row_blocks;
       const char* blk = reinterpret_cast<const char*>(p.frames) + ((size_t)s * p.row_pitch + (size_t)jb * kN) * 4;
-      const char* before = jb ? blk - kN * 4 : reinterpret_cast<const char*>(p.prev) + (size_t)s * p.prev_pitch * 4;
+      const char* before = jb ? blk - kN * 4 : prev_rd + (size_t)s * p.prev_pitch * 4;
       // sample 0 of the frame as if the whole frame lay in the one block / in the other; load t covers samples
       // [128 t, 128 t + 128): the first 16 - 2 m loads belong to the block in front
       const __amdgpu_buffer_rsrc_t ra = make_rsrc(before + 1024 * m8, kN * 4);
@@ -648,6 +656,22 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     unsigned kpack = 0, flags = 0;
     unsigned kpw[2] = {0, 0};            // WIDE: (kr, kl) of a run as 2 x (15 bits + first-element-NaN flag)
     UC_STAMP(9);
+    if (ROWS) {
+      // the frame m = 8 of a row's last block IS that block: what the next call's first offsets still read of this call
+      // goes to the state's other half straight from the registers (16 coalesced word stores on 1 frame in 8 row_blocks)
+      if (p.save && (f & 7u) == 7u) {
+        const unsigned g8 = f >> 3;
+        const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
+        if (g8 - s * p.row_blocks == p.row_blocks - 1u) {
+          const __amdgpu_buffer_rsrc_t rw = make_rsrc(prev_wr + (size_t)s * p.prev_pitch * 4, kN * 4);
+#pragma unroll
+          for (int m = 0; m < 8; m++) {
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xp[m].x), rw, voff4, T * 4 * (2 * m), 0);
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xp[m].y), rw, voff4, T * 4 * (2 * m + 1), 0);
+          }
+        }
+      }
+    }
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
       v2f v[16];

@@ -48,8 +48,14 @@ struct BandParams {
   // 256 m samples into block jb.  In front of block 0 of row s lies prev + s * prev_pitch (the newest block the FIFO
   // held before this call; prev_pitch = 0: one block of zeros for every row, the FIFO at power-on, main.c:94).
   // n_frames = rows * row_blocks * 8; `stride` is not used.
+  // A live state keeps that block in TWO halves, prev_half elements apart, and one device word *parity says which half is
+  // current: rows read half *parity, and (save != 0) the frame m = 8 of a row's last block -- which is that block, whole --
+  // stores its raw words into the OTHER half of its row on the way through (the replay kernel behind the launch flips
+  // *parity).  Nothing is copied by a kernel of its own, no frame reads what another one writes.  parity == nullptr: half 0.
   const void* prev;
-  size_t row_pitch, prev_pitch;
+  size_t row_pitch, prev_pitch, prev_half;
+  const unsigned int* parity;
+  uint32_t save;
   uint32_t row_blocks;
   uint32_t div_magic, div_shift;  // u / row_blocks for u < 2^31: (mulhi(u, div_magic) + u) >> div_shift (uc::rows_divisor)
 };

@@ -64,6 +64,9 @@ struct RxParams {
   // offered so far (trace records carry stream-global block indices), rx_loop_words() words each -- loaded at the start of
   // the replay and stored back at its end; nullptr = a recorded stream (the locals start as at power-on, block 0)
   uint32_t* loop_state;
+  // live streams: the word that says which half of the state's newest-block store is current (uc_kernels.hpp: BandParams);
+  // the replay flips it on its way out -- the band launch in front of it has filled the other half.  nullptr: none.
+  unsigned int* parity;
 };
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);
@@ -72,11 +75,14 @@ int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_
 int launch_rx_pack(const void* src, size_t src_stride, uint32_t n, uint32_t nb, size_t n_streams, const uint32_t* acc,
                    const uint32_t* na, void* dst, size_t pitch, bool aligned16, hipStream_t stream);
 int launch_rx_replay(const RxParams& p, hipStream_t stream);
-// live streams: words of main()'s locals (+ the block counter) per stream; their power-on image; the FIFO's newest block a
-// call leaves behind -- last[s] = n words of `base` at s * pitch + ((na ? na[s] : nb) - 1) * n (untouched when na[s] == 0)
+// live streams: words of main()'s locals (+ the block counter) per stream; their power-on image.
 int rx_loop_words();
 int launch_rx_state_init(uint32_t* loop_state, size_t n_streams, uint32_t n, float snr_threshold, hipStream_t stream);
+// The FIFO's newest block a BUSY-MASKED call leaves behind (without a mask the band kernel stores it on its way through):
+// half (1 - *parity) of `last` ([2][n_streams][n] words) receives, for every stream, the stream's last accepted block of the
+// call -- n words of `base` at s * pitch + (na[s] - 1) * n -- or, when every block of the stream was dropped, the block the
+// current half holds.  Must run BEFORE the replay kernel of the call (which flips *parity).
 int launch_rx_last(const void* base, size_t pitch, const uint32_t* na, uint32_t nb, uint32_t n, size_t n_streams,
-                   void* last, bool aligned16, hipStream_t stream);
+                   void* last, const unsigned int* parity, bool aligned16, hipStream_t stream);
 
 }  // namespace uc

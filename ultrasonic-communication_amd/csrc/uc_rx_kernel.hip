@@ -147,6 +147,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
     __builtin_memcpy(p.loop_state + s * kImageWords, mine, sizeof(SeqLoop));
     p.loop_state[s * kImageWords + kStateWords] = block_base + p.nb;
   }
+  if (p.parity && s == 0) *p.parity ^= 1u;  // (nothing of this launch reads it)
   if (p.carry_out && count) {
     // the FIFO after the call's last accepted block: its last 9 records are what the next block's FIFO starts with
     float2 keep[9];
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
     if (p.n_text) p.n_text[s] = ntext;
     if (p.n_trace) p.n_trace[s] = nt;
     loop_mem[kStateWords] = block_base + p.nb;
+    if (p.parity && s == 0) *p.parity ^= 1u;  // (nothing of this launch reads it)
   }
   __syncthreads();
   if (p.loop_state && lane < kImageWords) p.loop_state[s * kImageWords + lane] = loop_mem[lane];
@@ -271,15 +273,16 @@ __global__ __launch_bounds__(64) void state_init_kernel(uint32_t* loop_state, si
     loop_state[i] = img[i % kImageWords];
 }
 
-// the FIFO's newest block a call leaves behind: n words per stream, the stream's LAST accepted block of the call
+// the FIFO's newest block a busy-masked call leaves behind (uc_rx.hpp: launch_rx_last)
 template <int VEC>
 __global__ __launch_bounds__(kPackThreads) void last_kernel(const uint32_t* base, size_t pitch, const uint32_t* na, uint32_t nb,
-                                                            uint32_t n, uint32_t* last) {
+                                                            uint32_t n, uint32_t* last, const unsigned int* parity, size_t half) {
   const size_t s = blockIdx.x;
   const uint32_t count = na ? na[s] : nb;
-  if (count == 0) return;  // every block of the stream was dropped: the FIFO is as it was
-  const uint32_t* from = base + s * pitch + (size_t)(count - 1) * n;
-  uint32_t* d = last + s * (size_t)n;
+  const unsigned par = *parity & 1u;
+  // every block of the stream dropped: the FIFO is as it was -- the block moves to the other half with the rest
+  const uint32_t* from = count ? base + s * pitch + (size_t)(count - 1) * n : last + par * half + s * (size_t)n;
+  uint32_t* d = last + (par ^ 1u) * half + s * (size_t)n;
   if (VEC == 4) {
     typedef unsigned int v4u __attribute__((ext_vector_type(4)));
     for (uint32_t i = threadIdx.x; i < n / 4; i += kPackThreads) reinterpret_cast<v4u*>(d)[i] = reinterpret_cast<const v4u*>(from)[i];
@@ -307,14 +310,15 @@ int launch_rx_state_init(uint32_t* loop_state, size_t n_streams, uint32_t n, flo
 }
 
 int launch_rx_last(const void* base, size_t pitch, const uint32_t* na, uint32_t nb, uint32_t n, size_t n_streams, void* last,
-                   bool aligned16, hipStream_t stream) {
+                   const unsigned int* parity, bool aligned16, hipStream_t stream) {
   if (n_streams == 0 || nb == 0) return (int)hipSuccess;
+  const size_t half = n_streams * (size_t)n;
   if (aligned16)
     hipLaunchKernelGGL(last_kernel<4>, dim3((unsigned)n_streams), dim3(kPackThreads), 0, stream, (const uint32_t*)base, pitch, na,
-                       nb, n, (uint32_t*)last);
+                       nb, n, (uint32_t*)last, parity, half);
   else
     hipLaunchKernelGGL(last_kernel<1>, dim3((unsigned)n_streams), dim3(kPackThreads), 0, stream, (const uint32_t*)base, pitch, na,
-                       nb, n, (uint32_t*)last);
+                       nb, n, (uint32_t*)last, parity, half);
   return (int)hipGetLastError();
 }
 

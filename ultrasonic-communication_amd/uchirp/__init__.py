@@ -367,6 +367,38 @@ class Engine:
         traces = [trace[i, :ntrace[i]] for i in range(ns)] if want_trace else None
         return texts, traces
 
+    def receive_many_into(self, samples, text, n_text, trace=None, n_trace=None, busy=None, stream=None, _state=None):
+        """uc_receive_streams[_next] with every buffer on the device (contiguous torch tensors): asynchronous on `stream`,
+        nothing is staged, nothing is copied back -- the form a live host calls block after block, and the one that can be
+        captured into a hipGraph (after one eager call of the same shape has sized the scratch).
+        samples [n_streams, k * n] int32 / float32; text uint8 [n_streams, text_cap]; n_text int32 [n_streams];
+        trace (optional) uint8 [n_streams, trace_cap, 20] (view as RX_EVENT_DTYPE on the host); n_trace int32 [n_streams];
+        busy (optional) uint8 [n_streams, k]."""
+        import torch
+        t = samples
+        if t.dim() != 2 or not t.is_contiguous() or t.dtype not in (torch.int32, torch.float32) or t.device.type != "cuda":
+            raise ValueError("samples must be a contiguous 2-d int32 / float32 GPU tensor")
+        for name, x in (("text", text), ("n_text", n_text), ("trace", trace), ("n_trace", n_trace), ("busy", busy)):
+            if x is not None and (x.device.type != "cuda" or not x.is_contiguous()):
+                raise ValueError("%s must be a contiguous GPU tensor" % name)
+        dt = DTYPE_I32 if t.dtype == torch.int32 else DTYPE_F32
+        ns, nsmp = int(t.shape[0]), int(t.shape[1])
+        if text.shape[0] != ns or n_text.numel() != ns or (busy is not None and tuple(busy.shape) != (ns, nsmp // self.n)):
+            raise ValueError("output / busy shapes do not match %d streams" % ns)
+        trace_cap = int(trace.shape[1]) if trace is not None else 0
+        if trace is not None and (trace.shape[0] != ns or trace[0, 0].numel() * trace.element_size() != RX_EVENT_DTYPE.itemsize):
+            raise ValueError("trace must be [n_streams, trace_cap] records of %d bytes" % RX_EVENT_DTYPE.itemsize)
+        if stream is None:
+            stream = torch.cuda.current_stream(t.device).cuda_stream
+        p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
+        tail = (p(busy), p(text), int(text.shape[1]), p(n_text), p(trace), trace_cap, p(n_trace), C.c_void_p(stream) if stream else None)
+        if _state is None:
+            _check(lib().uc_receive_streams(self._h, p(t), dt, ns, nsmp, 0, *tail), "uc_receive_streams")
+        else:
+            if ns != _state.n_streams:
+                raise ValueError("this state holds %d streams" % _state.n_streams)
+            _check(lib().uc_receive_streams_next(self._h, _state._h, p(t), dt, nsmp, 0, *tail), "uc_receive_streams_next")
+
     def stream_geometry(self, n_samples):
         """uc_stream_geometry -> (halo, n_out, n_blocks, hop) for a buffer of n_samples (UC_STREAM)."""
         v = [C.c_size_t() for _ in range(4)]
@@ -698,8 +730,13 @@ class LiveStreams:
         """uc_receive_streams_next: the next whole blocks of every stream, [n_streams, k * n] -> (texts, traces) of this chunk."""
         return self.engine.receive_many(samples, busy=busy, text_cap=text_cap, want_trace=want_trace, stream=stream, _state=self)
 
-    def reset(self):
-        _check(lib().uc_rx_state_reset(self._h, None), "uc_rx_state_reset")
+    def next_into(self, samples, text, n_text, trace=None, n_trace=None, busy=None, stream=None):
+        """The same with every buffer on the device, asynchronous, capturable (Engine.receive_many_into)."""
+        return self.engine.receive_many_into(samples, text, n_text, trace=trace, n_trace=n_trace, busy=busy, stream=stream,
+                                             _state=self)
+
+    def reset(self, stream=None):
+        _check(lib().uc_rx_state_reset(self._h, C.c_void_p(stream) if stream else None), "uc_rx_state_reset")
 
     def close(self):
         if getattr(self, "_h", None):
