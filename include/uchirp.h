@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define UC_ABI_VERSION 5
+#define UC_ABI_VERSION 6
 
 /* pipeline variants */
 enum {
@@ -71,8 +71,15 @@ enum { UC_DOWN_CHIRP = 0, UC_UP_CHIRP = 1 };
 /* element type of `frames` */
 enum {
   UC_DTYPE_I32 = 0, /* raw DFSDM words, cast with (float) -- main.c:664 */
-  UC_DTYPE_F32 = 1  /* already-cast fifo_queue contents -- main.c:94   */
+  UC_DTYPE_F32 = 1, /* already-cast fifo_queue contents -- main.c:94   */
+  UC_DTYPE_PDM = 2  /* uc_receive_streams[_next] and their uc_group_ forms only: the microphones' 1-bit PDM streams, 32 bits
+                       per word (uc_dfsdm_sinc5's packing), one word per sample -- the DFSDM in front of the ISR
+                       (receiver/Src/dfsdm.c:59-61,69,78) runs on the device, its filter history travels in the uc_rx_state */
 };
+
+/* four PDM words of a silent microphone (alternating bits: the sinc^5 output is 0 +- 1 LSB): the filter history of a stream
+ * that STARTS (uc_rx_state at power-on; every stream of uc_receive_streams) */
+#define UC_PDM_SILENCE 0xAAAAAAAAu
 
 /* symbol_out values */
 #define UC_SYM_DOWN 0u    /* bit low : snr_down >  snr_up  (main.c:523-526) */
@@ -282,20 +289,25 @@ int uc_receive_stream_isr(uc_ctx* ctx, const void* samples, int dtype, size_t n_
 /*
  * The same receiver for MANY recorded streams at once ("one independent stream per GPU (replicas
  * across streams)" -- here thousands per GPU): stream s = n_samples words at samples + s * stream_stride_elems
- * (stream_stride_elems == 0: n_samples; n_samples / n blocks each).  One copy kernel lays every stream's ACCEPTED blocks
- * out behind the FIFO's 2 n initial zeros (busy: n_streams x (n_samples / n) bytes, nullable -- busy[s][b] != 0 drops block
- * b of stream s as the ISR would, receiver/Src/main.c:661), ONE launch of the band kernel evaluates every 256-sample
- * offset of every stream, and main()'s switch (main.c:417-554) + resync() (main.c:243-273) are replayed ON THE DEVICE,
- * one lane per stream: include/uchirp_mainloop.hpp compiled for the device, the code uc_receive_stream replays on the
- * host, so a stream's text and trace are the ones uc_receive_stream[_isr] gives for it alone, bit for bit.
+ * (stream_stride_elems == 0: n_samples; n_samples / n blocks each).  busy: n_streams x (n_samples / n) bytes, nullable --
+ * busy[s][b] != 0 drops block b of stream s as the ISR would (receiver/Src/main.c:661).
+ * The ISR shifts the FIFO by ONE block per accepted block (main.c:662), so of the 17 offsets dsp() can visit in the new FIFO
+ * (pos = 0 .. 2 n in steps of 256) 9 were evaluated when the block before it arrived: ONE launch of the band kernel evaluates
+ * the 8 offsets every accepted block ADDS -- each frame is the tail of one block and the head of the next, read through two
+ * base addresses from the caller's buffer as it lies (no packed copy, no frame that straddles two streams; with a busy mask
+ * the accepted blocks are first laid out one behind the other) -- and main()'s switch (main.c:417-554) + resync()
+ * (main.c:243-273) are replayed ON THE DEVICE, one wave or one lane per stream: include/uchirp_mainloop.hpp compiled for the
+ * device, the code uc_receive_stream replays on the host, so a stream's text and trace are the ones uc_receive_stream[_isr]
+ * gives for it alone, bit for bit.
  *   text    n_streams x text_cap bytes: the decoded characters of stream s at text + s * text_cap, NUL-terminated
  *   n_text  (nullable) characters per stream
  *   trace   (nullable) n_streams x trace_cap records, one per processed block of the stream; n_trace (nullable) how many
  * Every pointer may be host or device memory; with device pointers only, the call is asynchronous on hip_stream.
- * Without a busy mask, and with streams a multiple of 256 samples apart, nothing is copied: the band kernel runs over the
- * caller's buffer as it lies (only [2 n zeros | first block] of every stream is staged for the offsets that reach into the
- * FIFO's initial zeros); otherwise the context holds a packed copy of the streams (4 bytes per sample).  Either way
- * 8 bytes per 256 samples of statistics.
+ * dtype: UC_DTYPE_I32 / UC_DTYPE_F32 samples, or UC_DTYPE_PDM (the microphones' bit streams, one 32-bit word per sample: the
+ * DFSDM runs on the device first; device buffers 16-byte aligned, the stride a multiple of 4 words).
+ * 8 bytes per 256 samples of statistics are parked in the context between the kernels of a call.  That scratch serves one
+ * call at a time: calls of one context on DIFFERENT streams are ordered by the library (the later one waits, on the device,
+ * for the earlier one's kernels) -- use one context per stream, or live states, for calls that should overlap.
  */
 int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_streams, size_t n_samples,
                        size_t stream_stride_elems, const uint8_t* busy /*nullable*/, char* text, size_t text_cap,
@@ -305,11 +317,20 @@ int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_str
 /*
  * Live streams: the firmware does not process recordings -- its ISR appends a block every 26.2 ms and main() makes one pass
  * of its switch per block, for ever (receiver/Src/main.c:417-578, 659-668).  A uc_rx_state holds, on the device, what n_streams
- * such receivers carry from one block to the next: the FIFO's last two accepted blocks and main()'s locals (mag_stat[],
- * history[], state, sync_position, the byte being assembled ...).  uc_receive_streams_next() is uc_receive_streams() for the
- * NEXT n_samples (whole blocks) of every stream: the chunks of a stream, of any sizes, give exactly the text and trace of the
- * whole stream in one call (trace records carry stream-global block indices; `text` receives the characters decoded during
- * THIS call).  busy as in uc_receive_streams (flags of this chunk's blocks).  A state belongs to the context that made it.
+ * such receivers carry from one block to the next: the FIFO's newest accepted block, the (up, down) statistics of the 9 FIFO
+ * offsets that survive the ISR's shift, main()'s locals (mag_stat[], history[], state, sync_position, the byte being
+ * assembled ...), the number of blocks seen, the DFSDM's filter history, and the scratch of the call in flight.
+ * uc_receive_streams_next() is uc_receive_streams() for the NEXT n_samples (whole blocks) of every stream: the chunks of a
+ * stream, of any sizes, give exactly the text and trace of the whole stream in one call (trace records carry stream-global
+ * block indices; `text` receives the characters decoded during THIS call).  busy as in uc_receive_streams (flags of this
+ * chunk's blocks).  One new block of every stream costs 8 transforms per stream and reference, 2 kernel launches (4 with a
+ * busy mask, +2 for UC_DTYPE_PDM), no copy.
+ * Everything a step carries lives on the device, so with device pointers the call can be captured into a hipGraph and the
+ * graph replayed for every block that arrives (make one eager call of the same shape first: it sizes the scratch; nothing is
+ * allocated during a capture; uc_rx_state_reset puts the receivers back to power-on).
+ * A state belongs to the context that made it and must be destroyed BEFORE that context (uc_destroy / uc_group_destroy);
+ * calls on different states of one context may be in flight on different streams at once, calls on one state are the
+ * caller's to order (one stream).
  */
 typedef struct uc_rx_state uc_rx_state;
 int uc_rx_state_create(uc_ctx* ctx, size_t n_streams, uc_rx_state** out);   /* every receiver at power-on */
@@ -374,6 +395,19 @@ int uc_process_stream(uc_ctx* ctx, const void* samples, int dtype, size_t n_samp
  */
 int uc_dfsdm_sinc5(uc_ctx* ctx, const uint32_t* pdm_words, size_t n_words, int32_t* words_out,
                    void* hip_stream);
+
+/*
+ * The same peripheral for MANY microphones at once, block after block: stream s = n_words NEW words at
+ * pdm_words + s * stride_words (no history in the buffer), its n_words DFSDM words go to words_out + s * out_stride_words
+ * (strides 0: n_words).  history: n_streams x 4 words, in and out -- the last four PDM words every stream had before this
+ * call (UC_PDM_SILENCE x 4 for a stream that starts); the call leaves the last four words of [history | new words] there, so
+ * that the chunks of a stream, of any sizes (one word included), give exactly uc_dfsdm_sinc5 of the whole stream behind its
+ * first history: words_out[s][q] is the conversion that ends with new word q.  Integer arithmetic, exact.
+ * Host or device pointers, each on its own (device: 16-byte aligned, strides multiples of 4 words); asynchronous on hip_stream
+ * when all three are device memory.  The live receivers take PDM words directly: UC_DTYPE_PDM.
+ */
+int uc_dfsdm_sinc5_streams(uc_ctx* ctx, const uint32_t* pdm_words, size_t n_streams, size_t n_words, size_t stride_words,
+                           uint32_t* history, int32_t* words_out, size_t out_stride_words, void* hip_stream);
 
 /*
  * ---- Frame sharding across the GPUs of a node (BASELINE.json configs[4]) -----------------------

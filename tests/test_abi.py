@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(uchirp):
     missing = [s for s in decl if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(uchirp.EXPORTS) == decl
-    assert L.uc_abi_version() == 5
+    assert L.uc_abi_version() == 6
 
 
 def test_struct_layouts(uchirp):

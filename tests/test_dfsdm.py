@@ -164,3 +164,147 @@ def test_pdm_to_symbols_on_the_gpu(uchirp):
     gs, _ = e.process(words.reshape(-1, 2048))
     rs, _ = o.process(ref_words.reshape(-1, 2048))
     assert np.array_equal(gs, rs) and np.array_equal(gs, bits)
+
+
+def _sinc5_with_history(words, hist0=None):
+    """The oracle's DFSDM words of a stream behind its first filter history (four silent words unless given)."""
+    h = np.full(4, 0xAAAAAAAA, np.uint32) if hist0 is None else np.asarray(hist0, np.uint32)
+    return uco.dfsdm_sinc5(np.concatenate([h, np.asarray(words, np.uint32)]))
+
+
+def test_oracle_silent_history_is_silence():
+    """UC_PDM_SILENCE: alternating bits are the PDM stream of a silent microphone -- the filter output is 0 within the last
+    bit of the 24-bit result -- so a stream that starts behind four such words starts from rest, not from a full-scale step."""
+    y = uco.dfsdm_sinc5(np.full(64, 0xAAAAAAAA, np.uint32))
+    assert np.abs(y.astype(np.int64)).max() <= 256
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_streams", [1, 64, 4096])
+def test_sinc5_streams_with_carried_history_bit_exact(uchirp, n_streams):
+    """uc_dfsdm_sinc5_streams: many microphones, chunk after chunk, the 4-word filter history of every stream carried in an
+    array the call reads and brings up to date.  Chunks of ANY sizes -- one word, sizes around the 252-output tile, one
+    2048-word block, sizes that are not multiples of 4 -- give, stream by stream, exactly the oracle's DFSDM words of the
+    whole stream behind its first history; host arrays and device tensors; no stream's output touches its neighbour's."""
+    import torch
+    dev = torch.device("cuda:0")
+    e = uchirp.Engine(uchirp.RX_REAL)
+    rng = np.random.default_rng(100 + n_streams)
+    sizes = [1, 2, 3, 5, 4, 251, 252, 253, 256, 2048, 7, 504, 505, 2048, 1000]
+    total = sum(sizes)
+    w = rng.integers(0, 1 << 32, size=(n_streams, total), dtype=np.uint64).astype(np.uint32)
+    if n_streams >= 64:                                                       # the patterns of the single-stream test too
+        for k, (_, pat) in enumerate(patterns(total, seed=n_streams)):
+            w[k] = pat
+    hist0 = rng.integers(0, 1 << 32, size=(n_streams, 4), dtype=np.uint64).astype(np.uint32)
+    hist0[::2] = 0xAAAAAAAA
+    check = range(n_streams) if n_streams <= 64 else list(range(0, n_streams, 97)) + [n_streams - 1]
+    ref = {s: _sinc5_with_history(w[s], hist0[s]) for s in check}
+    # host arrays (any chunk sizes: the library pads its staging rows)
+    hist = hist0.copy()
+    got, b0 = [], 0
+    for nw in sizes:
+        got.append(e.dfsdm_streams(np.ascontiguousarray(w[:, b0:b0 + nw]), hist))
+        b0 += nw
+        assert np.array_equal(hist[:, -min(nw, 4):], w[:, b0 - min(nw, 4):b0])   # the history is the stream's last words
+    got = np.concatenate(got, axis=1)
+    for s in check:
+        assert np.array_equal(got[s], ref[s]), s
+    # device tensors (rows must stay 16-byte aligned: chunk sizes that are multiples of 4), guard words behind every row
+    hist_d = torch.from_numpy(hist0.view(np.int32).copy()).to(dev)
+    wd = torch.from_numpy(w.view(np.int32)).to(dev)
+    GUARD = -7654321
+    got, b0 = [], 0
+    for nw in [s4 for s4 in (4, 252, 256, 2048, 8, 504, 2048, 1000) if b0 + s4 <= total]:
+        if b0 + nw > total:
+            break
+        out = torch.full((n_streams, nw + 4), GUARD, dtype=torch.int32, device=dev)
+        chunk = wd[:, b0:b0 + nw].contiguous()
+        L = uchirp.lib()
+        import ctypes as C
+        rc = L.uc_dfsdm_sinc5_streams(e._h, C.c_void_p(chunk.data_ptr()), n_streams, nw, 0, C.c_void_p(hist_d.data_ptr()),
+                                      C.c_void_p(out.data_ptr()), nw + 4, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        assert rc == 0, L.uc_last_error()
+        torch.cuda.synchronize()
+        o = out.cpu().numpy()
+        assert (o[:, nw:] == GUARD).all(), "stored past the end of a row (chunk of %d)" % nw
+        got.append(o[:, :nw])
+        b0 += nw
+    got = np.concatenate(got, axis=1)
+    for s in check:
+        assert np.array_equal(got[s], ref[s][:got.shape[1]]), s
+    assert np.array_equal(hist_d.cpu().numpy().view(np.uint32), w[:, b0 - 4:b0])
+    # refused: misaligned device rows, overlapping streams
+    with pytest.raises(uchirp.UchirpError):
+        e.dfsdm_streams(wd[:, 1:7].contiguous()[:, :5].contiguous(), hist_d)     # 5-word rows: stride not a multiple of 4
+    e.close()
+
+
+def _pdm_transmissions(count, blocks, seed):
+    """`count` microphones: noise lead, one transmission each, rendered at the PDM bit rate (32 x 78125 Hz) and delta-sigma
+    modulated -> (pdm uint32 [count, blocks * 2048], messages)."""
+    from uchirp import tx
+    rng = np.random.default_rng(seed)
+    n_bits = blocks * 2048 * 32
+    pdm = np.zeros((count, blocks * 2048), np.uint32)
+    msgs = []
+    for s in range(count):
+        msg = "".join(chr(int(c)) for c in rng.integers(48, 123, size=int(rng.integers(2, 6))))
+        tone = tx.render(msg, fs_rx=78125.0 * 32, amplitude=0.35)
+        lead = (int(rng.integers(25, 40)) * 2048 + int(rng.integers(0, 2048))) * 32
+        x = rng.standard_normal(n_bits) * 0.01
+        assert lead + tone.size <= n_bits
+        x[lead:lead + tone.size] += tone
+        pdm[s] = uco.pdm_modulate(np.clip(x, -1.0, 1.0).astype(np.float32))
+        msgs.append(msg)
+    return pdm, msgs
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX])
+def test_live_receivers_fed_with_the_microphones_bit_streams(uchirp, variant):
+    """UC_DTYPE_PDM: the live chain of a node starts at the microphones' 1-bit PDM streams (receiver/Src/dfsdm.c:59-61,69,78 ->
+    main.c:659-668 -> 417-554).  The DFSDM runs on the device in front of the ISR's FIFO, its filter history travels in the
+    uc_rx_state.  Texts and traces -- block by block, in ragged chunks, with dropped blocks, recorded in one call -- equal,
+    bit for bit, the receiver fed with the ORACLE's DFSDM words of the same bit streams; the messages decode."""
+    import torch
+    N = 2048
+    blocks, ns = 112, 5
+    pdm, msgs = _pdm_transmissions(ns, blocks, seed=40 + variant)
+    words = np.stack([_sinc5_with_history(pdm[s]) for s in range(ns)])
+    assert words.shape == (ns, blocks * N)
+    e = uchirp.Engine(variant)
+    ref_t, ref_tr = e.receive_many(words)
+    assert sum(m in t for m, t in zip(msgs, ref_t)) >= ns - 2, (msgs, ref_t)   # (a bit slip at acquisition is the firmware's own)
+    rng = np.random.default_rng(3)
+    busy = (rng.random((ns, blocks)) < 0.05).astype(np.uint8)
+    ref_bt, ref_btr = e.receive_many(words, busy=busy)
+    # recorded, one call
+    t, tr = e.receive_many(pdm, pdm=True)
+    assert t == ref_t and all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(tr, ref_tr))
+    t, tr = e.receive_many(pdm, busy=busy, pdm=True)
+    assert t == ref_bt and all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(tr, ref_btr))
+    # live: one block per call (device chunks); ragged chunks with dropped blocks (host chunks)
+    for sizes, bz, want_t, want_tr in (([1] * blocks, None, ref_t, ref_tr), ([3, 1, 40, 2, 66], busy, ref_bt, ref_btr)):
+        live = e.live(ns)
+        texts, traces, b0 = [""] * ns, [[] for _ in range(ns)], 0
+        for k, nb in enumerate(sizes):
+            chunk = np.ascontiguousarray(pdm[:, b0 * N:(b0 + nb) * N])
+            arg = torch.from_numpy(chunk.view(np.int32)).to("cuda:0") if bz is None else chunk
+            t, tr = live.next(arg, busy=None if bz is None else np.ascontiguousarray(bz[:, b0:b0 + nb]), pdm=True)
+            for s in range(ns):
+                texts[s] += t[s]
+                traces[s].append(tr[s])
+            b0 += nb
+        assert b0 == blocks
+        for s in range(ns):
+            assert texts[s] == want_t[s], s
+            assert np.array_equal(np.concatenate(traces[s]).view(np.uint8), want_tr[s].view(np.uint8)), s
+        live.close()
+    # a state that began with PDM words refuses sample words in mid-stream
+    live = e.live(ns)
+    live.next(pdm[:, :N], pdm=True)
+    with pytest.raises(uchirp.UchirpError):
+        live.next(words[:, N:2 * N])
+    live.close()
+    e.close()

@@ -79,8 +79,9 @@ bool is_device_ptr(const void* p) {
 // (rx_guard below).
 struct RxScratch {
   DevBuf in, busy, acc, na, pad, rec, text, ntext, trace, ntrace;
+  DevBuf pcm, hist;  // UC_DTYPE_PDM: the DFSDM words of the call's blocks; the filter history of streams without a state
   void release() {
-    for (DevBuf* b : {&in, &busy, &acc, &na, &pad, &rec, &text, &ntext, &trace, &ntrace}) b->release();
+    for (DevBuf* b : {&in, &busy, &acc, &na, &pad, &rec, &text, &ntext, &trace, &ntrace, &pcm, &hist}) b->release();
   }
 };
 
@@ -114,7 +115,7 @@ struct uc_ctx {
   int32_t* d_cic4 = nullptr;  // sinc^5 byte tables, built on first use of uc_dfsdm_sinc5
   int32_t* d_cic1 = nullptr;
   int cic_blocks_per_cu = 0;
-  DevBuf s_cic_in, s_cic_out;
+  DevBuf s_cic_in, s_cic_out, s_cic_hist;
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
   int band_blocks_per_cu[5][3][2] = {};  // [default / wide / default + spectrum stores / rows / rows + wide][mode][dtype]: the instantiations differ in registers
@@ -467,6 +468,7 @@ void uc_destroy(uc_ctx* c) {
   if (c->d_cic1) (void)hipFree(c->d_cic1);
   c->s_cic_in.release();
   c->s_cic_out.release();
+  c->s_cic_hist.release();
   c->s_frames.release();
   c->s_mm.release();
   c->s_sym.release();
@@ -1067,13 +1069,8 @@ int uc_window_spectrum(uc_ctx* c, const void* frames, int dtype, size_t n_frames
   return 0;
 }
 
-int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t* words_out, void* hip_stream) {
-  if (!c) return fail(-EINVAL, "uc_dfsdm_sinc5: NULL ctx");
-  if (n_words <= 4) return 0;
-  if (!pdm_words || !words_out) return fail(-EINVAL, "uc_dfsdm_sinc5: NULL buffer");
-  hipError_t e = hipSetDevice(c->device);
-  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
-  hipStream_t stream = (hipStream_t)hip_stream;
+// the sinc^5 byte tables on the device and the kernel's LDS opt-in, once per context
+static int sinc5_prepare(uc_ctx* c) {
   if (!c->d_cic4) {
     std::vector<int32_t> t4, t1;
     uc::build_sinc5_tables(t4, t1);
@@ -1081,6 +1078,114 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
     if (!rc) rc = upload((void**)&c->d_cic1, t1.data(), t1.size() * sizeof(int32_t));
     if (rc) return rc;
   }
+  if (c->cic_blocks_per_cu == 0) {
+    c->cic_blocks_per_cu = uc::sinc5_max_blocks_per_cu();
+    if (c->cic_blocks_per_cu <= 0) {
+      c->cic_blocks_per_cu = 0;
+      return fail(-ENOMEM, "uc_dfsdm_sinc5: the kernel's LDS tables do not fit this device");
+    }
+  }
+  return 0;
+}
+
+// uc_dfsdm_sinc5_streams on device buffers: n_words NEW words of every stream, history carried in d_hist ([n_streams][4])
+static int sinc5_streams_launch(uc_ctx* c, const uint32_t* d_pdm, size_t n_streams, size_t n_words, size_t stride,
+                                uint32_t* d_hist, int32_t* d_out, size_t out_stride, hipStream_t stream) {
+  if (n_streams == 0 || n_words == 0) return 0;
+  if ((((uintptr_t)d_pdm | (uintptr_t)d_out | (uintptr_t)d_hist) & 15u) != 0 || (stride & 3u) != 0 || (out_stride & 3u) != 0)
+    return fail(-EINVAL, "uc_dfsdm_sinc5_streams: device buffers must be 16-byte aligned and the strides multiples of 4 words");
+  if (int rc = sinc5_prepare(c)) return rc;
+  uc::CicParams cp;
+  memset(&cp, 0, sizeof(cp));
+  cp.pdm = d_pdm;
+  cp.n_words = n_words;
+  cp.out = d_out;
+  cp.t4 = c->d_cic4;
+  cp.t1 = c->d_cic1;
+  cp.n_streams = n_streams;
+  cp.stride = stride;
+  cp.out_stride = out_stride;
+  cp.hist = d_hist;
+  const size_t tps = (n_words + 251) / 252;  // (uc::sinc5_tile_outputs() / waves per block: 252 outputs per tile)
+  if (tps * n_streams >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_dfsdm_sinc5_streams: too many tiles in one call");
+  cp.tps = (uint32_t)tps;
+  uc::rows_divisor(cp.tps, &cp.div_magic, &cp.div_shift);
+  size_t grid = (size_t)c->num_cu * (size_t)c->cic_blocks_per_cu;
+  if (c->grid_override > 0) grid = (size_t)c->grid_override;
+  const size_t per_block = (size_t)uc::sinc5_waves_per_block();
+  const size_t need = (tps * n_streams + per_block - 1) / per_block;
+  if (grid > need) grid = need;
+  if (c->clock_probe) {
+    if (c->clk_cic_blocks == 0) c->clk_cic_blocks = uc::clk::sinc5_max_blocks_per_cu();  // (the twin needs the same LDS opt-in)
+    if (c->clk_cic_blocks <= 0) return fail(-ENOMEM, "uc_dfsdm_sinc5: the clock-stamped kernel's LDS tables do not fit");
+    if (int crc = clock_buffer(c, grid, uc::clk::sinc5_waves_per_block(), stream, &cp.debug)) return crc;
+  }
+  const int lrc = (c->clock_probe ? uc::clk::launch_sinc5 : uc::launch_sinc5)(cp, (int)grid, stream);
+  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "sinc5 kernel launch");
+  return 0;
+}
+
+int uc_dfsdm_sinc5_streams(uc_ctx* c, const uint32_t* pdm_words, size_t n_streams, size_t n_words, size_t stride_words,
+                           uint32_t* history, int32_t* words_out, size_t out_stride_words, void* hip_stream) {
+  if (!c) return fail(-EINVAL, "uc_dfsdm_sinc5_streams: NULL ctx");
+  if (n_streams == 0 || n_words == 0) return 0;
+  if (!pdm_words || !words_out || !history) return fail(-EINVAL, "uc_dfsdm_sinc5_streams: NULL buffer");
+  if (stride_words == 0) stride_words = n_words;
+  if (out_stride_words == 0) out_stride_words = n_words;
+  if (stride_words < n_words || out_stride_words < n_words)
+    return fail(-EINVAL, "uc_dfsdm_sinc5_streams: streams overlap (stride < %zu words)", n_words);
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  // host buffers are staged through the context (padded to whole 16-byte rows), device buffers are used where they lie
+  const bool in_host = !is_device_ptr(pdm_words), hist_host = !is_device_ptr(history), out_host = !is_device_ptr(words_out);
+  const uint32_t* d_in = pdm_words;
+  size_t in_stride = stride_words;
+  if (in_host) {
+    in_stride = (n_words + 3) & ~(size_t)3;
+    if (int rc = c->s_cic_in.ensure(n_streams * in_stride * 4)) return rc;
+    e = hipMemcpy2DAsync(c->s_cic_in.p, in_stride * 4, pdm_words, stride_words * 4, n_words * 4, n_streams, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpy2DAsync(pdm)");
+    d_in = (const uint32_t*)c->s_cic_in.p;
+  }
+  uint32_t* d_hist = history;
+  if (hist_host) {
+    if (int rc = c->s_cic_hist.ensure(n_streams * 16)) return rc;
+    e = hipMemcpyAsync(c->s_cic_hist.p, history, n_streams * 16, hipMemcpyHostToDevice, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(history)");
+    d_hist = (uint32_t*)c->s_cic_hist.p;
+  }
+  int32_t* d_out = words_out;
+  size_t o_stride = out_stride_words;
+  if (out_host) {
+    o_stride = (n_words + 3) & ~(size_t)3;
+    if (int rc = c->s_cic_out.ensure(n_streams * o_stride * 4)) return rc;
+    d_out = (int32_t*)c->s_cic_out.p;
+  }
+  if (int rc = sinc5_streams_launch(c, d_in, n_streams, n_words, in_stride, d_hist, d_out, o_stride, stream)) return rc;
+  if (out_host || hist_host) {
+    if (out_host) {
+      e = hipMemcpy2DAsync(words_out, out_stride_words * 4, d_out, o_stride * 4, n_words * 4, n_streams, hipMemcpyDeviceToHost, stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpy2DAsync(words_out)");
+    }
+    if (hist_host) {
+      e = hipMemcpyAsync(history, d_hist, n_streams * 16, hipMemcpyDeviceToHost, stream);
+      if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(history)");
+    }
+    e = hipStreamSynchronize(stream);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamSynchronize");
+  }
+  return 0;
+}
+
+int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t* words_out, void* hip_stream) {
+  if (!c) return fail(-EINVAL, "uc_dfsdm_sinc5: NULL ctx");
+  if (n_words <= 4) return 0;
+  if (!pdm_words || !words_out) return fail(-EINVAL, "uc_dfsdm_sinc5: NULL buffer");
+  hipError_t e = hipSetDevice(c->device);
+  if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
+  hipStream_t stream = (hipStream_t)hip_stream;
+  if (int prc = sinc5_prepare(c)) return prc;
   const size_t n_out = n_words - 4;
   const uint32_t* d_in = pdm_words;
   if (!is_device_ptr(pdm_words)) {
@@ -1102,6 +1207,7 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
     return fail(-EINVAL, "uc_dfsdm_sinc5: a device `words_out` pointer must be 16-byte aligned");
   }
   uc::CicParams cp;
+  memset(&cp, 0, sizeof(cp));
   cp.pdm = d_in;
   cp.n_words = n_words;
   cp.out = d_out;
@@ -1109,13 +1215,6 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   cp.t1 = c->d_cic1;
   cp.ctr = nullptr;
   cp.debug = nullptr;
-  if (c->cic_blocks_per_cu == 0) {
-    c->cic_blocks_per_cu = uc::sinc5_max_blocks_per_cu();
-    if (c->cic_blocks_per_cu <= 0) {
-      c->cic_blocks_per_cu = 0;
-      return fail(-ENOMEM, "uc_dfsdm_sinc5: the kernel's LDS tables do not fit this device");
-    }
-  }
   size_t grid = (size_t)c->num_cu * (size_t)c->cic_blocks_per_cu;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   const size_t need = (n_out + uc::sinc5_tile_outputs() - 1) / uc::sinc5_tile_outputs();
@@ -1426,6 +1525,7 @@ struct uc_rx_state {
   float2* d_carry = nullptr;    // [n_streams][9]: (up, down) mag_max of the 9 FIFO offsets that survive the ISR's shift
                                 // (main.c:662): offsets n .. 2 n of the FIFO become 0 .. n of the next one; zeros at power-on
   uint32_t* d_loop = nullptr;   // [n_streams][rx_loop_words()]: main()'s locals (main.c:314-339) + blocks offered so far
+  uint32_t* d_hist = nullptr;   // [n_streams][4] PDM words: the DFSDM's sinc^5 history of every microphone (UC_DTYPE_PDM chunks)
   RxScratch rx;                 // scratch of the call in flight
   uint64_t blocks_seen = 0;     // host mirror of the block count (the overflow check only; a replayed graph does not bump it)
   int dtype = -1;               // of the words in d_last (the first call decides)
@@ -1438,10 +1538,13 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
   if (!c || !text || text_cap == 0) return fail(-EINVAL, "uc_receive_streams: NULL argument");
   if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX)
     return fail(-ENOTSUP, "uc_receive_streams: variant %d has no up/down state machine", (int)c->cfg.variant);
-  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return fail(-EINVAL, "uc_receive_streams: bad dtype %d", dtype);
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32 && dtype != UC_DTYPE_PDM)
+    return fail(-EINVAL, "uc_receive_streams: bad dtype %d", dtype);
   if (n_streams == 0) return 0;
   const uint32_t n = c->cfg.n;
   const uint32_t per_block = n / 256;  // new FIFO offsets per accepted block
+  const bool pdm = dtype == UC_DTYPE_PDM;
+  const int dtype_in = dtype;
   if (stream_stride_elems == 0) stream_stride_elems = n_samples;
   if (stream_stride_elems < n_samples) return fail(-EINVAL, "uc_receive_streams: streams overlap (stride %zu < %zu samples)",
                                                    stream_stride_elems, n_samples);
@@ -1517,6 +1620,26 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       e = hipMemcpyAsync(sc.in.p, samples, span * 4, hipMemcpyHostToDevice, stream);
       if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(streams)");
       d_in = sc.in.p;
+    }
+    if (pdm) {
+      // The chain starts at the microphones' bit streams: the DFSDM (receiver/Src/dfsdm.c:59-61,69,78) turns every 32 PDM
+      // bits into one word of `buf[]` -- whole blocks here, the filter history of every stream carried in the state (or,
+      // for streams that start with this call, the bit pattern of a silent microphone) -- and the ISR sees int32 words.
+      // The peripheral filters whether or not the ISR later drops the block: the busy mask applies behind it.
+      uint32_t* d_hist = st ? st->d_hist : nullptr;
+      if (!st) {
+        if (int rc = sc.hist.ensure(n_streams * 16)) return rc;
+        d_hist = (uint32_t*)sc.hist.p;
+        e = hipMemsetD32Async((hipDeviceptr_t)d_hist, (int)UC_PDM_SILENCE, n_streams * 4, stream);
+        if (e != hipSuccess) return hip_fail(e, "hipMemsetD32Async(pdm history)");
+      }
+      if (int rc = sc.pcm.ensure(n_streams * nb * (size_t)n * 4)) return rc;
+      if (int rc = sinc5_streams_launch(c, (const uint32_t*)d_in, n_streams, nb * (size_t)n, stream_stride_elems, d_hist,
+                                        (int32_t*)sc.pcm.p, nb * (size_t)n, stream))
+        return rc;
+      d_in = sc.pcm.p;
+      stream_stride_elems = nb * (size_t)n;
+      dtype = UC_DTYPE_I32;
     }
     // The ISR (main.c:659-668) appends a block only when the main loop has consumed the previous one; a block that arrives
     // while it is busy is DROPPED, the FIFO is not shifted.  The FIFO therefore only ever holds ACCEPTED blocks: with a busy
@@ -1602,7 +1725,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
     if (st) {
       st->blocks_seen += nb;
-      st->dtype = dtype;
+      st->dtype = dtype_in;
     }
   }
   if (host_out) {
@@ -1647,6 +1770,7 @@ extern "C" void uc_rx_state_destroy(uc_rx_state* st) {
   if (st->d_carry) (void)hipFree(st->d_carry);
   if (st->d_loop) (void)hipFree(st->d_loop);
   if (st->d_parity) (void)hipFree(st->d_parity);
+  if (st->d_hist) (void)hipFree(st->d_hist);
   st->rx.release();
   delete st;
 }
@@ -1662,6 +1786,7 @@ extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   const uint32_t n = c->cfg.n;
   e = hipMemsetAsync(st->d_last, 0, 2 * st->n_streams * (size_t)n * 4, stream);
   if (e == hipSuccess) e = hipMemsetAsync(st->d_parity, 0, sizeof(unsigned int), stream);
+  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)st->d_hist, (int)UC_PDM_SILENCE, st->n_streams * 4, stream);
   if (e == hipSuccess) e = hipMemsetAsync(st->d_carry, 0, st->n_streams * (size_t)(n / 256 + 1) * sizeof(float2), stream);
   if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(FIFO state)");
   const int lrc = uc::launch_rx_state_init(st->d_loop, st->n_streams, n, c->cfg.snr_threshold, stream);
@@ -1687,6 +1812,7 @@ extern "C" int uc_rx_state_create(uc_ctx* c, size_t n_streams, uc_rx_state** out
   const uint32_t n = c->cfg.n;
   e = hipMalloc((void**)&st->d_last, 2 * n_streams * (size_t)n * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_parity, 256);
+  if (e == hipSuccess) e = hipMalloc((void**)&st->d_hist, n_streams * 16);
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_carry, n_streams * (size_t)(n / 256 + 1) * sizeof(float2));
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_loop, n_streams * (size_t)uc::rx_loop_words() * 4);
   if (e != hipSuccess) {

@@ -62,6 +62,14 @@ __device__ __forceinline__ int from_prev_lane(int v) {
   return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
 }
 
+// MULTI (uc_dfsdm_sinc5_streams): many microphones at once, the filter history of every one CARRIED between calls instead
+// of lying in front of the samples.  Stream s = p.n_words new words at p.pdm + s * p.stride, its four history words at
+// p.hist + 4 s, its p.n_words outputs at p.out + s * p.out_stride.  A stream is cut into tiles of 252 outputs as the single
+// stream is; tile T = (stream T / tps, tile T % tps); lane 0 of a stream's FIRST tile takes its four words from the
+// history array (a second, 16-byte resource: every other lane is out of its range and reads zeros, lane 0 is out of range
+// of the sample resource -- the two loads are OR-ed, no branch), everything behind the load is the single-stream code.
+// (The history array is brought up to date by hist_kernel behind this launch: no tile reads what another one writes.)
+template <bool MULTI>
 __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
 #ifdef UC_CLOCKSTAMP
   const unsigned long long clk0_ = __builtin_readcyclecounter();
@@ -93,8 +101,15 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     c4[i] = (4u * b + ((unsigned)lane & 3u)) << 4;
     c1[i] = (unsigned)kT1Base | ((8u * b + ((unsigned)lane & 7u)) << 2);
   }
-  const size_t n_out = p.n_words - 4;
-  const size_t tiles = (n_out + kTileOut - 1) / kTileOut;
+  const size_t n_out = MULTI ? p.n_words : p.n_words - 4;  // (MULTI: per stream)
+  const size_t tiles = MULTI ? (size_t)p.tps * p.n_streams : (n_out + kTileOut - 1) / kTileOut;
+  // MULTI: tile -> (stream, tile of the stream), tile < 2^31
+  auto split = [&](size_t tile, size_t& s, size_t& t) {
+    const unsigned u = (unsigned)tile;
+    const unsigned q = (__umulhi(u, p.div_magic) + u) >> p.div_shift;
+    s = q;
+    t = u - q * p.tps;
+  };
   // (readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane; without it the tile
   // index, the buffer resources and all the 64-bit address arithmetic live in VGPRs and every buffer access is
   // wrapped in a waterfall loop)
@@ -103,7 +118,27 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
 
   // words base + 4 lane .. + 3 of a tile; past the end of the buffer the resource returns 0 (those outputs
   // are not stored), and so does a tile beyond the last one
-  auto load_tile = [&](size_t tile) {
+  auto load_tile = [&](size_t tile) -> v4u {
+    if constexpr (MULTI) {
+      if (tile >= tiles) return v4u{0u, 0u, 0u, 0u};
+      size_t s, t;
+      split(tile, s, t);
+      const uint32_t* stream = p.pdm + s * p.stride;
+      if (t == 0) {
+        // words -4 .. -1 of the stream are its carried history: lane 0 reads them, lanes 1 .. 63 read words 4 (lane - 1) ..
+        const int recs = p.n_words < (size_t)kTileOut ? (int)p.n_words : kTileOut;
+        const __amdgpu_buffer_rsrc_t rin = make_rsrc(stream, recs * 4);
+        const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.hist + 4 * s, 16);
+        const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rin, (lane - 1) * 16, 0, UC_STREAM_CPOL);
+        const v4u h = __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16, 0, 0);
+        return a | h;
+      }
+      const size_t first = t * kTileOut - 4;
+      const size_t left = p.n_words - first;
+      const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
+      const __amdgpu_buffer_rsrc_t rin = make_rsrc(stream + first, recs * 4);
+      return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, UC_STREAM_CPOL);
+    }
     const size_t base = tile * kTileOut;  // first word of the tile = first output of the tile + 4 - 4
     const size_t left = tile < tiles ? p.n_words - base : 0;
     const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
@@ -117,7 +152,14 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
   };
   // One tile of a wave: 256 words in, 252 outputs out.
   auto process = [&](const v4u w, size_t tile) {
-    const size_t base = tile * kTileOut;
+    size_t base = tile * kTileOut;
+    const int32_t* out_base = p.out;
+    if constexpr (MULTI) {
+      size_t s = 0, t = 0;
+      if (tile < tiles) split(tile, s, t);
+      base = t * kTileOut;
+      out_base = p.out + s * p.out_stride;
+    }
     const unsigned wd[4] = {w.x, w.y, w.z, w.w};
     int g[4][5];
 #pragma unroll
@@ -161,7 +203,7 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     // Pinned by tests/test_dfsdm.py::test_sinc5_ragged_tails_on_the_device_never_write_past_the_end (guard words).
     const size_t left = tile < tiles ? n_out - base : 0;
     const int recs = left < (size_t)kTileOut ? (int)left : kTileOut;
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(p.out + (tile < tiles ? base : 0), recs * 4);
+    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out_base + (tile < tiles ? base : 0), recs * 4);
     v4u r;
     r.x = (unsigned)word(y0); r.y = (unsigned)word(y1); r.z = (unsigned)word(y2); r.w = (unsigned)word(y3);
 #if UC_CIC_KNOCK == 1  // (knock-out build: one lane of 63 stores)
@@ -238,23 +280,49 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
 #endif
 }
 
+// the filter history a call of uc_dfsdm_sinc5_streams leaves behind: the last four words of [history | the call's words]
+__global__ __launch_bounds__(256) void hist_kernel(const CicParams p) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= p.n_streams) return;
+  uint32_t* h = const_cast<uint32_t*>(p.hist) + 4 * s;
+  const uint32_t* w = p.pdm + s * p.stride;
+  uint32_t v[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {  // word n_words - 4 + k of the stream, counted from its first NEW word
+    const long long i = (long long)p.n_words - 4 + k;
+    v[k] = i >= 0 ? w[i] : h[4 + i];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) h[k] = v[k];
+}
+
 }  // namespace
 
 UC_LAUNCH_BEGIN
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream) {
+  if (p.n_streams) {  // uc_dfsdm_sinc5_streams
+    if (grid <= 0 || p.n_words == 0) return (int)hipSuccess;
+    hipLaunchKernelGGL(sinc5_kernel<true>, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((p.n_streams + 255) / 256)), dim3(256), 0, stream, p);
+    return (int)hipGetLastError();
+  }
   if (grid <= 0 || p.n_words <= 4) return (int)hipSuccess;
-  hipLaunchKernelGGL(sinc5_kernel, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
+  hipLaunchKernelGGL(sinc5_kernel<false>, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
   return (int)hipGetLastError();
 }
 
 // Called once per context on its device, before the first launch: more than the default 64 KiB of
 // dynamic LDS needs the opt-in; returns the resident workgroups per CU (0 if the opt-in fails).
 int sinc5_max_blocks_per_cu() {
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          (int)kCicLdsBytes) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kCicLdsBytes) != hipSuccess)
     return 0;
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel, TC, kCicLdsBytes) != hipSuccess || nb <= 0) nb = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel<false>, TC, kCicLdsBytes) != hipSuccess || nb <= 0) nb = 1;
   return nb;
 }
 

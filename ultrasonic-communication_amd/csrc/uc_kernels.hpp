@@ -168,6 +168,13 @@ struct CicParams {
   const int32_t* t1;     // [4][256]    per-byte contribution to output m+4
   unsigned int* ctr;     // one word per workgroup, zero at launch: the tile tickets its waves draw; nullptr = static deal
   unsigned long long* debug;  // diagnostic builds only (UC_CLOCKSTAMP), else nullptr
+  // uc_dfsdm_sinc5_streams (n_streams != 0): stream s = n_words NEW words at pdm + s * stride (no history in the buffer),
+  // n_words outputs at out + s * out_stride; hist = [n_streams][4] words, the filter history of every stream: read by the
+  // streams' first tiles, then brought up to date (the last four words of [history | new words]) by a second small kernel
+  size_t n_streams, stride, out_stride;
+  const uint32_t* hist;
+  uint32_t tps;                    // tiles per stream: ceil(n_words / 252)
+  uint32_t div_magic, div_shift;   // tile / tps (uc::rows_divisor)
 };
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
 int sinc5_max_blocks_per_cu();

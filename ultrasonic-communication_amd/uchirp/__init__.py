@@ -21,7 +21,8 @@ LIB_PATH = os.environ.get("UCHIRP_LIB") or os.path.join(_ROOT, "libuchirp.so")  
 
 RX_REAL, SYNC_CPLX, COMPRESS, DECHIRP_DOWN, IQ, STREAM = range(6)
 DOWN_CHIRP, UP_CHIRP = 0, 1
-DTYPE_I32, DTYPE_F32 = 0, 1
+DTYPE_I32, DTYPE_F32, DTYPE_PDM = 0, 1, 2
+PDM_SILENCE = 0xAAAAAAAA   # UC_PDM_SILENCE: the filter history of a stream that starts
 SYM_DOWN, SYM_UP, SYM_NONE = 0, 1, 0xFF
 FLAG_LIBM_TRIG, FLAG_TRUE_DC, FLAG_STREAM_UP, FLAG_IQ_BASEBAND, FLAG_NO_FRAME_PAIRS = 1, 2, 8, 16, 32
 (TABLE_UP, TABLE_DOWN, TABLE_HANN, TABLE_H_UP, TABLE_H_DOWN, TABLE_CARRIER_C, TABLE_CARRIER_S,
@@ -37,7 +38,8 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
            "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters",
            "uc_rx_state_create", "uc_rx_state_reset", "uc_rx_state_destroy", "uc_receive_streams_next",
-           "uc_rx_state_streams", "uc_group_receive_streams", "uc_group_receive_streams_next", "uc_group_process_stream"]
+           "uc_rx_state_streams", "uc_group_receive_streams", "uc_group_receive_streams_next", "uc_group_process_stream",
+           "uc_dfsdm_sinc5_streams"]
 GROUP_ID_BYTES = 128
 
 
@@ -119,6 +121,8 @@ def lib():
     L.uc_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
     L.uc_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
     L.uc_dfsdm_sinc5.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    L.uc_dfsdm_sinc5_streams.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p,
+                                         C.c_size_t, C.c_void_p]
     L.uc_set_table.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
     L.uc_window_bins.argtypes = [C.c_void_p]
     L.uc_window_spectrum.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p]
@@ -323,10 +327,11 @@ class Engine:
         """uc_rx_state_create: n_streams live receivers at power-on; feed them chunk after chunk with LiveStreams.next()."""
         return LiveStreams(self, n_streams)
 
-    def receive_many(self, samples, busy=None, text_cap=64, want_trace=True, stream=None, _state=None):
+    def receive_many(self, samples, busy=None, text_cap=64, want_trace=True, stream=None, _state=None, pdm=False):
         """uc_receive_streams: samples [n_streams, n_samples] (numpy int32 / float32, or a contiguous torch device tensor);
         busy [n_streams, n_samples // n] or None.  Returns (texts: list of str, traces: list of RX_EVENT_DTYPE arrays or
-        None).  Host results either way (the call waits)."""
+        None).  Host results either way (the call waits).  pdm=True: the words are the microphones' 1-bit PDM streams
+        (uint32 / int32 bit patterns, one word per sample: UC_DTYPE_PDM)."""
         if _is_torch(samples):
             import torch
             t = samples
@@ -339,11 +344,17 @@ class Engine:
                 stream = torch.cuda.current_stream(t.device).cuda_stream
         else:
             a = np.ascontiguousarray(samples)
+            if pdm and a.dtype == np.uint32:
+                a = a.view(np.int32)
             if a.ndim != 2 or a.dtype not in (np.int32, np.float32):
                 raise TypeError("samples must be a 2-d int32 / float32 array")
             dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
             ns, nsmp = a.shape
             ptr = a.ctypes.data_as(C.c_void_p)
+        if pdm:
+            if dt != DTYPE_I32:
+                raise TypeError("PDM words are 32-bit integers")
+            dt = DTYPE_PDM
         nb = nsmp // self.n
         bz = None
         if busy is not None:
@@ -367,7 +378,7 @@ class Engine:
         traces = [trace[i, :ntrace[i]] for i in range(ns)] if want_trace else None
         return texts, traces
 
-    def receive_many_into(self, samples, text, n_text, trace=None, n_trace=None, busy=None, stream=None, _state=None):
+    def receive_many_into(self, samples, text, n_text, trace=None, n_trace=None, busy=None, stream=None, _state=None, pdm=False):
         """uc_receive_streams[_next] with every buffer on the device (contiguous torch tensors): asynchronous on `stream`,
         nothing is staged, nothing is copied back -- the form a live host calls block after block, and the one that can be
         captured into a hipGraph (after one eager call of the same shape has sized the scratch).
@@ -382,6 +393,10 @@ class Engine:
             if x is not None and (x.device.type != "cuda" or not x.is_contiguous()):
                 raise ValueError("%s must be a contiguous GPU tensor" % name)
         dt = DTYPE_I32 if t.dtype == torch.int32 else DTYPE_F32
+        if pdm:
+            if dt != DTYPE_I32:
+                raise TypeError("PDM words are 32-bit integers")
+            dt = DTYPE_PDM
         ns, nsmp = int(t.shape[0]), int(t.shape[1])
         if text.shape[0] != ns or n_text.numel() != ns or (busy is not None and tuple(busy.shape) != (ns, nsmp // self.n)):
             raise ValueError("output / busy shapes do not match %d streams" % ns)
@@ -467,6 +482,35 @@ class Engine:
         res = np.zeros(max(a.size - 4, 0), np.int32)
         _check(lib().uc_dfsdm_sinc5(self._h, a.ctypes.data_as(C.c_void_p), a.size, res.ctypes.data_as(C.c_void_p),
                                     None), "uc_dfsdm_sinc5")
+        return res
+
+    def dfsdm_streams(self, pdm_words, history, out=None, stream=None):
+        """uc_dfsdm_sinc5_streams: pdm_words [n_streams, n_words] NEW words of every microphone, history [n_streams, 4] (in and
+        out: updated in place) -> int32 DFSDM words [n_streams, n_words].  numpy uint32 arrays (synchronous) or contiguous
+        torch int32 device tensors (asynchronous on `stream`)."""
+        if _is_torch(pdm_words):
+            import torch
+            t, h = pdm_words, history
+            for x in (t, h):
+                if not x.is_contiguous() or x.dtype != torch.int32 or x.device.type != "cuda" or x.dim() != 2:
+                    raise ValueError("pdm_words / history must be contiguous 2-d int32 GPU tensors (bit patterns of the words)")
+            ns, nw = int(t.shape[0]), int(t.shape[1])
+            if tuple(h.shape) != (ns, 4):
+                raise ValueError("history must be [n_streams, 4]")
+            if out is None:
+                out = torch.empty((ns, nw), dtype=torch.int32, device=t.device)
+            if stream is None:
+                stream = torch.cuda.current_stream(t.device).cuda_stream
+            _check(lib().uc_dfsdm_sinc5_streams(self._h, C.c_void_p(t.data_ptr()), ns, nw, 0, C.c_void_p(h.data_ptr()),
+                                                C.c_void_p(out.data_ptr()), 0, C.c_void_p(stream)), "uc_dfsdm_sinc5_streams")
+            return out
+        a = np.ascontiguousarray(pdm_words, np.uint32)
+        if a.ndim != 2 or history.dtype != np.uint32 or history.shape != (a.shape[0], 4) or not history.flags.c_contiguous:
+            raise ValueError("pdm_words [n_streams, n_words], history uint32 [n_streams, 4] (contiguous: updated in place)")
+        res = np.zeros(a.shape, np.int32)
+        _check(lib().uc_dfsdm_sinc5_streams(self._h, a.ctypes.data_as(C.c_void_p), a.shape[0], a.shape[1], 0,
+                                            history.ctypes.data_as(C.c_void_p), res.ctypes.data_as(C.c_void_p), 0, None),
+               "uc_dfsdm_sinc5_streams")
         return res
 
     def process_frame(self, pcm, mag_mean=1.0):
@@ -726,14 +770,15 @@ class LiveStreams:
         _check(lib().uc_rx_state_create(engine._h, self.n_streams, C.byref(h)), "uc_rx_state_create")
         self._h = h
 
-    def next(self, samples, busy=None, text_cap=64, want_trace=True, stream=None):
+    def next(self, samples, busy=None, text_cap=64, want_trace=True, stream=None, pdm=False):
         """uc_receive_streams_next: the next whole blocks of every stream, [n_streams, k * n] -> (texts, traces) of this chunk."""
-        return self.engine.receive_many(samples, busy=busy, text_cap=text_cap, want_trace=want_trace, stream=stream, _state=self)
+        return self.engine.receive_many(samples, busy=busy, text_cap=text_cap, want_trace=want_trace, stream=stream, _state=self,
+                                        pdm=pdm)
 
-    def next_into(self, samples, text, n_text, trace=None, n_trace=None, busy=None, stream=None):
+    def next_into(self, samples, text, n_text, trace=None, n_trace=None, busy=None, stream=None, pdm=False):
         """The same with every buffer on the device, asynchronous, capturable (Engine.receive_many_into)."""
         return self.engine.receive_many_into(samples, text, n_text, trace=trace, n_trace=n_trace, busy=busy, stream=stream,
-                                             _state=self)
+                                             _state=self, pdm=pdm)
 
     def reset(self, stream=None):
         _check(lib().uc_rx_state_reset(self._h, C.c_void_p(stream) if stream else None), "uc_rx_state_reset")
