@@ -5,7 +5,10 @@
  * The microphones here are synthetic: noise, then the K7 transmission (generator/ChirpGenerator.ipynb: G, 7 x H, L, the
  * message MSB first, 12 x G), one symbol per block, a different message and noise per stream.
  *
- * usage: host_live [n_streams=3]
+ * usage: host_live [n_streams=3] [pdm]
+ * With `pdm` the chain starts where the board's does: at the microphones' 1-bit PDM streams (2.5 Mbit/s each, a second-order
+ * delta-sigma modulator here), 2048 words of 32 bits per block and microphone, handed over as UC_DTYPE_PDM -- the DFSDM
+ * (receiver/Src/dfsdm.c:59-61,69,78) runs on the device and its filter history travels in the uc_rx_state with the rest.
  * Prints every stream's characters as they are decoded and, at the end, what each stream received.  Exit 0 when every
  * stream received its message.  Without a GPU: prints uc_create's error and exits 0 (there is no CPU path). */
 #include <math.h>
@@ -44,8 +47,36 @@ static void block(int32_t* out, const uc_config* cfg, int kind /* 1 H, 0 L, 2 G 
   }
 }
 
+/* the same block as the microphone's bit stream: the waveform at the PDM bit rate (32 x fs) through a second-order
+ * delta-sigma modulator whose integrators (dsm[0], dsm[1]) run on from block to block; full scale = 1 */
+static void block_pdm(uint32_t* out, const uc_config* cfg, int kind, double amp, double sigma, double dsm[2]) {
+  const double fs = cfg->fs, T = cfg->n / fs, k = (cfg->f1 - cfg->f0) / T, pi = 3.14159265358979323846;
+  uint32_t i;
+  int j;
+  for (i = 0; i < cfg->n; i++) {
+    const double nz = sigma * sqrt(-2.0 * log(uniform01())) * cos(2.0 * pi * uniform01());
+    uint32_t w = 0;
+    for (j = 0; j < 32; j++) {
+      const double t = (i + j / 32.0) / fs;
+      double x = nz, y;
+      if (kind != 2) {
+        const double f = kind ? cfg->f0 + k * t / 2.0 : cfg->f1 - k * t / 2.0;
+        const double arg = 2.0 * pi * f * t - pi / 2.0;
+        x += amp * (cos(arg) + sin(arg));
+      }
+      y = dsm[1] >= 0.0 ? 1.0 : -1.0;
+      dsm[0] += x - y;
+      dsm[1] += dsm[0] - y;
+      if (y > 0.0) w |= (uint32_t)1 << j; /* bit t of the stream = bit (t & 31) of word t >> 5 */
+    }
+    out[i] = w;
+  }
+}
+
 int main(int argc, char** argv) {
   const int ns = argc > 1 ? atoi(argv[1]) : 3;
+  const int pdm = argc > 2 && strcmp(argv[2], "pdm") == 0;
+  static double dsm[MAXS][2];
   static const char* const MSGS[4] = {"Hello World!", "uchirp", "MI355X", "0123456789"};
   uc_config cfg;
   uc_ctx* uc = NULL;
@@ -80,9 +111,10 @@ int main(int argc, char** argv) {
       if (q >= 1 && q <= 7) kind = 1;
       else if (q == 8) kind = 0;
       else if (q >= 9 && q < 9 + 8 * len) kind = (m[(q - 9) / 8] >> (7 - (q - 9) % 8)) & 1;
-      block(words + (size_t)s * NN, &cfg, kind, 2000.0, 50.0);
+      if (pdm) block_pdm((uint32_t*)words + (size_t)s * NN, &cfg, kind, 0.25, 0.00625, dsm[s]);
+      else block(words + (size_t)s * NN, &cfg, kind, 2000.0, 50.0);
     }
-    if (uc_receive_streams_next(uc, rx, words, UC_DTYPE_I32, NN, NN, NULL, &text[0][0], sizeof(text[0]), n_text, NULL, 0, NULL,
+    if (uc_receive_streams_next(uc, rx, words, pdm ? UC_DTYPE_PDM : UC_DTYPE_I32, NN, NN, NULL, &text[0][0], sizeof(text[0]), n_text, NULL, 0, NULL,
                                 NULL) != 0) {
       printf("uc_receive_streams_next: %s\n", uc_last_error());
       return 1;

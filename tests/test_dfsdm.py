@@ -301,6 +301,19 @@ def test_live_receivers_fed_with_the_microphones_bit_streams(uchirp, variant):
             assert texts[s] == want_t[s], s
             assert np.array_equal(np.concatenate(traces[s]).view(np.uint8), want_tr[s].view(np.uint8)), s
         live.close()
+    # the node's form: uc_group_receive_streams_next takes the bit streams too (world size 1 here: a rank's whole code path)
+    g = uchirp.Group(variant, devices=[0])
+    st = g.rx_state(0, ns)
+    cap = 64
+    th, nh, acc, at = np.zeros((ns, cap), np.uint8), np.zeros(ns, np.uint32), [""] * ns, 0
+    for nb in (2, 50, 60):
+        chunk = np.ascontiguousarray(pdm[:, at * N:(at + nb) * N]).view(np.int32)
+        g.receive_streams([chunk], ns, nb * N, [th], cap, n_text=[nh], states=[st], dtype=uchirp.DTYPE_PDM)
+        acc = [a + bytes(th[i, :nh[i]]).decode("latin-1") for i, a in enumerate(acc)]
+        at += nb
+    assert at == blocks and acc == ref_t
+    g.rx_state_destroy(st)
+    g.close()
     # a state that began with PDM words refuses sample words in mid-stream
     live = e.live(ns)
     live.next(pdm[:, :N], pdm=True)

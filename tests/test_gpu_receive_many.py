@@ -275,8 +275,9 @@ def test_plain_c_host_runs_live_microphones(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(root, "include"),
                            os.path.join(root, "tests", "c", "host_live.c"), "-o", exe, "-L" + libdir, "-luchirp", "-lm",
                            "-Wl,-rpath," + libdir])
-    out = subprocess.run([exe, "4"], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    for s, m in enumerate(("Hello World!", "uchirp", "MI355X", "0123456789")):
-        assert ('stream %d received "%s"' % (s, m)) in out.stdout
-    print(out.stdout.strip().splitlines()[-4:])
+    for mode in ([], ["pdm"]):        # DFSDM words; the microphones' 1-bit streams (UC_DTYPE_PDM: the DFSDM on the device)
+        out = subprocess.run([exe, "4"] + mode, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        for s, m in enumerate(("Hello World!", "uchirp", "MI355X", "0123456789")):
+            assert ('stream %d received "%s"' % (s, m)) in out.stdout
+        print(mode, out.stdout.strip().splitlines()[-4:])

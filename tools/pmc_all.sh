@@ -5,7 +5,7 @@
 # usage (on the GPU box): bash tools/pmc_all.sh <tag> ["target ..."]   -> gpurun_out/pmcall_<tag>/ (+ summary JSONs)
 # Never wrap the program: rocprofv3 ... -- python3 <script> directly.
 tag="${1:-rXX}"
-targets="${2:-band_rx_real_f32 band_sync_cplx_f32 band_dechirp_down_f32 compress_f32 iq2048_fw_f32 iq2048_bb_f32 iq1024_fw_f32 iq1024_bb_f32 stream_d8_f32 sinc5}"
+targets="${2:-band_rx_real_f32 band_sync_cplx_f32 band_dechirp_down_f32 compress_f32 iq2048_fw_f32 iq2048_bb_f32 iq1024_fw_f32 iq1024_bb_f32 stream_d8_f32 sinc5 sinc5_streams rows_rx_real_f32 rows_sync_cplx_f32}"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out="gpurun_out/pmcall_$tag"
 mkdir -p "$out"
@@ -32,7 +32,7 @@ for t in $targets; do
   run_pass $t sqb "$SQ_B"
   run_pass $t fetch "FETCH_SIZE"
   run_pass $t write "WRITE_SIZE"
-  if [ "$t" != "sinc5" ]; then
+  if true; then
     timeout -k 10 120 python3 tools/run_target.py $t --frames-log2 20 --clock --seconds 2.0 > "$out/$t.clock.json" 2> "$out/$t.clock.err" && echo "$t clock: $(python3 -c "import json;d=json.load(open('$out/$t.clock.json'));print(d['shader_clock_MHz_median'], d['ms_last_launch_events'])")"
   fi
 done

@@ -8,7 +8,10 @@
   --info prints {"target", "kernel", "units", "unit", "alg_bytes_per_unit"} of the launch and exits (no GPU work)
 
 Targets: band_rx_real_f32 band_rx_real_i32 band_sync_cplx_f32 band_dechirp_down_f32 compress_f32 iq2048_fw_f32
-iq2048_bb_f32 iq1024_fw_f32 iq1024_bb_f32 stream_d8_f32 sinc5
+iq2048_bb_f32 iq1024_fw_f32 iq1024_bb_f32 stream_d8_f32 sinc5 sinc5_streams rows_rx_real_f32 rows_sync_cplx_f32
+(sinc5_streams: uc_dfsdm_sinc5_streams, one 2048-word block of every microphone per launch; rows_*: the live receivers' step,
+uc_receive_streams_next with one new block of every stream per launch = 8 new FIFO offsets per stream: the band kernel's ROWS
+build + the replay kernel)
 (keys of profiles/r*_valu_insts.json; the I/Q targets run on the pass-band stream of BASELINE configs[2]).
 """
 import argparse
@@ -44,6 +47,11 @@ SPEC = {  # target -> (kernel-name substring, units, unit, algorithmic bytes per
     "iq1024_bb_f32": ("iq1024_kernel", 2 * nf, "frame", 4096 + 1),
     "stream_d8_f32": ("stream_kernel", nf * 2048, "sample", 4.5),
     "sinc5": ("sinc5_kernel", nf * 512, "word", 8.0),
+    "sinc5_streams": ("sinc5_kernel", nf * 512, "word", 8.0),
+    # a new block of a live stream: 8192 B read once (the frames overlap in cache), 8192 B kept for the next call, 8 x 8 B of
+    # records -- per NEW FIFO OFFSET (frame): 2056 B
+    "rows_rx_real_f32": ("band_kernel", nf, "frame", 2056),
+    "rows_sync_cplx_f32": ("band_kernel", nf, "frame", 2056),
 }
 kname, units, unit, alg = SPEC[T]
 if args.info:
@@ -71,6 +79,32 @@ if T.startswith("iq"):
 
     def launch():
         e.process(x, n_frames=units, want_symbols=bb, want_stats=not bb, symbols_out=sym, stats_out=st, stream=stream.cuda_stream)
+elif T == "sinc5_streams":
+    import ctypes as C
+    e = uchirp.Engine(uchirp.RX_REAL)
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    ns = units // 2048
+    pdm = torch.randint(-2 ** 31, 2 ** 31 - 1, (ns, 2048), generator=g, device=dev, dtype=torch.int64).to(torch.int32)
+    out = torch.empty((ns, 2048), dtype=torch.int32, device=dev)
+    hist = torch.full((ns, 4), -1431655766, dtype=torch.int32, device=dev)
+
+    def launch():
+        e.dfsdm_streams(pdm, hist, out=out, stream=stream.cuda_stream)
+elif T.startswith("rows_"):
+    e = uchirp.Engine(uchirp.RX_REAL if "rx_real" in T else uchirp.SYNC_CPLX)
+    ns = nf // 8
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    chunk = torch.randn((ns, 2048), generator=g, device=dev) * 50.0
+    if args.zeros:
+        chunk.zero_()
+    live = e.live(ns)
+    text = torch.zeros((ns, 16), dtype=torch.uint8, device=dev)
+    ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
+
+    def launch():
+        live.next_into(chunk, text, ntext, stream=stream.cuda_stream)
 elif T == "sinc5":
     e = uchirp.Engine(uchirp.RX_REAL)
     g = torch.Generator(device=dev)
