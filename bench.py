@@ -740,6 +740,45 @@ def parse_args(argv=None):
     return ap.parse_args(argv)
 
 
+class Watchdog:
+    """A rank that hangs (a peer died inside a collective, a rendezvous that never completes) must end the run LOUDLY and
+    soon, not sit until the driver's own limit kills it without a line of output.  Every rank starts one: the main thread
+    marks its progress (`mark`), a daemon thread checks the clock; past the limit it prints which rank, in which phase, after
+    which step, for how long -- and ends the process with status 4 (os._exit: a thread cannot unblock a collective; the
+    launcher then ends the other ranks).  UC_BENCH_TIMEOUT seconds for the whole run (default 300: well inside the driver's
+    600 s), never a retry."""
+
+    def __init__(self, rank, world, limit_s):
+        import threading
+        self.rank, self.world, self.limit = rank, world, float(limit_s)
+        self.t0 = time.time()
+        self.phase, self.step, self.t_mark = "start", -1, self.t0
+        self._stop = threading.Event()
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def mark(self, phase, step=-1):
+        self.phase, self.step, self.t_mark = phase, step, time.time()
+
+    def stop(self):
+        self._stop.set()
+
+    def _run(self):
+        while not self._stop.wait(0.5):
+            now = time.time()
+            if now - self.t0 > self.limit:
+                sys.stderr.write("bench.py WATCHDOG: rank %d of %d gave up after %.0f s (UC_BENCH_TIMEOUT): last progress %.1f s ago, "
+                                 "phase '%s'%s -- a peer has probably died or never arrived; exiting with status 4\n"
+                                 % (self.rank, self.world, now - self.t0, now - self.t_mark, self.phase,
+                                    (", last completed step %d" % self.step) if self.step >= 0 else ""))
+                sys.stderr.flush()
+                os._exit(4)
+
+
+def bench_timeout():
+    return float(os.environ.get("UC_BENCH_TIMEOUT", "300"))
+
+
 def launch_ranks(args):
     """`python bench.py --gpus N` outside a launcher: start the N ranks as fresh child processes.
     This parent never imports torch and never touches the GPU (a process that has initialised the GPU
@@ -760,7 +799,9 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else sys.stderr))
-    deadline = time.time() + float(os.environ.get("UC_BENCH_TIMEOUT", "900"))
+    # every rank carries a watchdog of its own (UC_BENCH_TIMEOUT, default 300 s) and reports where it hung; this parent
+    # waits a little longer, then says which ranks were still alive and ends exactly those
+    deadline = time.time() + bench_timeout() + 15.0
     rc = 0
     while rc == 0 and any(p.poll() is None for p in procs):
         time.sleep(0.2)
@@ -768,6 +809,10 @@ def launch_ranks(args):
         if time.time() > deadline:
             rc = -1
     if rc:
+        alive = [r for r, p in enumerate(procs) if p.poll() is None]
+        ended = {r: p.returncode for r, p in enumerate(procs) if p.poll() is not None}
+        sys.stderr.write("bench.py: %s; ranks still running: %s; ranks that had ended (exit status): %s -- ending the rest\n"
+                         % ("timed out" if rc == -1 else "a rank failed (exit %s)" % rc, alive, ended))
         for p in procs:                      # a rank died or hung: the others wait in a collective; end exactly those
             if p.poll() is None:
                 p.kill()
@@ -806,6 +851,8 @@ def single_process(args):
     os.dup2(2, 1)                              # RCCL's banner and anything else on descriptor 1 goes to stderr
     nf, mag_mean = args.frames, 1000.0
     devs = [torch.device("cuda", 0 if rehearse else d) for d in range(world)]
+    wd = Watchdog(0, 1, bench_timeout())      # (one process: ncclCommInitAll and the in-process gathers can hang too)
+    wd.mark("uc_group_create (ncclCommInitAll over %d devices)" % world)
     grp = uchirp.Group(uchirp.RX_REAL, devices=[d.index for d in devs], mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
     frames, streams = [], []
     for r, d in enumerate(devs):
@@ -818,6 +865,8 @@ def single_process(args):
     def step(k, ev=None):
         if ev is not None:
             for r in range(world):
+                if k >= NBUF:                 # the write-after-gather wait in FRONT of the bracket: [e0, e1] = the kernel alone
+                    grp.wait_gather(r, gat[k % NBUF][r], handles[r])
                 ev[r][0].record(streams[r])
         grp.process(frames, world * nf, gat[k % NBUF], streams=handles)
         if ev is not None:
@@ -836,8 +885,10 @@ def single_process(args):
             step(0)
         sync()
         ramp_launches += 4
+    wd.mark("warm-up")
     for k in range(args.warmup):
         step(k)
+        wd.mark("warm-up", k)
     sync()
     evs = []
     for k in range(args.steps):
@@ -849,8 +900,11 @@ def single_process(args):
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, evs[k])
+        wd.mark("timed region: enqueued", k)
+    wd.mark("timed region: waiting for the devices (gathers included)", args.steps - 1)
     sync()
     elapsed = time.perf_counter() - t0
+    wd.stop()
     km = np.array([[a.elapsed_time(b) for a, b in row] for row in evs]).mean(axis=0)       # kernel ms by device
     last = gat[(args.steps - 1) % NBUF]
     host = [g.cpu().numpy() for g in last]
@@ -924,6 +978,7 @@ def main():
     if have_gpu:
         torch.cuda.set_device(local_rank)
     dist = None
+    wd = Watchdog(rank, world, bench_timeout() if world > 1 else 1e9)
     # UC_BENCH_HELLO=1: run the N > 1 leg -- configs[4] framing, RCCL process group, async all-gather, digest check,
     # text decode -- with whatever world size there is, 1 included (what a one-GPU box can exercise of it on RCCL).
     multi = world > 1 or os.environ.get("UC_BENCH_HELLO") == "1"
@@ -941,11 +996,13 @@ def main():
             sk.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             sk.close()
+        wd.mark("rendezvous (torch.distributed.init_process_group)")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         world = dist.get_world_size()          # n_gpus printed below is what the process group reports
+        wd.mark("rendezvous done")
 
     from uchirp import synth
     mag_mean = 1000.0
@@ -980,14 +1037,26 @@ def main():
         ctl = torch.device("cpu") if rehearse else device           # where the launcher's own collectives live (gloo / RCCL)
         idt = torch.zeros(uchirp.GROUP_ID_BYTES, dtype=torch.uint8, device=ctl)
         why = ""
-        if rank == 0:
+        # Preflight on EVERY rank, agreed on before anybody enters ncclCommInitRank: a rank that cannot load RCCL, select its
+        # device or make a context would never arrive there, and the others would wait for it until the watchdog fires.
+        wd.mark("uc_group_preflight")
+        pre = 1
+        try:
+            uchirp.Group.preflight(uchirp.RX_REAL, device=local_rank, mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
+        except Exception as ex:
+            pre, why = 0, "preflight on rank %d: %s" % (rank, ex)
+        pf = torch.tensor([pre], dtype=torch.int32, device=ctl)
+        dist.all_reduce(pf, op=dist.ReduceOp.MIN)
+        pre_all = int(pf.item()) == 1
+        if rank == 0 and pre_all:
             try:
                 idt.copy_(torch.frombuffer(bytearray(uchirp.Group.unique_id()), dtype=torch.uint8))
             except Exception as ex:                      # (an all-zero id tells the others)
                 why = str(ex)
         dist.broadcast(idt, 0)
         ok = 0
-        if bool(idt.any().item()):
+        wd.mark("uc_group_create_rank (ncclCommInitRank)")
+        if pre_all and bool(idt.any().item()):
             try:
                 grp = uchirp.Group(uchirp.RX_REAL, world=world, rank=rank, unique_id=idt.cpu().numpy().tobytes(),
                                    device=local_rank, mag_mean=mag_mean, time_frame=MATCHED_TIME_FRAME)
@@ -1034,6 +1103,11 @@ def main():
         b = k % NBUF
         if grp is not None:                   # decode into this rank's slice of gathered2[b] + in-place all-gather, all in C
             if e0 is not None:
+                # the write-after-gather wait for the gather that last used this buffer goes in FRONT of e0 (the library
+                # would enqueue the same wait behind it): [e0, e1] brackets the kernel alone, and what a step costs beyond
+                # the kernel -- that wait included -- shows up in gather_ms_exposed, where it belongs
+                if k >= NBUF:
+                    grp.wait_gather(0, gathered2[b], gstream.cuda_stream)
                 e0.record(gstream)
             grp.process([frames], world * nf, [gathered2[b]], streams=[gstream.cuda_stream])
             if e1 is not None:
@@ -1077,10 +1151,13 @@ def main():
                 eng.process(frames, want_stats=False, symbols_out=sym2[0], stream=stream.cuda_stream)
             torch.cuda.synchronize()
             ramp_launches += 4
+    wd.mark("warm-up")
     for k in range(args.warmup):
         step(k)
+        wd.mark("warm-up", k)
     drain()
     sync()
+    wd.mark("barrier in front of the timed region")
     if multi:
         dist.barrier()
     sync()
@@ -1091,12 +1168,16 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(k, ev[k][0], ev[k][1])
+        wd.mark("timed region: enqueued", k)
+    wd.mark("timed region: waiting for the device (gathers included)", args.steps - 1)
     drain()
     sync()
+    wd.mark("barrier behind the timed region", args.steps - 1)
     if multi:
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    wd.mark("checks behind the timed region", args.steps - 1)
     # Sustained run behind the timed region (untimed, N = 1 only): the SMU's power figure is a moving average over about a
     # second, so the 40 ms of the timed region cannot show it; 1.5 s of back-to-back launches can.  Reports the socket power
     # and the SMU's clock over the last 0.5 s, and the rate the kernel holds meanwhile.
@@ -1250,6 +1331,11 @@ def main():
             # what a step costs beyond the kernel on the slowest rank: the gather that the next kernel does not hide,
             # launch gaps, and (N > 1) waiting for the slowest rank inside the collective
             out["gather_ms_exposed"] = float((sm - km).max()) if have_gpu else None
+            out["gather_ms_exposed_by_rank"] = [float(v) for v in (sm - km)] if have_gpu else None
+            # the world size the C group's RCCL communicator reports (n_gpus above is torch.distributed's)
+            out["rccl_world"] = int(grp.world) if grp is not None else None
+            out["scaling_note"] = ("no 1 -> 8 curve has been measured by the builder (one-GPU boxes only): the first real "
+                                   "N > 1 numbers are the driver's")
         else:
             # correctness figure of the measured run: decoded symbols vs transmitted bits.  ~23 % is EXPECTED here:
             # configs[1] runs the firmware's literal TIME_FRAME = 0.0205 s reference tables against frames that

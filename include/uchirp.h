@@ -454,6 +454,11 @@ int uc_group_unique_id(void* id, size_t cap);  /* writes UC_GROUP_ID_BYTES bytes
 int uc_group_create(const uc_config* cfg, const int32_t* devices, int n_devices, uc_group** out);
 int uc_group_create_rank(const uc_config* cfg, const void* id, int world, int rank, uc_group** out);
 void uc_group_destroy(uc_group* g);
+/* Everything uc_group_create_rank does on this rank EXCEPT the communicator's rendezvous (RCCL loads, the device answers, a
+ * context and the group's streams can be made); 0 or < 0.  A launcher calls it on every rank and agrees on the results with
+ * a collective of its own BEFORE any rank calls uc_group_create_rank -- a rank that fails before ncclCommInitRank would leave
+ * the others waiting in it (bench.py does exactly this). */
+int uc_group_preflight(const uc_config* cfg);
 int uc_group_world(const uc_group* g);        /* ranks in the communicator */
 int uc_group_local_count(const uc_group* g);  /* devices this process drives (n_devices, or 1) */
 int uc_group_first_rank(const uc_group* g);   /* rank of local device 0 (local device l is rank first + l) */
@@ -474,9 +479,14 @@ uc_ctx* uc_group_ctx(uc_group* g, int local); /* the context of local device l (
  * or make a stream of yours wait for its gather with uc_group_wait_gather().
  * Host pointers: the shard is staged through the context (synchronous copy-in), the stream is gathered in a device
  * buffer of the group and copied out; the call then blocks until gathered[l] is complete.
- * All ranks of the communicator must make the same sequence of calls (it is a collective).  A negative return may leave
- * this rank's part of the step half enqueued (the other ranks then wait in the collective): treat it as fatal for the group
- * -- uc_group_destroy and rebuild -- not as something to retry.
+ * All ranks of the communicator must make the same sequence of calls (it is a collective).  Arguments are checked for EVERY
+ * local device before anything is enqueued: a call refused for its arguments (-EINVAL: a NULL shard or buffer, a bad dtype, a
+ * state of the wrong size) has touched no stream and started no collective -- the group is as it was and stays usable.
+ * Any other negative return (a HIP or RCCL error in mid-step) may leave this rank's part of the step half enqueued (the other
+ * ranks then wait in the collective): treat it as fatal for the group -- uc_group_destroy (which never waits for a peer) and
+ * rebuild -- not as something to retry.
+ * The gather stream of every device is created with the highest stream priority the device offers: the decode kernels are
+ * persistent and own every CU, so RCCL's kernel starts when workgroups retire -- ahead of the next decode launch's.
  */
 int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, size_t n_frames_total,
                            size_t stride_elems, uint8_t* const* gathered, void* const* hip_streams);

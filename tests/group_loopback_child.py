@@ -37,6 +37,9 @@ def run(variant, kw, flat, n_frames, stride, halo, world, steps=7, dtype=uchirp.
         keep.append(mine)
         ptrs.append(mine.data_ptr() + 4 * halo)
     bufs = [[torch.full((n_frames,), 0x77, dtype=torch.uint8, device=dev) for _ in range(world)] for _ in range(3)]
+    # the shard copies and the fills above ran on torch's stream; the group launches on non-blocking streams of its own,
+    # which do not wait for it: everything must have landed before the first step reads a shard or writes a slice
+    torch.cuda.synchronize()
     for k in range(steps):
         g.process(ptrs, n_frames, bufs[k % 3], stride=stride, dtype=dtype)
     g.synchronize()
@@ -63,6 +66,55 @@ for world in (2, 3, 8):
         if nf >= 117:
             texts = synth.decode_hello(sym.cpu().numpy(), 12)
             assert texts and all(t == "Hello World!" for t in texts)
+# ---- a call refused for its arguments has enqueued NOTHING: one local device of several gets a NULL shard / a NULL buffer --
+# the call returns < 0 before any stream is touched and before any collective starts, the group stays usable (the next step
+# gives the right stream) and uc_group_destroy returns without waiting for anybody
+frames, _ = synth.device_hello_frames(0, 117 * 8, dev, seed=5, snr_db=-10.0)
+nf = 117 * 8
+eng = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0, time_frame=N / 78125.0)
+want, _ = eng.process(frames.reshape(-1), n_frames=nf, want_stats=False)
+eng.close()
+for world in (2, 3):
+    g = uchirp.Group(uchirp.RX_REAL, devices=[0] * world, mag_mean=1000.0, time_frame=N / 78125.0)
+    shards = []
+    for r in range(world):
+        first, count = uchirp.partition(nf, world, r)
+        shards.append(frames.reshape(-1)[first * N:(first + count) * N].clone())
+    outs = [torch.zeros(nf, dtype=torch.uint8, device=dev) for _ in range(world)]
+    torch.cuda.synchronize()
+    for bad in range(world):
+        for what in ("frames", "gathered", "dtype"):
+            p_ = [x.data_ptr() for x in shards]
+            o_ = list(outs)
+            kw = {}
+            if what == "frames":
+                p_[bad] = 0
+            elif what == "gathered":
+                o_[bad] = 0
+            else:
+                kw["dtype"] = 7
+            try:
+                g.process(p_, nf, o_, **kw)
+                raise SystemExit("a NULL %s on local device %d of %d was accepted" % (what, bad, world))
+            except uchirp.UchirpError as ex:
+                assert "NULL" in str(ex) or "dtype" in str(ex), ex
+        g.process([x.data_ptr() for x in shards], nf, outs)          # the group is as it was
+        g.synchronize()
+        assert all(torch.equal(o, want) for o in outs), (world, bad)
+        checks += 1
+    # a refused receive: one state missing
+    try:
+        g.receive_streams([shards[0]] * world, world, N, [torch.zeros((world, 8), dtype=torch.uint8, device=dev)] * world, 8,
+                          states=[None] * world)
+        raise SystemExit("NULL states accepted")
+    except (uchirp.UchirpError, AttributeError, TypeError):
+        pass
+    g.process([x.data_ptr() for x in shards], nf, outs)
+    g.synchronize()
+    assert all(torch.equal(o, want) for o in outs)
+    g.close()                                                        # returns: nothing is waiting for a peer
+    checks += 1
+
 # overlapping FIFO reads (stride 256): neighbouring shards overlap by n - 256 samples
 flat = synth.device_frames(40, dev, seed=9, snr_db=-3.0)[0].reshape(-1)
 nfr = (flat.numel() - N) // 256 + 1

@@ -108,3 +108,41 @@ def test_group_entry_points_reject_bad_arguments_without_a_gpu():
     dev = (C.c_int32 * 2)(0, 0)
     assert L.uc_group_create(C.byref(cfg), dev, 0, C.byref(h)) == EINVAL and not h.value          # no devices
     assert L.uc_group_create(C.byref(cfg), dev, 2, C.byref(h)) == EINVAL and not h.value          # one device named twice
+
+
+def test_rows_divisor_is_exact_for_every_dividend_below_2_to_31(tmp_path):
+    """uc::rows_divisor (csrc/uc_kernels.hpp): the multiply-high division the band kernel's ROWS build (frame -> stream, block)
+    and the multi-stream DFSDM kernel (tile -> stream, tile) do per unit of work; tests/cpp/divisor_check.cpp sweeps 4110
+    divisors around every multiple boundary."""
+    exe = str(tmp_path / "divisor_check")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "cpp", "divisor_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "rows_divisor ok" in out.stdout, out.stdout[-2000:]
+
+
+def test_bench_watchdog_ends_a_hung_rank_loudly():
+    """bench.py's Watchdog: a rank that makes no progress past UC_BENCH_TIMEOUT prints which rank, which phase, which step --
+    and exits with status 4 (the launcher then ends the others); a rank that finishes in time is left alone."""
+    import sys
+    code = ("import sys, time; sys.path.insert(0, %r); import bench\n"
+            "wd = bench.Watchdog(3, 8, bench.bench_timeout())\n"
+            "wd.mark('timed region: enqueued', 17)\n"
+            "time.sleep(float(sys.argv[1]))\n"
+            "wd.stop(); print('finished')\n") % ROOT
+    hung = subprocess.run([sys.executable, "-c", code, "30"], env=dict(os.environ, UC_BENCH_TIMEOUT="1"), capture_output=True,
+                          text=True, timeout=120)
+    assert hung.returncode == 4, (hung.returncode, hung.stderr[-500:])
+    assert "rank 3 of 8" in hung.stderr and "timed region: enqueued" in hung.stderr and "step 17" in hung.stderr
+    assert "finished" not in hung.stdout
+    fine = subprocess.run([sys.executable, "-c", code, "0.1"], env=dict(os.environ, UC_BENCH_TIMEOUT="30"), capture_output=True,
+                          text=True, timeout=120)
+    assert fine.returncode == 0 and "finished" in fine.stdout and "WATCHDOG" not in fine.stderr
+
+
+def test_group_entry_points_refuse_null_arguments_without_a_gpu():
+    """uc_group_preflight / uc_dfsdm_sinc5_streams: argument checks that come before any device call."""
+    import ctypes as C
+    L = uchirp.lib()
+    assert L.uc_group_preflight(None) < 0 and "NULL" in L.uc_last_error().decode()
+    assert L.uc_dfsdm_sinc5_streams(None, None, 1, 1, 0, None, None, 0, None) < 0

@@ -309,7 +309,22 @@ static int group_locals(uc_group* g, const uc_config* cfg, const int32_t* device
     if (rc) return rc;
     hipError_t e = hipSetDevice(L.device);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.compute, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&L.gather, hipStreamNonBlocking);
+    // The gather stream gets the HIGHEST priority the device offers: the decode kernels are persistent and fill every CU, so
+    // RCCL's copy kernel is dispatched only as workgroups retire -- with a priority above theirs it is the first thing
+    // the dispatcher places when that happens, instead of competing with the next decode launch's workgroups for the slots.
+    // (1 MiB per GPU and step: latency-bound on xGMI; what matters is when the kernel STARTS.)
+    if (e == hipSuccess) {
+      int least = 0, greatest = 0;
+      if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) {
+        (void)hipGetLastError();
+        least = greatest = 0;
+      }
+      e = hipStreamCreateWithPriority(&L.gather, hipStreamNonBlocking, greatest);
+      if (e != hipSuccess) {  // (no priorities on this device / runtime: a plain stream does the same work)
+        (void)hipGetLastError();
+        e = hipStreamCreateWithFlags(&L.gather, hipStreamNonBlocking);
+      }
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&L.kernel_done, hipEventDisableTiming);
     for (int k = 0; e == hipSuccess && k < kHazardRing; k++) e = hipEventCreateWithFlags(&L.hz_ev[k], hipEventDisableTiming);
     if (e != hipSuccess) return hip_fail(e, "uc_group: stream / event creation");
@@ -379,6 +394,27 @@ int uc_group_create_rank(const uc_config* cfg, const void* id, int world, int ra
   return 0;
 }
 
+// Everything uc_group_create_rank does on this rank EXCEPT entering the communicator's rendezvous: RCCL can be loaded, the
+// device can be selected, a context and the group's streams can be made.  A launcher runs it on every rank and agrees on the
+// results (an all-reduce of its own) BEFORE any rank calls uc_group_create_rank: a rank that would fail there never enters
+// ncclCommInitRank, and the ranks that did would wait for it for ever.
+int uc_group_preflight(const uc_config* cfg) {
+  if (!cfg) return fail(-EINVAL, "uc_group_preflight: NULL config");
+  int rc = load_rccl();
+  if (rc) return rc;
+  int version = 0;
+  const ncclResult_t r = g_rccl.GetVersion(&version);
+  if (r != ncclSuccess) return nccl_fail(r, "ncclGetVersion");
+  uc_group* g = new (std::nothrow) uc_group();
+  if (!g) return fail(-ENOMEM, "uc_group_preflight: out of memory");
+  g->world = 1;
+  g->first_rank = 0;
+  const int32_t dev = cfg->device;
+  rc = group_locals(g, cfg, &dev, 1);
+  uc_group_destroy(g);
+  return rc;
+}
+
 int uc_group_world(const uc_group* g) { return g ? g->world : fail(-EINVAL, "uc_group_world: NULL group"); }
 int uc_group_local_count(const uc_group* g) { return g ? (int)g->loc.size() : fail(-EINVAL, "uc_group_local_count: NULL group"); }
 int uc_group_first_rank(const uc_group* g) { return g ? g->first_rank : fail(-EINVAL, "uc_group_first_rank: NULL group"); }
@@ -399,6 +435,16 @@ int uc_group_process_batch(uc_group* g, const void* const* frames, int dtype, si
   const bool even = n_frames_total % (size_t)g->world == 0;
   std::vector<uint8_t*> dst((size_t)nl, nullptr);
   bool any_host = false;
+
+  // 0. every argument of every local device is looked at BEFORE anything is enqueued: a refused call (< 0 from here) has
+  //    touched no stream and started no collective -- the group is as it was, the peers are not left waiting for this rank
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return fail(-EINVAL, "uc_group_process_batch: bad dtype %d", dtype);
+  for (int l = 0; l < nl; l++) {
+    size_t first = 0, count = 0;
+    uc_partition(n_frames_total, g->world, g->first_rank + l, &first, &count);
+    if (!gathered[l]) return fail(-EINVAL, "uc_group_process_batch: gathered[%d] is NULL", l);
+    if (count && !frames[l]) return fail(-EINVAL, "uc_group_process_batch: frames[%d] is NULL", l);
+  }
 
   // 1. every local device decodes its shard into its slice of the gathered stream
   for (int l = 0; l < nl; l++) {
@@ -466,6 +512,23 @@ static int group_receive(uc_group* g, uc_rx_state* const* states, const void* co
   const size_t text_bytes = n_streams_total * text_cap, cnt_bytes = n_streams_total * sizeof(uint32_t);
   std::vector<uint8_t*> dtext((size_t)nl, nullptr), dcnt((size_t)nl, nullptr);
   bool any_host = false;
+
+  // every argument of every local device first: a refused call has enqueued nothing (see uc_group_process_batch)
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32 && dtype != UC_DTYPE_PDM) return fail(-EINVAL, "%s: bad dtype %d", who, dtype);
+  if (n_samples >= (size_t)2048 && !samples) return fail(-EINVAL, "%s: samples is NULL", who);
+  for (int l = 0; l < nl; l++) {
+    size_t first = 0, count = 0;
+    uc_partition(n_streams_total, g->world, g->first_rank + l, &first, &count);
+    if (!text[l]) return fail(-EINVAL, "%s: text[%d] is NULL", who, l);
+    if (n_text && !n_text[l]) return fail(-EINVAL, "%s: n_text[%d] is NULL", who, l);
+    if (count && n_samples >= (size_t)2048 && !samples[l]) return fail(-EINVAL, "%s: samples[%d] is NULL", who, l);
+    if (states) {
+      if (!states[l]) return fail(-EINVAL, "%s: states[%d] is NULL", who, l);
+      if (uc_rx_state_streams(states[l]) != count)
+        return fail(-EINVAL, "%s: states[%d] holds %zu streams, rank %d owns %zu of %zu", who, l, uc_rx_state_streams(states[l]),
+                    g->first_rank + l, count, n_streams_total);
+    }
+  }
 
   for (int l = 0; l < nl; l++) {
     Local& L = g->loc[(size_t)l];
@@ -575,6 +638,16 @@ int uc_group_process_stream(uc_group* g, const void* const* samples, int dtype, 
   const size_t peak_bytes = n_blocks * sizeof(uc_peak);
   std::vector<uint8_t*> dst((size_t)nl, nullptr);
   bool any_host = false;
+  // every argument of every local device first: a refused call has enqueued nothing (see uc_group_process_batch)
+  if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32) return fail(-EINVAL, "uc_group_process_stream: bad dtype %d", dtype);
+  for (int l = 0; l < nl; l++) {
+    size_t first_sample = 0, n_shard = 0, first_out = 0, n_out = 0;
+    if (const int rc = uc_stream_span(g->loc[(size_t)l].ctx, n_samples_total, g->world, g->first_rank + l, &first_sample, &n_shard,
+                                      &first_out, &n_out))
+      return rc;
+    if (!peaks[l]) return fail(-EINVAL, "uc_group_process_stream: peaks[%d] is NULL", l);
+    if (n_out && !samples[l]) return fail(-EINVAL, "uc_group_process_stream: samples[%d] is NULL", l);
+  }
   for (int l = 0; l < nl; l++) {
     Local& L = g->loc[(size_t)l];
     size_t first_sample = 0, n_shard = 0, first_out = 0, n_out = 0;

@@ -39,7 +39,7 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters",
            "uc_rx_state_create", "uc_rx_state_reset", "uc_rx_state_destroy", "uc_receive_streams_next",
            "uc_rx_state_streams", "uc_group_receive_streams", "uc_group_receive_streams_next", "uc_group_process_stream",
-           "uc_dfsdm_sinc5_streams"]
+           "uc_dfsdm_sinc5_streams", "uc_group_preflight"]
 GROUP_ID_BYTES = 128
 
 
@@ -135,6 +135,7 @@ def lib():
     L.uc_group_create_rank.argtypes = [C.POINTER(Config), C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
     L.uc_group_destroy.argtypes = [C.c_void_p]
     L.uc_group_destroy.restype = None
+    L.uc_group_preflight.argtypes = [C.POINTER(Config)]
     for fn in (L.uc_group_world, L.uc_group_local_count, L.uc_group_first_rank, L.uc_group_synchronize):
         fn.argtypes = [C.c_void_p]
     L.uc_group_ctx.argtypes = [C.c_void_p, C.c_int]
@@ -658,6 +659,13 @@ class Group:
         self.n_local = lib().uc_group_local_count(h)
         self.first_rank = lib().uc_group_first_rank(h)
         self.n = int(self.cfg.n)
+
+    @staticmethod
+    def preflight(variant=RX_REAL, device=0, **over):
+        """uc_group_preflight: everything uc_group_create_rank does on this rank except the communicator's rendezvous; raises
+        UchirpError where the real call would fail before it.  Agree on the result across ranks BEFORE anybody builds a group."""
+        cfg = default_config(variant, device=int(device), **over)
+        _check(lib().uc_group_preflight(C.byref(cfg)), "uc_group_preflight")
 
     @staticmethod
     def unique_id():
