@@ -1150,7 +1150,9 @@ int uco_process_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samp
 /* receiver/Src/dfsdm.c:59-61 (SINC5, Oversampling 32, IntOversampling 1), :69 (clock divider 32:
  * 80 MHz / 32 = 2.5 MHz bit clock -> 78125 words/s), :78 (RightBitShift 2); the 24-bit result sits
  * in bits 31:8 of the data register (agent/ *.raw values are multiples of 256).
- * Hogenauer form: five integrators at the bit rate, decimate, five combs, int64 (no wrap needed).
+ * Hogenauer form: five integrators at the bit rate, decimate, five combs, in MODULAR 64-bit arithmetic: on a constant input the
+ * fifth integrator grows like t^5 / 120 and passes 2^63 after ~16 k bits -- as in the hardware the combs undo the wrap exactly
+ * (the true result fits 27 bits), so the sums are uint64_t (well-defined wrap; int64_t overflowed: found by tools/sanitize.sh).
  * Bit t of the stream is bit (t & 31) of word t >> 5 (LSB first), 1 -> +1, 0 -> -1.
  * The first 4 words only fill the filter: out[q] is the conversion that ends with word q + 4.
  * The hardware block itself is not in the reference (it is silicon): UNPINNED by the reference;
@@ -1158,19 +1160,20 @@ int uco_process_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samp
 int uco_dfsdm_sinc5(const uint32_t* pdm, size_t n_words, int32_t* out) {
   if (n_words <= 4) return 0;
   if (!pdm || !out) return -EINVAL;
-  int64_t i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
-  int64_t d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
+  uint64_t i1 = 0, i2 = 0, i3 = 0, i4 = 0, i5 = 0;
+  uint64_t d1 = 0, d2 = 0, d3 = 0, d4 = 0, d5 = 0;
   for (size_t w = 0; w < n_words; w++) {
     uint32_t bits = pdm[w];
     for (int b = 0; b < 32; b++) {
-      int64_t sgn = ((bits >> b) & 1u) ? 1 : -1;
+      const uint64_t sgn = ((bits >> b) & 1u) ? (uint64_t)1 : ~(uint64_t)0; /* +1 / -1 mod 2^64 */
       i1 += sgn; i2 += i1; i3 += i2; i4 += i3; i5 += i4;
     }
-    int64_t c1 = i5 - d1; d1 = i5;
-    int64_t c2 = c1 - d2; d2 = c1;
-    int64_t c3 = c2 - d3; d3 = c2;
-    int64_t c4 = c3 - d4; d4 = c3;
-    int64_t c5 = c4 - d5; d5 = c4;
+    uint64_t u1 = i5 - d1; d1 = i5;
+    uint64_t u2 = u1 - d2; d2 = u1;
+    uint64_t u3 = u2 - d3; d3 = u2;
+    uint64_t u4 = u3 - d4; d4 = u3;
+    uint64_t u5 = u4 - d5; d5 = u4;
+    const int64_t c5 = (int64_t)u5; /* |true value| <= 2^25 once the filter is full: the low 64 bits ARE the value */
     if (w >= 4) {
       /* floor shift; the 24-bit register clips the single value +2^23 (all-ones input) */
       int64_t v = c5 >> 2;

@@ -1,0 +1,47 @@
+#!/bin/bash
+# Host-side AddressSanitizer + UndefinedBehaviorSanitizer pass (build container, no GPU; GPU sanitizers are not available on
+# this pool and are not attempted).  What is instrumented: every host translation unit of libuchirp.so -- csrc/uc_api.cpp
+# (staging buffers, counter rings, graph slots, receive paths: argument checks and everything in front of the first device
+# call), csrc/uc_tables.cpp (reference tables, sinc^5 byte tables), csrc/uc_group.cpp (partition / span arithmetic, argument
+# checks, RCCL loading) -- the oracle, the loop-back RCCL stand-in, and a C++ harness (tests/cpp/san_host.cpp) that drives
+# include/uchirp_mainloop.hpp with a CPU dsp(), the table builders and the span functions over random and edge inputs.
+# The kernels' objects are linked in as they are (device code cannot be sanitized here).
+#   bash tools/sanitize.sh [log=profiles/rXX_sanitize.txt]      (also: make -C ultrasonic-communication_amd sanitize)
+# Exit status 0 = every step ran clean (any sanitizer report aborts the step: halt_on_error).
+set -e -o pipefail
+cd "$(dirname "$0")/.."
+ROOT="$PWD"
+LOG="${1:-$ROOT/gpurun_out/sanitize.txt}"
+mkdir -p "$(dirname "$LOG")"
+B="$ROOT/build/san"
+mkdir -p "$B"
+LLVM=/opt/rocm/lib/llvm/bin
+RT="$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)"
+SAN="-fsanitize=address,undefined -fno-sanitize-recover=all -fno-omit-frame-pointer -g -O1 -shared-libsan"
+PKG="$ROOT/ultrasonic-communication_amd"
+{
+echo "== host-side ASan + UBSan pass, $(date -u +%Y-%m-%dT%H:%MZ), $($LLVM/clang --version | head -1)"
+echo "== flags: $SAN"
+make -C "$PKG" libuchirp.so > /dev/null            # the kernel objects (not instrumented)
+for f in uc_api uc_tables uc_group; do
+  /opt/rocm/bin/hipcc -std=c++17 -fPIC -Wall -Wextra -Wno-unused-parameter -ffp-contract=off -Wno-option-ignored $SAN -c "$PKG/csrc/$f.cpp" -o "$B/$f.o"
+done
+KOBJ="$(ls "$PKG"/csrc/*_kernel.o "$PKG"/csrc/*_kernel.clk.o)"
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $SAN -o "$B/libuchirp.so" "$B"/uc_api.o "$B"/uc_tables.o "$B"/uc_group.o $KOBJ -ldl
+$LLVM/clang -std=gnu11 -fPIC -Wall -Wextra -ffp-contract=off -march=x86-64-v3 $SAN -shared -o "$B/libuc_oracle.so" "$ROOT/oracle/uc_oracle.c" -lm
+$LLVM/clang++ -std=c++17 -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $SAN -shared -o "$B/libloopback_rccl.so" \
+   "$ROOT/tests/stubs/loopback_rccl.cpp" -L/opt/rocm/lib -lamdhip64 -lrt
+$LLVM/clang++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" $SAN -o "$B/san_host" \
+   "$ROOT/tests/cpp/san_host.cpp" "$PKG/csrc/uc_tables.cpp" -L"$B" -luchirp -Wl,-rpath,"$B" -Wl,-rpath,"$(dirname "$RT")"
+echo "== built: $(ls "$B" | tr '\n' ' ')"
+export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1:strict_string_checks=1:detect_stack_use_after_return=1
+export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
+echo "== 1. C++ harness (mainloop header with a CPU dsp(), table builders, partition / span functions, C-ABI argument checks)"
+UC_TUNING=1 UC_RCCL_LIB="$B/libloopback_rccl.so" "$B/san_host"
+echo "== 2. the CPU test files against the instrumented libraries (UCHIRP_LIB / UCO_LIB), ASan runtime preloaded into python"
+LD_PRELOAD="$RT" UCHIRP_LIB="$B/libuchirp.so" UCO_LIB="$B/libuc_oracle.so"\
+  python -m pytest "$ROOT/tests/test_group_cpu.py" "$ROOT/tests/test_oracle_golden.py" "$ROOT/tests/test_abi.py" \
+  "$ROOT/tests/test_shard_gloo.py" "$ROOT/tests/test_dfsdm.py" -q -m "not gpu" -p no:cacheprovider -x 2>&1 | grep -v "^  File" | tail -25
+echo "== clean: no AddressSanitizer / UndefinedBehaviorSanitizer report in any step"
+} 2>&1 | tee "$LOG"
+grep -q "^== clean" "$LOG"
