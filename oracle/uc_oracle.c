@@ -1238,13 +1238,24 @@ static float rx_symbol_snr(rx_env* e, uint32_t pos, hist_lite* h, int updown) {
 
 /* resync(): main.c:243-273.  Q8 fixed: an out-of-range neighbour is not evaluated
  * (the firmware evaluates it first and checks the bound afterwards). */
-static void rx_resync(rx_env* e, float snr, hist_lite* hist, uint32_t offset, uint32_t* sync_position, int updown) {
+/* how close two compared quantities are, relative to the larger one (the decision margins of uco_receive_stream_diag) */
+static float rel_gap(float a, float b) {
+  const float m = fmaxf(fmaxf(fabsf(a), fabsf(b)), 1e-30f);
+  return fabsf(a - b) / m;
+}
+
+static void rx_resync(rx_env* e, float snr, hist_lite* hist, uint32_t offset, uint32_t* sync_position, int updown, float* margin) {
   const uint32_t n = e->c->n;
   int32_t pos_l = (int32_t)*sync_position - (int32_t)offset;
   int32_t pos_r = (int32_t)*sync_position + (int32_t)offset;
   float snr_l = -INFINITY, snr_r = -INFINITY;
   if (pos_l >= 0) snr_l = rx_symbol_snr(e, (uint32_t)pos_l, &hist[2], updown);
   if (pos_r <= (int32_t)(2 * n)) snr_r = rx_symbol_snr(e, (uint32_t)pos_r, &hist[3], updown);
+  if (margin) { /* the three compares below */
+    if (isfinite(snr_l)) *margin = fminf(*margin, rel_gap(snr, snr_l));
+    if (isfinite(snr_r)) *margin = fminf(*margin, rel_gap(snr, snr_r));
+    if (isfinite(snr_l) && isfinite(snr_r)) *margin = fminf(*margin, rel_gap(snr_l, snr_r));
+  }
   if ((snr > snr_l) && (snr > snr_r)) {
     /* keep */
   } else {
@@ -1265,6 +1276,17 @@ int uco_receive_stream(uco_ctx* c, const void* samples, int dtype, size_t n_samp
  * `if (!new_pcm_data && ...)` (receiver/Src/main.c:661) skips the block: no FIFO shift, no pass of the switch. */
 int uco_receive_stream_isr(uco_ctx* c, const void* samples, int dtype, size_t n_samples, const uint8_t* busy, int precision,
                            char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace) {
+  return uco_receive_stream_diag(c, samples, dtype, n_samples, busy, precision, text, text_cap, trace, trace_cap, n_trace, NULL);
+}
+
+/* The same loop; margin (nullable, trace_cap floats) receives, per processed block, how close the block's CLOSEST decision
+ * was to going the other way, as a relative gap (1e30: the block took no decision): the block maximum against
+ * (1 + SNR_THRESHOLD) x mag_mean and the two largest of the eight acquisition maxima (main.c:461-475); snr_up / snr_down
+ * against the threshold and against each other (main.c:493-505, 521-531); resync()'s three compares (main.c:252-271).
+ * Test infrastructure for the many-stream fuzz: a float32 receiver may legitimately differ from this float64 one where
+ * -- and only where -- such a gap is within round-off. */
+int uco_receive_stream_diag(uco_ctx* c, const void* samples, int dtype, size_t n_samples, const uint8_t* busy, int precision,
+                            char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace, float* margin) {
   if (!c || (!samples && n_samples) || !text || text_cap == 0) return -EINVAL;
   if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX) return -ENOTSUP;
   const uint32_t n = c->n;
@@ -1303,6 +1325,7 @@ int uco_receive_stream_isr(uco_ctx* c, const void* samples, int dtype, size_t n_
     const int prev_state = state;
     int bit = -1;
     snr_up = snr_down = 0.0f;
+    float mg = 1e30f;
     switch (state) {
       case UC_STATE_IDLE: {
         sync_cnt = 0;
@@ -1327,6 +1350,12 @@ int uco_receive_stream_isr(uco_ctx* c, const void* samples, int dtype, size_t n_
           }
           mag_stat[0] = mag_max_max;
           snr = (mag_max_max - mag_mean) / mag_mean;
+          {
+            float second = 0.0f;
+            for (int i = 0; i < 8; i++)
+              if ((uint32_t)i != max_idx && history[i].mag_max > second) second = history[i].mag_max;
+            mg = fminf(rel_gap(mag_max_max, (1.0f + thr) * mag_mean), rel_gap(mag_max_max, second));
+          }
           if (snr >= thr) {
             state = UC_STATE_SYNCHRONIZING;
             if (++sync_cnt >= 3) {
@@ -1341,12 +1370,13 @@ int uco_receive_stream_isr(uco_ctx* c, const void* samples, int dtype, size_t n_
       case UC_STATE_SYNCHRONIZED: /* main.c:491-510 */
         snr_up = rx_symbol_snr(&e, sync_position, &history[0], UC_UP_CHIRP);
         snr_down = rx_symbol_snr(&e, sync_position, &history[1], UC_DOWN_CHIRP);
+        mg = fminf(fminf(rel_gap(snr_up, thr), rel_gap(snr_down, thr)), rel_gap(snr_up, snr_down));
         if ((snr_up >= thr) || (snr_down >= thr)) {
           if (snr_down > snr_up) {
-            rx_resync(&e, snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
+            rx_resync(&e, snr_down, history, offset, &sync_position, UC_DOWN_CHIRP, &mg);
             state = UC_STATE_DATA_RECEIVING;
           } else {
-            rx_resync(&e, snr_up, history, offset, &sync_position, UC_UP_CHIRP);
+            rx_resync(&e, snr_up, history, offset, &sync_position, UC_UP_CHIRP, &mg);
           }
         } else {
           state = UC_STATE_IDLE;
@@ -1355,15 +1385,16 @@ int uco_receive_stream_isr(uco_ctx* c, const void* samples, int dtype, size_t n_
       case UC_STATE_DATA_RECEIVING: /* main.c:512-550 */
         snr_up = rx_symbol_snr(&e, sync_position, &history[0], UC_UP_CHIRP);
         snr_down = rx_symbol_snr(&e, sync_position, &history[1], UC_DOWN_CHIRP);
+        mg = fminf(fminf(rel_gap(snr_up, thr), rel_gap(snr_down, thr)), rel_gap(snr_up, snr_down));
         if ((snr_up >= thr) || (snr_down >= thr)) {
           if (snr_down > snr_up) {
             bit = 0;
             msg = (unsigned char)((msg << 1) + 0);
-            rx_resync(&e, snr_down, history, offset, &sync_position, UC_DOWN_CHIRP);
+            rx_resync(&e, snr_down, history, offset, &sync_position, UC_DOWN_CHIRP, &mg);
           } else {
             bit = 1;
             msg = (unsigned char)((msg << 1) + 1);
-            rx_resync(&e, snr_up, history, offset, &sync_position, UC_UP_CHIRP);
+            rx_resync(&e, snr_up, history, offset, &sync_position, UC_UP_CHIRP, &mg);
           }
           if (++msg_cnt >= 8) {
             if (ntext + 1 < text_cap) text[ntext++] = (char)msg;
@@ -1388,6 +1419,7 @@ int uco_receive_stream_isr(uco_ctx* c, const void* samples, int dtype, size_t n_
       ev->reserved = 0;
       ev->snr_up = snr_up;
       ev->snr_down = snr_down;
+      if (margin) margin[nt] = mg;
     }
     nt++;
   }

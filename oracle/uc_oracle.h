@@ -72,6 +72,9 @@ int uco_receive_stream(uco_ctx* ctx, const void* samples, int dtype, size_t n_sa
 /* ... with the ISR's drop-on-busy (main.c:661): same outputs as uc_receive_stream_isr */
 int uco_receive_stream_isr(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples, const uint8_t* busy, int precision,
                            char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace);
+/* the same, plus per processed block the relative gap of the block's closest decision (uc_oracle.c); margin: trace_cap floats, nullable */
+int uco_receive_stream_diag(uco_ctx* ctx, const void* samples, int dtype, size_t n_samples, const uint8_t* busy, int precision,
+                            char* text, size_t text_cap, uc_rx_event* trace, size_t trace_cap, size_t* n_trace, float* margin);
 
 /* UC_STREAM (BASELINE config 4): same outputs as uc_stream_geometry / uc_process_stream,
  * evaluated as the direct float64 time-domain sums of the definition in include/uchirp.h

@@ -68,6 +68,7 @@ def lib():
                                          C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
         L.uco_receive_stream_isr.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_int, C.c_char_p,
                                              C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]
+        L.uco_receive_stream_diag.argtypes = L.uco_receive_stream_isr.argtypes + [C.c_void_p]
         L.uco_stream_geometry.argtypes = [C.c_void_p, C.c_size_t] + [C.POINTER(C.c_size_t)] * 4
         L.uco_process_stream.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_size_t, C.c_void_p, C.c_void_p, C.c_int]
         L.uco_dfsdm_sinc5.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p]
@@ -179,9 +180,11 @@ class Oracle:
             raise RuntimeError("uco_process_batch rc=%d" % rc)
         return sym, stats
 
-    def receive(self, samples, precision=F64, busy=None):
+    def receive(self, samples, precision=F64, busy=None, margins=False):
         """The receiver's main loop over a recorded stream -> (text, trace[RX_EVENT_DTYPE]).
-        busy: optional per-block flags: the ISR drops those blocks (main.c:661)."""
+        busy: optional per-block flags: the ISR drops those blocks (main.c:661).
+        margins=True: -> (text, trace, margin float32[len(trace)]): per processed block the relative gap of the block's closest
+        decision (uco_receive_stream_diag); 1e30 where the block decided nothing."""
         a = np.ascontiguousarray(samples).reshape(-1)
         if a.dtype not in (np.int32, np.float32):
             raise TypeError("samples must be int32 or float32")
@@ -191,10 +194,13 @@ class Oracle:
         text = C.create_string_buffer(4096)
         nt = C.c_size_t(0)
         bz = None if busy is None else np.ascontiguousarray(busy, np.uint8).reshape(-1)
-        rc = lib().uco_receive_stream_isr(self._h, _ptr(a), dt, a.size, _ptr(bz) if bz is not None else None, precision, text,
-                                          4096, _ptr(trace), nb, C.byref(nt))
+        mg = np.full(max(nb, 1), 1e30, np.float32)
+        rc = lib().uco_receive_stream_diag(self._h, _ptr(a), dt, a.size, _ptr(bz) if bz is not None else None, precision, text,
+                                           4096, _ptr(trace), nb, C.byref(nt), _ptr(mg))
         if rc < 0:
             raise RuntimeError("uco_receive_stream rc=%d" % rc)
+        if margins:
+            return text.raw[:rc].decode("latin-1"), trace[:nt.value], mg[:nt.value]
         return text.raw[:rc].decode("latin-1"), trace[:nt.value]    # (the returned count: a decoded byte may be 0)
 
     def stream_geometry(self, n_samples):

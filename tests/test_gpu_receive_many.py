@@ -100,6 +100,20 @@ def test_many_streams_equal_one_stream_at_a_time(uchirp, variant):
         uchirp.Engine(uchirp.COMPRESS).receive_many(x[:2])
 
 
+SOFT_GAP = 2e-3     # a decision whose two sides are this close (relative) in the ORACLE may legitimately go the other way in float32
+
+
+def classify_divergence(tr_g, tr_o, margin_o):
+    """First block where the traces part, judged by the oracle's OWN decision margin there (uco_receive_stream_diag): every
+    decision of the block -- the acquisition maximum against (1 + SNR_THRESHOLD) x mag_mean and against the runner-up of the
+    eight maxima, snr_up / snr_down against the threshold and each other, resync()'s compares -- -> ("soft" | "bad", block, gap)."""
+    n = min(len(tr_g), len(tr_o))
+    d = [i for i in range(n) if any(tr_g[f][i] != tr_o[f][i] for f in FIELDS)]
+    i = d[0] if d else n
+    gap = float(margin_o[i]) if i < len(margin_o) else float("inf")
+    return ("soft" if gap < SOFT_GAP else "bad"), i, gap
+
+
 def test_a_thousand_random_transmissions_with_dropped_blocks_against_the_oracle(uchirp):
     x, busy, msgs = _transmissions(1000, seed=5, blocks=150)
     variants = np.random.default_rng(6).integers(0, 2, size=1000)        # 0 RX_REAL, 1 SYNC_CPLX
@@ -109,30 +123,26 @@ def test_a_thousand_random_transmissions_with_dropped_blocks_against_the_oracle(
         e, o = uchirp.Engine(variant), uco.Oracle(variant)
         texts, traces = e.receive_many(x[idx], busy=busy[idx])
         for k, s in enumerate(idx):
-            text_o, tr_o = o.receive(x[s], precision=uco.F64, busy=busy[s])
+            text_o, tr_o, mg_o = o.receive(x[s], precision=uco.F64, busy=busy[s], margins=True)
             tr_g = traces[k]
             decoded += int(msgs[s] in text_o)
             same = texts[k] == text_o and len(tr_g) == len(tr_o) and all(np.array_equal(tr_g[f], tr_o[f]) for f in FIELDS)
             if same:
                 continue
-            # a decision within float32 round-off of a threshold / of a tie may differ: judge the first diverging block by
-            # the ORACLE's snrs there
-            n = min(len(tr_g), len(tr_o))
-            d = [i for i in range(n) if any(tr_g[f][i] != tr_o[f][i] for f in FIELDS)]
-            i = d[0] if d else n
-            su, sd = (float(tr_o["snr_up"][i]), float(tr_o["snr_down"][i])) if i < n else (0.0, 0.0)
-            near = min(abs(su - 2.0), abs(sd - 2.0), abs(su - sd)) < 2e-3 * max(1.0, abs(su), abs(sd))
-            # (acquisition blocks carry no snr in the trace: there the compared quantity is the block maximum against
-            # 3 x mag_mean; those divergences show as state changes in IDLE / SYNCHRONIZING)
-            acq = i < n and tr_o["state_before"][i] < 2
-            if near or acq:
+            # a decision within float32 round-off of going the other way may differ: the first diverging block is judged by
+            # the ORACLE's own margin there -- acquisition blocks included (the block maximum against 3 x mag_mean, the two
+            # largest of the eight maxima), not waved through
+            kind, i, gap = classify_divergence(tr_g, tr_o, mg_o)
+            if kind == "soft":
                 soft += 1
+                print("soft: stream %d variant %d block %d: the oracle's closest decision there had a relative gap of %.2e" % (s, variant, i, gap))
             else:
                 bad += 1
-                print("FAIL stream %d variant %d block %d snr %.5f / %.5f: %r vs %r" % (s, variant, i, su, sd, text_o, texts[k]))
+                print("FAIL stream %d variant %d block %d gap %.3e: %r vs %r" % (s, variant, i, gap, text_o, texts[k]))
         e.close()
-    print("1000 transmissions: %d failures, %d near-threshold divergences, oracle decoded the text in %d" % (bad, soft, decoded))
-    assert bad == 0 and soft <= 10 and decoded >= 300
+    print("1000 transmissions: %d failures, %d divergences at decisions within %.0e of a tie in the oracle, oracle decoded the text in %d"
+          % (bad, soft, SOFT_GAP, decoded))
+    assert bad == 0 and soft <= 3 and decoded >= 300
 
 
 @pytest.mark.parametrize("variant", [uco.SYNC_CPLX, uco.RX_REAL])
