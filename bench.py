@@ -569,8 +569,10 @@ def hello_world1(args, device, torch, mag_mean):
 def receive_leg(args, device, torch):
     """SURVEY.md section 8 f1 as a number: the WHOLE receiver (ISR FIFO, the 8 dsp() offsets x {up, down} of every block,
     main()'s switch and resync, byte assembly: receiver/Src/main.c:417-554, 243-273, 659-668) for thousands of recorded
-    microphone streams at once -- uc_receive_streams: one pack kernel, one band-kernel launch over every 256-sample offset
-    of every stream, the switch replayed on the device one lane per stream.  Streams: 40 blocks of noise + a sample skew,
+    microphone streams at once -- uc_receive_streams: ONE launch of the band kernel's ROWS build over the 8 FIFO offsets every
+    block adds (the other 9 of its FIFO were evaluated when the block before it arrived, main.c:662; frames read through two
+    base addresses from the caller's buffer, nothing packed or copied), the switch replayed on the device one wave or lane per
+    stream.  Streams: 40 blocks of noise + a sample skew,
     the K7 "Hello World!" transmission rendered at 78 125 Hz, noise; generated on the device.  Real time for ONE
     microphone is 38.1 blocks/s (the MCU keeps up with exactly one)."""
     import ctypes as C
@@ -616,7 +618,7 @@ def receive_leg(args, device, torch):
         dt = (time.perf_counter() - t0) / reps
         texts = [bytes(r[:k]).decode("latin-1") for r, k in zip(text.cpu().numpy(), ntext.cpu().numpy())]
         out[name] = {"streams": ns, "ms_per_call": dt * 1e3, "blocks_per_s": ns * nb / dt,
-                     "dsp_frames_per_s": ns * (nb + 2) * 8 / dt, "x_real_time": ns * nb / dt / (fs / N),
+                     "dsp_frames_per_s": ns * nb * 8 / dt, "x_real_time": ns * nb / dt / (fs / N),
                      "streams_decoding_the_text": sum(1 for t in texts if MSG in t), "first_text": texts[0]}
         if ns == 4096:
             # the same microphones LIVE: one new block of every stream per call (uc_rx_state / uc_receive_streams_next), the
@@ -624,6 +626,7 @@ def receive_leg(args, device, torch):
             live = eng.live(ns)
             chunks = [x[:, b * N:(b + 1) * N].contiguous() for b in range(nb)]
             acc = [bytearray() for _ in range(ns)]
+            nt_host = torch.empty(ns, dtype=torch.int32).pin_memory()     # (a live host keeps a pinned landing buffer)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for ch in chunks:
@@ -632,7 +635,9 @@ def receive_leg(args, device, torch):
                                                C.c_void_p(stream.cuda_stream))
                 if rc != 0:
                     raise RuntimeError(L.uc_last_error().decode())
-                nt = ntext.cpu().numpy()                       # (a live host reads its characters after every block)
+                nt_host.copy_(ntext, non_blocking=True)        # (a live host reads its characters after every block:
+                stream.synchronize()                           #  one 16 KiB copy and one wait per 26.2 ms)
+                nt = nt_host.numpy()
                 if nt.any():
                     tt = text.cpu().numpy()
                     for si in np.nonzero(nt)[0]:
@@ -644,8 +649,60 @@ def receive_leg(args, device, torch):
             out["live_4096_streams"] = {"streams": ns, "blocks_per_call": 1, "calls": nb, "ms_per_call": dt_live * 1e3,
                                         "real_time_ms_per_call": N / fs * 1e3, "headroom_x_real_time": N / fs / dt_live,
                                         "microphones_served_in_real_time": int(ns * N / fs / dt_live),
-                                        "streams_whose_chunks_add_up_to_the_recorded_call": same}
-            del chunks
+                                        "streams_whose_chunks_add_up_to_the_recorded_call": same,
+                                        "kernel_launches_per_call": 2, "new_dsp_frames_per_call": ns * 8,
+                                        "what": "one new block of every stream per call, the host reads the counts back after "
+                                                "every call (a sync per block)"}
+            # the same step with no host in the loop: back to back on one stream, and replayed from ONE captured hipGraph
+            # (everything a step carries -- newest block, the 9 surviving FIFO records, main()'s locals, block counts -- lives
+            # on the device); then the chain from the microphones' 1-bit PDM streams (UC_DTYPE_PDM: + the DFSDM, on the device)
+            live = eng.live(ns)
+            side = torch.cuda.Stream(device)
+            reps_a = 60
+            with torch.cuda.stream(side):
+                for k in range(10):
+                    live.next_into(chunks[k], text, ntext, stream=side.cuda_stream)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(side)
+                for k in range(reps_a):
+                    live.next_into(chunks[10 + k], text, ntext, stream=side.cuda_stream)
+                e1.record(side)
+                e1.synchronize()
+                eager_ms = e0.elapsed_time(e1) / reps_a
+                gr = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gr, stream=side):
+                    live.next_into(chunks[0], text, ntext, stream=side.cuda_stream)
+                for k in range(5):
+                    gr.replay()
+                e0.record(side)
+                for k in range(reps_a):
+                    gr.replay()
+                e1.record(side)
+                e1.synchronize()
+                graph_ms = e0.elapsed_time(e1) / reps_a
+            live.close()
+            out["live_4096_streams"].update({"ms_per_call_back_to_back": eager_ms, "ms_per_call_graph_replay": graph_ms,
+                                             "microphones_served_in_real_time_back_to_back": int(ns * N / fs / (eager_ms * 1e-3))})
+            live = eng.live(ns)
+            gp = torch.Generator(device=device)
+            gp.manual_seed(7)
+            pdm = [torch.randint(-(1 << 31), (1 << 31) - 1, (ns, N), generator=gp, device=device, dtype=torch.int64).to(torch.int32)
+                   for _ in range(4)]
+            with torch.cuda.stream(side):
+                for k in range(6):
+                    live.next_into(pdm[k % 4], text, ntext, stream=side.cuda_stream, pdm=True)
+                e0.record(side)
+                for k in range(reps_a):
+                    live.next_into(pdm[k % 4], text, ntext, stream=side.cuda_stream, pdm=True)
+                e1.record(side)
+                e1.synchronize()
+            live.close()
+            out["live_pdm_4096_streams"] = {"streams": ns, "ms_per_call_back_to_back": e0.elapsed_time(e1) / reps_a,
+                                            "kernel_launches_per_call": 4,
+                                            "what": "one new block of every microphone per call as 2048 x 32 PDM bits "
+                                                    "(UC_DTYPE_PDM, random bits: timing only; parity: tests/test_dfsdm.py): "
+                                                    "sinc5 + history, ROWS band launch, replay"}
+            del chunks, pdm
         eng.close()
         del x, text, ntext
     return out

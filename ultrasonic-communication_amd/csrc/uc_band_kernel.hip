@@ -672,8 +672,28 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         }
       }
     }
+    // SYNC_CPLX live receivers: acquisition looks at the UP reference only (receiver/Src/main.c:447-451); a stream that is
+    // IDLE when its block arrives cannot read a DOWN statistic of that block before the block has left the FIFO (it takes
+    // three evaluations, five blocks, to reach SYNCHRONIZED), so the second transform of its 8 new offsets is skipped --
+    // p.need_down[row] == 0, written by the replay kernel of the previous call (one-block calls only; nullptr: never skip)
+    bool skip_down = false;
+    if (ROWS && MODE == kModeCplx && p.need_down) {
+      const unsigned g8 = f >> 3;
+      const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
+      skip_down = __builtin_amdgcn_readfirstlane((int)p.need_down[s]) == 0;
+    }
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
+      if (ROWS && MODE == kModeCplx && run == 1 && skip_down) {  // (uniform over the workgroup: no barrier is left behind)
+        float* e = ring + ring_n * kRingStride + wave * 6;
+        if (lane == 0) {
+          e[0] = pv[0]; e[1] = pv[1]; e[2] = 0.f; e[3] = 0.f;
+          e[4] = __uint_as_float(WIDE ? kpw[0] : kpack);
+          e[5] = __uint_as_float(WIDE ? 0u : flags);
+        }
+        ring_n++;
+        continue;
+      }
       v2f v[16];
       // ---- pass 1: window*chirp multiply, radix-16, Ns = 1 ------------------
 #if UC_BAND_KNOCK & 1024  // (pricing only: the raw samples through LDS in front of pass 1 -- 4 b128 stores, a barrier, 4 b128 loads)

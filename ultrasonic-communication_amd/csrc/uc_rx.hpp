@@ -67,6 +67,9 @@ struct RxParams {
   // live streams: the word that says which half of the state's newest-block store is current (uc_kernels.hpp: BandParams);
   // the replay flips it on its way out -- the band launch in front of it has filled the other half.  nullptr: none.
   unsigned int* parity;
+  // live streams: [n_streams] words the replay leaves for the NEXT call's band launch: 0 = the stream is IDLE after this call
+  // (the complex receiver's acquisition needs the UP transform only), 1 = every other state.  nullptr: none.
+  uint32_t* need_down;
 };
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);
