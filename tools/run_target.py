@@ -48,10 +48,10 @@ SPEC = {  # target -> (kernel-name substring, units, unit, algorithmic bytes per
     "stream_d8_f32": ("stream_kernel", nf * 2048, "sample", 4.5),
     "sinc5": ("sinc5_kernel", nf * 512, "word", 8.0),
     "sinc5_streams": ("sinc5_kernel", nf * 512, "word", 8.0),
-    # a new block of a live stream: 8192 B read once (the frames overlap in cache), 8192 B kept for the next call, 8 x 8 B of
-    # records -- per NEW FIFO OFFSET (frame): 2056 B
-    "rows_rx_real_f32": ("band_kernel", nf, "frame", 2056),
-    "rows_sync_cplx_f32": ("band_kernel", nf, "frame", 2056),
+    # a new block of a live stream: 8192 B of the block + 8192 B of the block in front of it read once (the 8 frames overlap in
+    # cache), 8192 B kept for the next call, 8 x 8 B of records -- per NEW FIFO OFFSET (frame): 3080 B
+    "rows_rx_real_f32": ("band_kernel", nf, "frame", 3080),
+    "rows_sync_cplx_f32": ("band_kernel", nf, "frame", 3080),
 }
 kname, units, unit, alg = SPEC[T]
 if args.info:

@@ -39,9 +39,17 @@
 #define UC_CPLX_NRES 14  // ... and how many of the 16 entries of that table
 #endif
 
+#ifndef UC_ROWS_CPOL
+#define UC_ROWS_CPOL 0  // cache policy of the ROWS build's frame loads: every 256-sample segment of a block is read by up to 8
+#endif                  // frames (the batch builds read every byte once and say so: UC_STREAM_CPOL = nt)
+
 namespace uc {
 
 namespace {
+
+__device__ __forceinline__ float buf_ld32_rows(__amdgpu_buffer_rsrc_t r, int voff, int soff) {
+  return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, UC_ROWS_CPOL));
+}
 
 constexpr int T = kBandThreads;  // 128
 // LDS: the 2048-point complex tile, then a ring of per-frame window partials that a
@@ -489,8 +497,8 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       const int tsplit = 16 - 2 * (int)m8;
 #pragma unroll
       for (int m = 0; m < 8; m++)
-        xp[m] = mkv(buf_ld32_stream(2 * m < tsplit ? ra : rb, voff4, T * 4 * (2 * m)),
-                    buf_ld32_stream(2 * m + 1 < tsplit ? ra : rb, voff4, T * 4 * (2 * m + 1)));
+        xp[m] = mkv(buf_ld32_rows(2 * m < tsplit ? ra : rb, voff4, T * 4 * (2 * m)),
+                    buf_ld32_rows(2 * m + 1 < tsplit ? ra : rb, voff4, T * 4 * (2 * m + 1)));
     } else {
       const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + u * p.stride * 4, kN * 4);
 #pragma unroll
