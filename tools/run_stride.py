@@ -3,7 +3,7 @@
 whole frame apart (every byte of every frame comes from HBM: 8193 B/frame) and over frames 256 samples apart (7/8 of every
 frame's bytes are cache hits: 1025 B/frame from HBM) -- same frames per launch, same box, alternated; per leg the rate (HIP
 events), the in-kernel shader clock (clock-stamped twin) and the socket power / SMU clock over the last second of a sustained run.
-Usage: python tools/run_stride.py [frames_log2=20] [seconds=3]   -> JSON lines"""
+Usage: python tools/run_stride.py [frames_log2=20] [seconds=3] [only: 2048|256]   -> JSON lines"""
 import json
 import os
 import sys
@@ -26,6 +26,8 @@ flat = frames.reshape(-1)
 e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
 stream = torch.cuda.current_stream(dev)
 legs = [("stride 2048 (8193 B/frame from HBM)", 0, nf), ("stride 256 (1025 B/frame from HBM, the rest cache hits)", 256, nf)]
+if len(sys.argv) > 3:
+    legs = [l for l in legs if l[0].startswith("stride " + sys.argv[3] + " ")]
 sym = torch.empty(nf, dtype=torch.uint8, device=dev)
 for rep in range(2):
     for name, stride, n in legs:
