@@ -6,7 +6,10 @@
  * The microphones are synthetic: noise, then the K7 transmission (generator/ChirpGenerator.ipynb: G, 7 x H, L, the message
  * MSB first, 12 x G), one symbol per block, a different message and noise per stream.
  *
- * usage: host_node_live [n_streams=5] [n_devices=1]
+ * usage: host_node_live [n_streams=5] [n_devices=1] [pdm]
+ * With `pdm` the node's chain starts at the microphones' 1-bit PDM streams (UC_DTYPE_PDM: 2048 words of 32 bits per block and
+ * microphone from a second-order delta-sigma modulator; the DFSDM of receiver/Src/dfsdm.c:59-61,69,78 runs on the devices,
+ * every microphone's filter history travels in its device's uc_rx_state).
  * Prints what each stream received, as seen in the gathered arrays of EVERY local device.  Exit 0 when every device holds
  * every stream's message.  Without a GPU: prints uc_group_create's error and exits 0 (there is no CPU path). */
 #include <math.h>
@@ -47,9 +50,37 @@ static void block(int32_t* out, const uc_config* cfg, int kind /* 1 H, 0 L, 2 G 
   }
 }
 
+/* the same block as the microphone's bit stream (see tests/c/host_live.c): the waveform at 32 x fs through a second-order
+ * delta-sigma modulator whose integrators run on from block to block; full scale = 1 */
+static void block_pdm(uint32_t* out, const uc_config* cfg, int kind, double amp, double sigma, double dsm[2]) {
+  const double fs = cfg->fs, T = cfg->n / fs, k = (cfg->f1 - cfg->f0) / T, pi = 3.14159265358979323846;
+  uint32_t i;
+  int j;
+  for (i = 0; i < cfg->n; i++) {
+    const double nz = sigma * sqrt(-2.0 * log(uniform01())) * cos(2.0 * pi * uniform01());
+    uint32_t w = 0;
+    for (j = 0; j < 32; j++) {
+      const double t = (i + j / 32.0) / fs;
+      double x = nz, y;
+      if (kind != 2) {
+        const double f = kind ? cfg->f0 + k * t / 2.0 : cfg->f1 - k * t / 2.0;
+        const double arg = 2.0 * pi * f * t - pi / 2.0;
+        x += amp * (cos(arg) + sin(arg));
+      }
+      y = dsm[1] >= 0.0 ? 1.0 : -1.0;
+      dsm[0] += x - y;
+      dsm[1] += dsm[0] - y;
+      if (y > 0.0) w |= (uint32_t)1 << j;
+    }
+    out[i] = w;
+  }
+}
+
 int main(int argc, char** argv) {
   const int ns = argc > 1 ? atoi(argv[1]) : 5;
   const int nd = argc > 2 ? atoi(argv[2]) : 1;
+  const int pdm = argc > 3 && strcmp(argv[3], "pdm") == 0;
+  static double dsm[MAXS][2];
   static const char* const MSGS[4] = {"Hello World!", "uchirp", "MI355X", "0123456789"};
   uc_config cfg;
   uc_group* g = NULL;
@@ -104,10 +135,12 @@ int main(int argc, char** argv) {
       if (q >= 1 && q <= 7) kind = 1;
       else if (q == 8) kind = 0;
       else if (q >= 9 && q < 9 + 8 * len) kind = (m[(q - 9) / 8] >> (7 - (q - 9) % 8)) & 1;
-      block(words + (size_t)s * NN, &cfg, kind, 2000.0, 50.0);
+      if (pdm) block_pdm((uint32_t*)words + (size_t)s * NN, &cfg, kind, 0.25, 0.00625, dsm[s]);
+      else block(words + (size_t)s * NN, &cfg, kind, 2000.0, 50.0);
     }
     /* host buffers: the call returns with the gathered characters of every stream in every device's arrays */
-    if (uc_group_receive_streams_next(g, rx, share, UC_DTYPE_I32, (size_t)ns, NN, NN, NULL, textp, CAP, cntp, NULL) != 0) {
+    if (uc_group_receive_streams_next(g, rx, share, pdm ? UC_DTYPE_PDM : UC_DTYPE_I32, (size_t)ns, NN, NN, NULL, textp, CAP, cntp,
+                                      NULL) != 0) {
       printf("uc_group_receive_streams_next: %s\n", uc_last_error());
       return 1;
     }

@@ -234,6 +234,24 @@ def test_sinc5_streams_with_carried_history_bit_exact(uchirp, n_streams):
     for s in check:
         assert np.array_equal(got[s], ref[s][:got.shape[1]]), s
     assert np.array_equal(hist_d.cpu().numpy().view(np.uint32), w[:, b0 - 4:b0])
+    # every buffer on its own: device words with a row pitch wider than the chunk, HOST history, HOST outputs with a pitch
+    if n_streams <= 64:
+        import ctypes as C
+        L = uchirp.lib()
+        nw, pitch_in, pitch_out = 504, 512, 600
+        wide = torch.zeros((n_streams, pitch_in), dtype=torch.int32, device=dev)
+        wide[:, :nw] = wd[:, :nw]
+        wide[:, nw:] = 0x5A5A5A5A                                                 # (never read: the filter sees nw words per row)
+        h_host = hist0.copy()
+        o_host = np.full((n_streams, pitch_out), 77, np.int32)
+        rc = L.uc_dfsdm_sinc5_streams(e._h, C.c_void_p(wide.data_ptr()), n_streams, nw, pitch_in, h_host.ctypes.data_as(C.c_void_p),
+                                      o_host.ctypes.data_as(C.c_void_p), pitch_out, None)
+        assert rc == 0, L.uc_last_error()
+        for s in check:
+            assert np.array_equal(o_host[s, :nw], ref[s][:nw]), s
+        assert (o_host[:, nw:] == 77).all() and np.array_equal(h_host, w[:, nw - 4:nw])
+        assert L.uc_dfsdm_sinc5_streams(e._h, C.c_void_p(wide.data_ptr()), n_streams, nw, nw - 4, h_host.ctypes.data_as(C.c_void_p),
+                                        o_host.ctypes.data_as(C.c_void_p), pitch_out, None) < 0          # rows overlap
     # refused: misaligned device rows, overlapping streams
     with pytest.raises(uchirp.UchirpError):
         e.dfsdm_streams(wd[:, 1:7].contiguous()[:, :5].contiguous(), hist_d)     # 5-word rows: stride not a multiple of 4

@@ -259,11 +259,12 @@ def test_plain_c_host_serves_the_microphones_of_a_node(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-O2", "-I" + os.path.join(ROOT, "include"),
                            os.path.join(ROOT, "tests", "c", "host_node_live.c"), "-o", exe, "-L" + libdir, "-luchirp", "-lm",
                            "-Wl,-rpath," + libdir])
-    out = subprocess.run([exe, "6", "1"], capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    for s, m in enumerate(("Hello World!", "uchirp", "MI355X", "0123456789", "Hello World!", "uchirp")):
-        assert ('stream %d received "%s"' % (s, m)) in out.stdout
-    print(out.stdout.strip().splitlines()[-3:])
+    for mode in ([], ["pdm"]):        # DFSDM words; the microphones' 1-bit streams (UC_DTYPE_PDM through the group)
+        out = subprocess.run([exe, "6", "1"] + mode, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        for s, m in enumerate(("Hello World!", "uchirp", "MI355X", "0123456789", "Hello World!", "uchirp")):
+            assert ('stream %d received "%s"' % (s, m)) in out.stdout
+        print(mode, out.stdout.strip().splitlines()[-3:])
 
 
 def test_group_process_stream_of_one_device_equals_the_engine(uchirp):
