@@ -657,6 +657,7 @@ class Group:
             _check(lib().uc_group_create_rank(C.byref(self.cfg), C.c_char_p(bytes(unique_id)), int(world), int(rank),
                                               C.byref(h)), "uc_group_create_rank")
         self._h = h
+        self._states = []
         self.world = lib().uc_group_world(h)
         self.n_local = lib().uc_group_local_count(h)
         self.first_rank = lib().uc_group_first_rank(h)
@@ -676,6 +677,8 @@ class Group:
         return buf.raw
 
     def close(self):
+        for st in list(getattr(self, "_states", [])):     # states first: a state must be destroyed before its context
+            st.close()
         if getattr(self, "_h", None):
             lib().uc_group_destroy(self._h)
             self._h = None
@@ -753,15 +756,21 @@ class Group:
         return tuple(x.value for x in v)
 
     def rx_state(self, local, n_streams):
-        """uc_rx_state_create on the context of local device `local` -> a raw handle (free with rx_state_destroy)."""
+        """uc_rx_state_create on the context of local device `local` -> a GroupRxState (close it, or rx_state_destroy it,
+        BEFORE the group goes: a state must not outlive its context; the object keeps the group alive until then)."""
         h = C.c_void_p()
         _check(lib().uc_rx_state_create(C.c_void_p(lib().uc_group_ctx(self._h, int(local))), int(n_streams), C.byref(h)),
                "uc_rx_state_create")
-        return h
+        st = GroupRxState(self, h)
+        self._states.append(st)
+        return st
 
     @staticmethod
-    def rx_state_destroy(h):
-        lib().uc_rx_state_destroy(h)
+    def rx_state_destroy(st):
+        if isinstance(st, GroupRxState):
+            st.close()
+        else:
+            lib().uc_rx_state_destroy(st)
 
     def wait_gather(self, local, gathered, stream):
         _check(lib().uc_group_wait_gather(self._h, int(local), C.c_void_p(self._ptr(gathered)), C.c_void_p(int(stream) if stream else None)),
@@ -769,6 +778,26 @@ class Group:
 
     def synchronize(self):
         _check(lib().uc_group_synchronize(self._h), "uc_group_synchronize")
+
+
+class GroupRxState:
+    """A uc_rx_state made on a context of a Group (Group.rx_state): holds the group, is closed with it at the latest."""
+
+    def __init__(self, group, handle):
+        self.group, self._h = group, handle
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().uc_rx_state_destroy(self._h)
+            self._h = None
+            if self in self.group._states:
+                self.group._states.remove(self)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class LiveStreams:
