@@ -10,8 +10,11 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "ultrasonic-communication_amd"))
+import time
+
 import torch
 import uchirp
+from bench import PowerSampler
 
 N = 2048
 counts = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "4096,65536").split(",")]
@@ -50,9 +53,21 @@ for ns in counts:
         e1.record(s)
         e1.synchronize()
         graph_ms = e0.elapsed_time(e1) / calls
+        # socket power / SMU clock over the last second of 2 s of graph replays
+        ps = PowerSampler(torch, dev)
+        ps.start()
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < float(os.environ.get("UC_LIVE_SUSTAIN_S", "2.0")):
+            for k in range(64):
+                gr.replay()
+            s.synchronize()
+        t1 = time.perf_counter()
+        power = ps.stop(t1 - 1.0, t1)
     print(json.dumps({"variant": vname, "streams": ns, "calls": calls, "eager_ms_per_call": eager_ms, "graph_ms_per_call": graph_ms,
                       "new_frames_per_call": ns * 8, "frames_per_s_eager": ns * 8 / eager_ms * 1e3,
                       "microphones_in_real_time_eager": int(ns * 26.2144 / eager_ms),
+                      "socket_W": round(power["socket_W_mean"], 1) if power else None, "cap_W": power["cap_W"] if power else None,
+                      "smu_clock_MHz": round(power["sclk_MHz_smu_mean"]) if power and power.get("sclk_MHz_smu_mean") else None,
                       "env": {k: v for k, v in os.environ.items() if k.startswith("UC_")},
                       "what": "uc_receive_streams_next back to back, one new block of every stream per call, no host sync"}), flush=True)
     live.close()

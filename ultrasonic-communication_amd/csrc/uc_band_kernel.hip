@@ -492,13 +492,21 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       const char* before = jb ? blk - kN * 4 : prev_rd + (size_t)s * p.prev_pitch * 4;
       // sample 0 of the frame as if the whole frame lay in the one block / in the other; load t covers samples
       // [128 t, 128 t + 128): the first 16 - 2 m loads belong to the block in front
-      const __amdgpu_buffer_rsrc_t ra = make_rsrc(before + 1024 * m8, kN * 4);
-      const __amdgpu_buffer_rsrc_t rb = make_rsrc(blk - (kN * 4 - 1024 * (int)m8), kN * 4);
-      const int tsplit = 16 - 2 * (int)m8;
+      if (jb != 0) {
+        // behind the row's first block the block in front is the row's previous one: the frame lies in memory as one piece
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(before + 1024 * m8, kN * 4);
 #pragma unroll
-      for (int m = 0; m < 8; m++)
-        xp[m] = mkv(buf_ld32_rows(2 * m < tsplit ? ra : rb, voff4, T * 4 * (2 * m)),
-                    buf_ld32_rows(2 * m + 1 < tsplit ? ra : rb, voff4, T * 4 * (2 * m + 1)));
+        for (int m = 0; m < 8; m++)
+          xp[m] = mkv(buf_ld32_rows(rx, voff4, T * 4 * (2 * m)), buf_ld32_rows(rx, voff4, T * 4 * (2 * m + 1)));
+      } else {
+        const __amdgpu_buffer_rsrc_t ra = make_rsrc(before + 1024 * m8, kN * 4);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(blk - (kN * 4 - 1024 * (int)m8), kN * 4);
+        const int tsplit = 16 - 2 * (int)m8;
+#pragma unroll
+        for (int m = 0; m < 8; m++)
+          xp[m] = mkv(buf_ld32_rows(2 * m < tsplit ? ra : rb, voff4, T * 4 * (2 * m)),
+                      buf_ld32_rows(2 * m + 1 < tsplit ? ra : rb, voff4, T * 4 * (2 * m + 1)));
+      }
     } else {
       const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + u * p.stride * 4, kN * 4);
 #pragma unroll
