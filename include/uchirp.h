@@ -509,6 +509,8 @@ int uc_group_synchronize(uc_group* g);
  * A stream's text is the one uc_receive_stream[_isr] gives for it alone, bit for bit, wherever it ran.
  * uc_group_receive_streams_next is the LIVE form (uc_receive_streams_next): states[l] = uc_rx_state_create(uc_group_ctx(g, l),
  * count of rank first + l) holds that share's receivers between calls; text receives what was decoded during THIS call.
+ * (A block completes at most ONE character per stream, plus the newline that ends a message: for one-block calls text_cap = 4
+ * is plenty and keeps what is gathered per step at 8 bytes per stream of the node.)
  */
 int uc_group_receive_streams(uc_group* g, const void* const* samples, int dtype, size_t n_streams_total, size_t n_samples,
                              size_t stream_stride_elems, const uint8_t* const* busy /*nullable*/, char* const* text,
