@@ -323,7 +323,7 @@ int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_str
  * uc_receive_streams_next() is uc_receive_streams() for the NEXT n_samples (whole blocks) of every stream: the chunks of a
  * stream, of any sizes, give exactly the text and trace of the whole stream in one call (trace records carry stream-global
  * block indices; `text` receives the characters decoded during THIS call).  busy as in uc_receive_streams (flags of this
- * chunk's blocks).  One new block of every stream costs 8 transforms per stream and reference, 2 kernel launches (4 with a
+ * chunk's blocks).  One new block of every stream costs 8 transforms per stream and reference, 2 kernel launches (5 with a
  * busy mask, +2 for UC_DTYPE_PDM), no copy.
  * Everything a step carries lives on the device, so with device pointers the call can be captured into a hipGraph and the
  * graph replayed for every block that arrives (make one eager call of the same shape first: it sizes the scratch; nothing is
