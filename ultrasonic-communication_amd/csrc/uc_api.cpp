@@ -696,6 +696,7 @@ static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stre
   // instantiation that also stores the window bins (uc_band_kernel.hip: SPEC), so that what the device captures are
   // compared with is the arithmetic of the throughput kernel
   const bool spec = p.spectrum != nullptr && !p.wide;
+  // (frames that overlap run the default build with default-policy loads: same registers, same occupancy -- shares the entry)
   int& bpc = c->band_blocks_per_cu[rows ? (p.wide ? 4 : 3) : (p.wide ? 1 : (spec ? 2 : 0))][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
   if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0, spec, rows);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;

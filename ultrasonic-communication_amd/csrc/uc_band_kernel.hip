@@ -343,8 +343,14 @@ __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
 // multiple of 256 samples -- which is a whole number of this kernel's 128-sample load instructions, so each load takes one
 // of two buffer resources by a SCALAR select and nothing is ever copied together.  A separate instantiation again: the
 // batch builds carry none of it.
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, bool ROWS = false>
+// FRAMES = 2 (OVERLAP): the batch addressing over frames that OVERLAP (stride < n: the reference's own FIFO reads, main.c:447-451,
+// 256 or 512 samples apart): the same loads with the default cache policy instead of `nt` -- with `nt` a frame's bytes are
+// fetched again by each of the up to 8 frames that share them (6384 instead of 1025 B of HBM traffic per frame at stride 256),
+// and that traffic is power the clock does not get (profiles/r05_stride_power.txt: +18-23 % frames/s).  Nothing else differs.
+enum { kFramesBatch = 0, kFramesRows = 1, kFramesOverlap = 2 };
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, int FRAMES = kFramesBatch>
 __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
+  constexpr bool ROWS = FRAMES == kFramesRows;
 #ifdef UC_STAMPS
   unsigned long long acc_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   unsigned long long last_ = __builtin_readcyclecounter();
@@ -510,8 +516,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     } else {
       const __amdgpu_buffer_rsrc_t rx = make_rsrc(reinterpret_cast<const char*>(p.frames) + u * p.stride * 4, kN * 4);
 #pragma unroll
-      for (int m = 0; m < 8; m++)
-        xp[m] = mkv(buf_ld32_stream(rx, voff4, T * 4 * (2 * m)), buf_ld32_stream(rx, voff4, T * 4 * (2 * m + 1)));
+      for (int m = 0; m < 8; m++) {
+        if (FRAMES == kFramesOverlap)
+          xp[m] = mkv(buf_ld32_rows(rx, voff4, T * 4 * (2 * m)), buf_ld32_rows(rx, voff4, T * 4 * (2 * m + 1)));
+        else
+          xp[m] = mkv(buf_ld32_stream(rx, voff4, T * 4 * (2 * m)), buf_ld32_stream(rx, voff4, T * 4 * (2 * m + 1)));
+      }
     }
   };
   load_unit(f, xp);
@@ -1087,16 +1097,16 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   UC_CLOCK_END(p.debug, 2);
 }
 
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, bool ROWS = false>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, int FRAMES = kFramesBatch>
 static int launch_one(const BandParams& p, int grid, hipStream_t stream) {
-  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC, ROWS>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
+  hipLaunchKernelGGL((band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC, FRAMES>), dim3((unsigned)grid), dim3((unsigned)T), 0, stream, p);
   return (int)hipGetLastError();
 }
 
-template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, bool ROWS = false>
+template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, int FRAMES = kFramesBatch>
 static int occupancy_one() {
   int nb = 0;
-  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC, ROWS>, T, 0);
+  hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, band_kernel<MODE, DTYPE, WAVES, WIDE, SPEC, FRAMES>, T, 0);
   if (e != hipSuccess || nb <= 0) nb = 2 * WAVES;
   return nb;
 }
@@ -1110,18 +1120,28 @@ UC_LAUNCH_BEGIN
       if (mode == kModePair || spec) return (int)hipErrorInvalidValue;                    \
       if (mode == kModeRxReal) {                                                          \
         if (wide) {                                                                       \
-          if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 2, true, false, true>(__VA_ARGS__);   \
-          return FN<kModeRxReal, UC_DTYPE_F32, 2, true, false, true>(__VA_ARGS__);        \
+          if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 2, true, false, kFramesRows>(__VA_ARGS__);   \
+          return FN<kModeRxReal, UC_DTYPE_F32, 2, true, false, kFramesRows>(__VA_ARGS__);        \
         }                                                                                 \
-        if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 3, false, false, true>(__VA_ARGS__);    \
-        return FN<kModeRxReal, UC_DTYPE_F32, 3, false, false, true>(__VA_ARGS__);         \
+        if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 3, false, false, kFramesRows>(__VA_ARGS__);    \
+        return FN<kModeRxReal, UC_DTYPE_F32, 3, false, false, kFramesRows>(__VA_ARGS__);         \
       }                                                                                   \
       if (wide) {                                                                         \
-        if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, true, false, true>(__VA_ARGS__);       \
-        return FN<kModeCplx, UC_DTYPE_F32, 2, true, false, true>(__VA_ARGS__);            \
+        if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, true, false, kFramesRows>(__VA_ARGS__);       \
+        return FN<kModeCplx, UC_DTYPE_F32, 2, true, false, kFramesRows>(__VA_ARGS__);            \
       }                                                                                   \
-      if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, false, false, true>(__VA_ARGS__);        \
-      return FN<kModeCplx, UC_DTYPE_F32, 2, false, false, true>(__VA_ARGS__);             \
+      if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, false, false, kFramesRows>(__VA_ARGS__);        \
+      return FN<kModeCplx, UC_DTYPE_F32, 2, false, false, kFramesRows>(__VA_ARGS__);             \
+    }                                                                                     \
+    if (overlap && !spec && !wide && mode != kModePair) { /* overlapping frames (stride < n): default occupancy of each mode */ \
+      if (mode == kModeRxReal && waves == 3) {                                            \
+        if (dtype == UC_DTYPE_I32) return FN<kModeRxReal, UC_DTYPE_I32, 3, false, false, kFramesOverlap>(__VA_ARGS__);  \
+        return FN<kModeRxReal, UC_DTYPE_F32, 3, false, false, kFramesOverlap>(__VA_ARGS__);                            \
+      }                                                                                   \
+      if (mode == kModeCplx && waves == 2) {                                              \
+        if (dtype == UC_DTYPE_I32) return FN<kModeCplx, UC_DTYPE_I32, 2, false, false, kFramesOverlap>(__VA_ARGS__);    \
+        return FN<kModeCplx, UC_DTYPE_F32, 2, false, false, kFramesOverlap>(__VA_ARGS__);                              \
+      }                                                                                   \
     }                                                                                     \
     if (spec && !wide) { /* uc_window_spectrum on the default two-round build, at each mode's default occupancy */ \
       if (mode == kModePair) {                                                            \
@@ -1174,10 +1194,11 @@ UC_LAUNCH_BEGIN
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream) {
   if (grid <= 0) return (int)hipSuccess;
   const bool wide = p.wide != 0, spec = p.spectrum != nullptr, rows = p.row_blocks != 0;
+  const bool overlap = !rows && p.stride < (size_t)kN;
   UC_DISPATCH(launch_one, p, grid, stream);
 }
 
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec, bool rows) {
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec, bool rows, bool overlap) {
   UC_DISPATCH(occupancy_one);
 }
 

@@ -82,7 +82,8 @@ enum BandMode { kModeRxReal = 0, kModeCplx = 1, kModePair = 2 };
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
 // spec: the instantiation that also stores the window bins (p.spectrum != nullptr on the default two-round build)
 // rows: the ROWS instantiation (p.row_blocks != 0; RX_REAL / SYNC_CPLX at their default occupancy -- `waves` is not looked at)
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false, bool rows = false);
+// overlap: frames that overlap (p.stride < kN) on the default builds of RX_REAL / SYNC_CPLX: the same kernel with default-policy loads
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false, bool rows = false, bool overlap = false);
 
 // Full-spectrum pipeline: UC_COMPRESS (FFT x H x IFFT, two frames per complex transform).
 struct FullParams {
@@ -199,7 +200,8 @@ int sinc5_waves_per_block();
 namespace clk {
 int launch_band(int mode, int dtype, int waves, const BandParams& p, int grid, hipStream_t stream);
 // rows: the ROWS instantiation (p.row_blocks != 0; RX_REAL / SYNC_CPLX at their default occupancy -- `waves` is not looked at)
-int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false, bool rows = false);
+// overlap: frames that overlap (p.stride < kN) on the default builds of RX_REAL / SYNC_CPLX: the same kernel with default-policy loads
+int band_max_blocks_per_cu(int mode, int dtype, int waves, bool wide, bool spec = false, bool rows = false, bool overlap = false);
 int launch_compress(int dtype, const FullParams& p, int grid, hipStream_t stream);
 int compress_max_blocks_per_cu(int dtype);
 int launch_iq(int dtype, const IqParams& p, int grid, hipStream_t stream, int n);
