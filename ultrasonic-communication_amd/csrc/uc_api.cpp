@@ -849,7 +849,10 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     }
     ip.work_ctr = nullptr;
     int wslot = -1;
-    if (!c->static_deal && ip.group >= 2) {
+    // (tickets only for batches of at least four full groups per workgroup: below that the launch is over before the skew they
+    // even out has built up, and the tickets cost more than they save -- 65 536 base-band frames: +13 % dealt statically,
+    // 262 144: -3 %; the band kernel's rule, profiles/r05_live_deal.txt)
+    if (!c->static_deal && ip.group >= 2 && n_frames >= (size_t)4 * (size_t)c->iq_group * grid) {
       const size_t ngroups = (n_frames + ip.group - 1) / ip.group;
       if (ngroups > grid) {  // dynamic hand-out
         const int wrc = take_work_counter(c, stream, &ip.work_ctr, &wslot);
@@ -885,7 +888,8 @@ static int process_batch_impl(uc_ctx* c, const void* frames, int dtype, size_t n
     fp.work_ctr = nullptr;
     fp.chunk_log2 = 0;
     int wslot = -1;
-    if (!c->static_deal && c->compress_chunk >= 2 && npairs > (size_t)c->compress_chunk * grid) {  // more chunks than workgroups
+    // (at least four chunks per workgroup: 16 384 pairs +22 % dealt statically, 65 536 pairs -2 %)
+    if (!c->static_deal && c->compress_chunk >= 2 && npairs >= (size_t)4 * (size_t)c->compress_chunk * grid) {
       const int wrc = take_work_counter(c, stream, &fp.work_ctr, &wslot);  // dynamic hand-out of chunks of consecutive pairs
       if (wrc) return wrc;
       if (fp.work_ctr) {
@@ -1355,7 +1359,8 @@ int uc_process_stream(uc_ctx* c, const void* samples, int dtype, size_t n_sample
   sp.work_ctr = nullptr;
   sp.chunk_log2 = 0;
   int wslot = -1;
-  if (!c->static_deal && n_blocks > (size_t)c->stream_chunk * grid) {  // more chunks than workgroups
+  // (tickets only from sixteen chunks per workgroup on: 2^26 samples +50 % dealt statically, 2^28 +9 %, 2^31 -11 %)
+  if (!c->static_deal && n_blocks >= (size_t)16 * (size_t)c->stream_chunk * grid) {
     // dynamic hand-out of chunks of consecutive blocks
     const int wrc = take_work_counter(c, stream, &sp.work_ctr, &wslot);
     if (wrc) return wrc;
