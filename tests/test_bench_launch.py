@@ -169,3 +169,6 @@ def test_gpu_two_ranks_through_the_c_group_rehearsed_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["gather_backend"].startswith("uc_group_process_batch") and d["gates_failed"] == []
     assert d["transmissions"] == 2 * 65520 // 117 and d["transmissions_decoded_exactly"] == d["transmissions"]
     assert d["decoded_text_first"] == "Hello World!" and len(d["per_rank"]["kernel_ms_by_rank"]) == 2
+    # round 5: the exposed gather per rank (kernel bracketed alone: the write-after-gather wait sits in front of it), the world
+    # size the C group's communicator reports, and the statement that no curve was measured by the builder
+    assert len(d["gather_ms_exposed_by_rank"]) == 2 and d["rccl_world"] == 2 and "no 1 -> 8 curve" in d["scaling_note"]
