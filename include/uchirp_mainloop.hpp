@@ -69,6 +69,7 @@ class MainLoop {
   }
 
   UC_HD int state() const { return state_; }
+  UC_HD uint32_t turn() const { return turn_; }  // which of the two interleaved position sets the NEXT acquisition pass visits
   UC_HD uint32_t sync_position() const { return sync_position_; }
 
   // `put(char)` receives the decoded characters ('\n' ends a message), as the firmware's printf does

@@ -1531,8 +1531,8 @@ struct uc_rx_state {
   float2* d_carry = nullptr;    // [n_streams][9]: (up, down) mag_max of the 9 FIFO offsets that survive the ISR's shift
                                 // (main.c:662): offsets n .. 2 n of the FIFO become 0 .. n of the next one; zeros at power-on
   uint32_t* d_loop = nullptr;   // [n_streams][rx_loop_words()]: main()'s locals (main.c:314-339) + blocks offered so far
-  uint32_t* d_need_down = nullptr;  // [n_streams]: 0 = the stream was IDLE after the last call (SYNC_CPLX: its next block needs
-                                    // the UP transform only, main.c:447-451); written by every call's replay
+  uint32_t* d_need = nullptr;   // [n_streams]: what the switch can still look at of every stream's NEXT block (which of its 8 new
+                                // FIFO offsets, and the DOWN statistics: main.c:447-453; uc_rx.hpp); written by every replay
   uint32_t* d_hist = nullptr;   // [n_streams][4] PDM words: the DFSDM's sinc^5 history of every microphone (UC_DTYPE_PDM chunks)
   RxScratch rx;                 // scratch of the call in flight
   uint64_t blocks_seen = 0;     // host mirror of the block count (the overflow check only; a replayed graph does not bump it)
@@ -1696,8 +1696,9 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       bp.prev_half = st ? n_streams * (size_t)n : 0;
       bp.parity = st ? st->d_parity : nullptr;
       bp.save = (st && !busy) ? 1u : 0u;  // (with a busy mask the last ACCEPTED block differs by stream: launch_rx_last)
-      // the complex receiver's acquisition is up-only: a stream that is IDLE when its ONE new block arrives gets one transform
-      bp.need_down = (st && nb == 1 && c->cfg.variant == UC_SYNC_CPLX) ? st->d_need_down : nullptr;
+      // acquisition evaluates 4 positions a block, the UP reference only: a stream that is IDLE when its ONE new block arrives
+      // gets the 3 or 5 transforms the switch can still look at (SYNC_CPLX: of the UP reference only) instead of 8
+      bp.need = (st && nb == 1) ? st->d_need : nullptr;
       bp.row_pitch = row_pitch;
       bp.row_blocks = (uint32_t)nb;
       uc::rows_divisor((uint32_t)nb, &bp.div_magic, &bp.div_shift);
@@ -1724,7 +1725,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     rp.n_trace = d_ntrace;
     rp.loop_state = st ? st->d_loop : nullptr;
     rp.parity = st ? st->d_parity : nullptr;
-    rp.need_down = st ? st->d_need_down : nullptr;
+    rp.need = st ? st->d_need : nullptr;
     int lrc;
     if (st && busy) {
       // what the next call's new offsets still read of this one: every stream's newest ACCEPTED block
@@ -1782,7 +1783,7 @@ extern "C" void uc_rx_state_destroy(uc_rx_state* st) {
   if (st->d_loop) (void)hipFree(st->d_loop);
   if (st->d_parity) (void)hipFree(st->d_parity);
   if (st->d_hist) (void)hipFree(st->d_hist);
-  if (st->d_need_down) (void)hipFree(st->d_need_down);
+  if (st->d_need) (void)hipFree(st->d_need);
   st->rx.release();
   delete st;
 }
@@ -1798,7 +1799,7 @@ extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   const uint32_t n = c->cfg.n;
   e = hipMemsetAsync(st->d_last, 0, 2 * st->n_streams * (size_t)n * 4, stream);
   if (e == hipSuccess) e = hipMemsetAsync(st->d_parity, 0, sizeof(unsigned int), stream);
-  if (e == hipSuccess) e = hipMemsetAsync(st->d_need_down, 0, st->n_streams * sizeof(uint32_t), stream);
+  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)st->d_need, 0x052, st->n_streams, stream);  // IDLE, turn 0
   if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)st->d_hist, (int)UC_PDM_SILENCE, st->n_streams * 4, stream);
   if (e == hipSuccess) e = hipMemsetAsync(st->d_carry, 0, st->n_streams * (size_t)(n / 256 + 1) * sizeof(float2), stream);
   if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(FIFO state)");
@@ -1825,7 +1826,7 @@ extern "C" int uc_rx_state_create(uc_ctx* c, size_t n_streams, uc_rx_state** out
   const uint32_t n = c->cfg.n;
   e = hipMalloc((void**)&st->d_last, 2 * n_streams * (size_t)n * 4);
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_parity, 256);
-  if (e == hipSuccess) e = hipMalloc((void**)&st->d_need_down, n_streams * sizeof(uint32_t));
+  if (e == hipSuccess) e = hipMalloc((void**)&st->d_need, n_streams * sizeof(uint32_t));
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_hist, n_streams * 16);
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_carry, n_streams * (size_t)(n / 256 + 1) * sizeof(float2));
   if (e == hipSuccess) e = hipMalloc((void**)&st->d_loop, n_streams * (size_t)uc::rx_loop_words() * 4);

@@ -480,6 +480,13 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     prev_rd = reinterpret_cast<const char*>(p.prev) + (size_t)par * p.prev_half * 4;
     prev_wr = const_cast<char*>(reinterpret_cast<const char*>(p.prev)) + (size_t)(par ^ 1u) * p.prev_half * 4;
   }
+  // ROWS, one-block live calls (p.need): what the switch can still look at of the row's new block (uc_rx.hpp: RxParams::need).
+  // rows_need = the word of the unit last handed to load_unit (read at the top of the frame loop, BEFORE the next unit is
+  // loaded); the word of a row is fetched once, when the row's first unit is loaded
+  unsigned rows_need = 0x1ffu, need_row = 0xffffffffu, need_word = 0x1ffu;
+  // ... and the units whose loads are already out: a unit that is not needed hands its turn to the next needed unit of its row
+  // (inside the group), so that a frame behind skipped ones still has its samples requested a whole computed frame ahead
+  unsigned span_lo = 1u, span_hi = 0u;
   auto load_unit = [&](size_t u, v2f (&xp)[NX]) {
     if (kPair) {
       const size_t fa = u << psh;
@@ -490,10 +497,33 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #pragma unroll
       for (int t = 0; t < NX; t++) xp[t] = mkv(buf_ld32_stream(ra, voff4, T * 4 * t), buf_ld32_stream(rb, voff4, T * 4 * t));
     } else if (ROWS) {
+      // (requested when an earlier unit of the row was loaded -- same row, so rows_need stands: nothing to do, and no
+      // address arithmetic spent on a unit that is passed over)
+      if (p.need && (unsigned)u >= span_lo && (unsigned)u <= span_hi) return;
       // unit u = (row s, block jb, m): samples [256 m, n) of the block in front of block jb, then [0, 256 m) of block jb
-      const unsigned g8 = (unsigned)u >> 3, m8 = ((unsigned)u & 7u) + 1u;
+      const unsigned g8 = (unsigned)u >> 3;
+      unsigned m8 = ((unsigned)u & 7u) + 1u;
       const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
       const unsigned jb = g8 - s * p.row_blocks;
+      if (p.need) {
+        if (s != need_row) {
+          need_word = (unsigned)__builtin_amdgcn_readfirstlane((int)p.need[s]);
+          need_row = s;
+        }
+        rows_need = need_word;
+        // An offset the switch cannot look at is neither loaded nor transformed -- except the m = 8 frame of a row's last
+        // block when it is the one that hands the block to the state (p.save): loaded, stored, not transformed.  The loads
+        // that go out now are those of the NEXT unit of the row that needs its samples (inside this group of units).
+        unsigned want = need_word & 0xffu;
+        if (p.save && jb == p.row_blocks - 1u) want |= 0x80u;
+        const unsigned rem = want >> (m8 - 1u);
+        if (rem == 0u) return;
+        const unsigned ahead = (unsigned)__builtin_ctz(rem);
+        if (((unsigned)u + ahead) > ((unsigned)u | gmask)) return;  // (that unit belongs to another group)
+        span_lo = (unsigned)u;
+        span_hi = (unsigned)u + ahead;
+        m8 += ahead;
+      }
       const char* blk = reinterpret_cast<const char*>(p.frames) + ((size_t)s * p.row_pitch + (size_t)jb * kN) * 4;
       const char* before = jb ? blk - kN * 4 : prev_rd + (size_t)s * p.prev_pitch * 4;
       // sample 0 of the frame as if the whole frame lay in the one block / in the other; load t covers samples
@@ -701,12 +731,38 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     // SYNC_CPLX live receivers: acquisition looks at the UP reference only (receiver/Src/main.c:447-451); a stream that is
     // IDLE when its block arrives cannot read a DOWN statistic of that block before the block has left the FIFO (it takes
     // three evaluations, five blocks, to reach SYNCHRONIZED), so the second transform of its 8 new offsets is skipped --
-    // p.need_down[row] == 0, written by the replay kernel of the previous call (one-block calls only; nullptr: never skip)
+    // bit 8 of the row's need word, written by the replay kernel of the previous call (one-block calls only; nullptr: never)
     bool skip_down = false;
-    if (ROWS && MODE == kModeCplx && p.need_down) {
-      const unsigned g8 = f >> 3;
-      const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
-      skip_down = __builtin_amdgcn_readfirstlane((int)p.need_down[s]) == 0;
+    if (ROWS && p.need) {
+      const unsigned cur_need = rows_need;  // of frame f: load_unit has not been called for the next frame yet
+      skip_down = MODE == kModeCplx && !((cur_need >> 8) & 1u);
+      if (!((cur_need >> (f & 7u)) & 1u)) {
+        // An offset the switch cannot look at (an IDLE stream: 3 or 5 of the 8 are evaluated, main.c:447-453): everything the
+        // frame body does besides the transform -- park the next group's id, prefetch, drain the ring at a group start,
+        // one zero ring entry (the record is never read) -- then on to the next frame.  Uniform over the workgroup.
+        if (dyn && (f & gmask) == 0 && j == 0) *next_slot = fetched;
+        // (straight into xp also in the double-buffered build: this frame does not use its samples, and whatever is already
+        // requested for a later unit of the row sits in xp -- the tail's copy from xq has run, or the first load went there)
+        if (has_next) load_unit(fnext, xp);
+        if ((f & gmask) == 0) {
+          // a group starts here: the parked id must be visible to both waves before the group's last frame reads it, and
+          // the previous group's ring entries are drained (behind a barrier, as in the frame body).  Elsewhere in a group
+          // the passed-over frame needs no barrier at all: wave 1 has nothing to do in it.
+          __syncthreads();
+          if (ring_n > 0) {
+            if (wave == 0) finalise(ring_f0, ring_n);
+            ring_f0 = f;
+            ring_n = 0;
+            __syncthreads();  // (the finaliser reads slot 0 before the entry below overwrites it)
+          }
+        }
+        if (wave == 0 && lane < kRingStride) ring[ring_n * kRingStride + lane] = 0.f;
+        ring_n++;
+        if (!has_next) break;
+        if (dyn && (fnext & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);
+        f = fnext;
+        continue;
+      }
     }
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {

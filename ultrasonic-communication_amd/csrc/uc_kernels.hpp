@@ -55,8 +55,9 @@ struct BandParams {
   const void* prev;
   size_t row_pitch, prev_pitch, prev_half;
   const unsigned int* parity;
-  const uint32_t* need_down;  // SYNC_CPLX, one-block calls of a live state: [rows] 0 = the row's stream is IDLE, its new
-                              // offsets need the UP transform only (main.c:447-451); nullptr = both transforms for every row
+  const uint32_t* need;       // one-block calls of a live state: [rows] what the switch can still look at of the row's NEW
+                              // block -- bits 0 .. 7: FIFO offset m = 1 .. 8 is needed, bit 8: the DOWN statistics are needed
+                              // (uc_rx.hpp: RxParams::need; main.c:447-451).  nullptr = everything for every row
   uint32_t save;
   uint32_t row_blocks;
   uint32_t div_magic, div_shift;  // u / row_blocks for u < 2^31: (mulhi(u, div_magic) + u) >> div_shift (uc::rows_divisor)

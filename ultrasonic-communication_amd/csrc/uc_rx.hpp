@@ -67,9 +67,14 @@ struct RxParams {
   // live streams: the word that says which half of the state's newest-block store is current (uc_kernels.hpp: BandParams);
   // the replay flips it on its way out -- the band launch in front of it has filled the other half.  nullptr: none.
   unsigned int* parity;
-  // live streams: [n_streams] words the replay leaves for the NEXT call's band launch: 0 = the stream is IDLE after this call
-  // (the complex receiver's acquisition needs the UP transform only), 1 = every other state.  nullptr: none.
-  uint32_t* need_down;
+  // live streams: [n_streams] words the replay leaves for the NEXT call's band launch (one-block calls use them): what main()
+  // can still look at of the stream's next block.  While a stream is IDLE the acquisition pass evaluates 4 positions a block,
+  // the UP reference only, alternating between two interleaved sets (`turn`, main.c:447-453): of the 8 offsets the next block
+  // adds, the pass of THAT block reads those <= 11 of its set, the pass of the block after it those >= 12 of the other set, and
+  // nothing later can read them (SYNCHRONIZED is three evaluations = five blocks away; by then the block has left the FIFO):
+  //   turn 0: offsets m = 2, 5, 7 (0x052)    turn 1: m = 1, 3, 4, 6, 8 (0x0AD)    bit 8 (DOWN statistics): 0
+  // every other state: 0x1FF.  nullptr: none.
+  uint32_t* need;
 };
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);

@@ -92,6 +92,12 @@ constexpr int kStateWords = (int)((sizeof(SeqLoop) + 3) / 4);
 constexpr int kImageWords = kStateWords + 1;
 static_assert(sizeof(SeqLoop) % 4 == 0, "main()'s locals are whole words");
 
+// what the switch can still look at of a stream's NEXT block (uc_rx.hpp: RxParams::need)
+__device__ __forceinline__ uint32_t need_word(int state, uint32_t turn) {
+  if (state != UC_STATE_IDLE) return 0x1FFu;
+  return turn ? 0x0ADu : 0x052u;
+}
+
 // main()'s loop, one lane per stream
 __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
     p.loop_state[s * kImageWords + kStateWords] = block_base + p.nb;
   }
   if (p.parity && s == 0) *p.parity ^= 1u;  // (nothing of this launch reads it)
-  if (p.need_down) p.need_down[s] = loop.state() != UC_STATE_IDLE ? 1u : 0u;
+  if (p.need) p.need[s] = need_word(loop.state(), loop.turn());
   if (p.carry_out && count) {
     // the FIFO after the call's last accepted block: its last 9 records are what the next block's FIFO starts with
     float2 keep[9];
@@ -256,7 +262,7 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
     if (p.n_trace) p.n_trace[s] = nt;
     loop_mem[kStateWords] = block_base + p.nb;
     if (p.parity && s == 0) *p.parity ^= 1u;  // (nothing of this launch reads it)
-    if (p.need_down) p.need_down[s] = loop.state() != UC_STATE_IDLE ? 1u : 0u;
+    if (p.need) p.need[s] = need_word(loop.state(), loop.turn());
   }
   __syncthreads();
   if (p.loop_state && lane < kImageWords) p.loop_state[s * kImageWords + lane] = loop_mem[lane];
