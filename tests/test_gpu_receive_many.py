@@ -275,6 +275,35 @@ def test_live_step_captured_into_a_graph_and_replayed_block_after_block(uchirp, 
     e.close()
 
 
+@pytest.mark.parametrize("env", [{"UC_GRID": "5"}, {"UC_GRID": "3", "UC_BAND_GROUP": "1"}, {"UC_BAND_GROUP": "2"},
+                                 {"UC_BAND_GROUP": "4", "UC_GRID": "64"}, {"UC_STATIC_DEAL": "1", "UC_BAND_GROUP": "8"}, {"UC_GRID": "1"}])
+def test_live_receivers_under_odd_launch_geometries(uchirp, monkeypatch, env):
+    """The ROWS build passes over the offsets an IDLE stream's switch cannot look at; the frame loop's bookkeeping (the parked
+    group id, the ring drain at a group start, the loads handed on to the row's next needed unit) must hold for every group
+    size and grid -- groups of one or two units that are passed over entirely, a single workgroup, tickets and the static deal.
+    One block per call, both receivers, against the recorded call (which evaluates everything)."""
+    monkeypatch.setenv("UC_TUNING", "1")
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    x, busy, msgs = _transmissions(21, seed=123, blocks=130)
+    for variant in (uco.RX_REAL, uco.SYNC_CPLX):
+        e = uchirp.Engine(variant)
+        whole_t, whole_tr = e.receive_many(x)
+        live = e.live(x.shape[0])
+        texts, traces = [""] * x.shape[0], [[] for _ in range(x.shape[0])]
+        for b in range(130):
+            t, tr = live.next(np.ascontiguousarray(x[:, b * N:(b + 1) * N]))
+            for s in range(x.shape[0]):
+                texts[s] += t[s]
+                traces[s].append(tr[s])
+        for s in range(x.shape[0]):
+            assert texts[s] == whole_t[s], (env, variant, s)
+            assert np.array_equal(np.concatenate(traces[s]).view(np.uint8), whole_tr[s].view(np.uint8)), (env, variant, s)
+        assert e.busy_counters() == 0
+        live.close()
+        e.close()
+
+
 def test_plain_c_host_runs_live_microphones(tmp_path):
     """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
     call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream
