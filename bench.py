@@ -710,6 +710,36 @@ def receive_leg(args, device, torch):
             del chunks, pdm
         eng.close()
         del x, text, ntext
+    # the shipping receiver (RX_REAL) LIVE at the scale one GPU serves: 65 536 microphones, one new block each per call, back
+    # to back.  Silent microphones here (noise: 94 GB would be needed for a transmission in every stream): an IDLE stream's
+    # switch can look at 3 or 5 of the 8 offsets its new block adds (main.c:447-453), and only those are evaluated; a stream in
+    # a tracking state costs all 8 (1.0 ms per block at this size, profiles/r05_live_async.txt)
+    ns = 65536
+    eng = uchirp.Engine(uchirp.RX_REAL, device=device.index)
+    live = eng.live(ns)
+    g = torch.Generator(device=device)
+    g.manual_seed(99)
+    bufs = [torch.randn((ns, N), generator=g, device=device) * 50.0 for _ in range(3)]
+    text = torch.zeros((ns, 8), dtype=torch.uint8, device=device)
+    ntext = torch.zeros(ns, dtype=torch.int32, device=device)
+    side = torch.cuda.Stream(device)
+    with torch.cuda.stream(side):
+        for k in range(12):
+            live.next_into(bufs[k % 3], text, ntext, stream=side.cuda_stream)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(side)
+        for k in range(60):
+            live.next_into(bufs[k % 3], text, ntext, stream=side.cuda_stream)
+        e1.record(side)
+        e1.synchronize()
+    ms = e0.elapsed_time(e1) / 60
+    live.close()
+    eng.close()
+    out["live_idle_rx_real_65536_streams"] = {"streams": ns, "ms_per_call_back_to_back": ms, "real_time_ms_per_call": N / fs * 1e3,
+                                              "microphones_served_in_real_time": int(ns * N / fs / (ms * 1e-3)),
+                                              "what": "uc_receive_streams_next, one new block of each of 65 536 silent microphones "
+                                                      "per call (IDLE streams: 3 or 5 of the 8 new FIFO offsets are evaluated)"}
+    del bufs
     return out
 
 
