@@ -341,8 +341,10 @@ __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
 // ROWS: the frames are the FIFO offsets a new block adds to a live receiver (uc_receive_streams[_next]; BandParams: `prev`,
 // row_pitch ...): every frame is the tail of one block followed by the head of the next, two base addresses, the split a
 // multiple of 256 samples -- which is a whole number of this kernel's 128-sample load instructions, so each load takes one
-// of two buffer resources by a SCALAR select and nothing is ever copied together.  A separate instantiation again: the
-// batch builds carry none of it.
+// of two buffer resources by a SCALAR select and nothing is ever copied together.  The m = 8 frame of a row's last block IS
+// that block and stores it for the next call on its way through (p.save); one-block calls of live receivers pass over the
+// offsets an IDLE stream's switch cannot look at (p.need: 3 or 5 of the 8, main.c:447-453).  A separate instantiation again:
+// the batch builds carry none of it.
 // FRAMES = 2 (OVERLAP): the batch addressing over frames that OVERLAP (stride < n: the reference's own FIFO reads, main.c:447-451,
 // 256 or 512 samples apart): the same loads with the default cache policy instead of `nt` -- with `nt` a frame's bytes are
 // fetched again by each of the up to 8 frames that share them (6384 instead of 1025 B of HBM traffic per frame at stride 256),
