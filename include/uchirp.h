@@ -323,9 +323,10 @@ int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_str
  * uc_receive_streams_next() is uc_receive_streams() for the NEXT n_samples (whole blocks) of every stream: the chunks of a
  * stream, of any sizes, give exactly the text and trace of the whole stream in one call (trace records carry stream-global
  * block indices; `text` receives the characters decoded during THIS call).  busy as in uc_receive_streams (flags of this
- * chunk's blocks).  One new block of every stream costs at most 8 transforms per stream and reference (a stream that is IDLE
- * when its block arrives, in a one-block call: the 3 - 5 of the 8 offsets acquisition can still look at, the UP reference only,
- * receiver/Src/main.c:447-453), 2 kernel launches (5 with a busy mask, +2 for UC_DTYPE_PDM), no copy.
+ * chunk's blocks).  One new block of every stream costs at most 8 transforms per stream and reference; one-block calls evaluate
+ * only the offsets main()'s switch can still look at -- an IDLE stream the 3 - 5 of the 8 that acquisition reaches, the UP
+ * reference only (receiver/Src/main.c:447-453), a SYNCHRONIZED / DATA_RECEIVING stream the 5 - 6 around its sync_position
+ * (main.c:491-550, 243-273) --, 2 kernel launches (5 with a busy mask, +2 for UC_DTYPE_PDM), no copy.
  * Everything a step carries lives on the device, so with device pointers the call can be captured into a hipGraph and the
  * graph replayed for every block that arrives (make one eager call of the same shape first: it sizes the scratch; nothing is
  * allocated during a capture; uc_rx_state_reset puts the receivers back to power-on).

@@ -304,6 +304,34 @@ def test_live_receivers_under_odd_launch_geometries(uchirp, monkeypatch, env):
         e.close()
 
 
+@pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX])
+def test_what_live_receivers_pass_over_is_never_looked_at(uchirp, monkeypatch, variant):
+    """One-block live calls evaluate only the FIFO offsets main()'s switch can still look at: an IDLE stream 3 or 5 of the 8 its
+    new block adds, the UP reference only (main.c:447-453); a SYNCHRONIZED / DATA_RECEIVING stream the positions around its
+    sync_position now and one block on, plus the acquisition set it would fall back to (main.c:491-550, 243-273).  Under the tests'
+    poison switch everything that is passed over gets a HUGE statistic instead of zero: a switch that looked at one of them would
+    lock, move or decode differently.  Texts and traces still equal the recorded call (which evaluates everything), bit for bit."""
+    monkeypatch.setenv("UC_TUNING", "1")
+    monkeypatch.setenv("UC_RX_POISON", "1")
+    x, busy, msgs = _transmissions(48, seed=500 + variant, blocks=170)
+    e = uchirp.Engine(variant)
+    for bz in (None, busy):
+        whole_t, whole_tr = e.receive_many(x, busy=bz)
+        live = e.live(x.shape[0])
+        texts, traces = [""] * x.shape[0], [[] for _ in range(x.shape[0])]
+        for b in range(170):
+            t, tr = live.next(np.ascontiguousarray(x[:, b * N:(b + 1) * N]), busy=None if bz is None else np.ascontiguousarray(bz[:, b:b + 1]))
+            for s in range(x.shape[0]):
+                texts[s] += t[s]
+                traces[s].append(tr[s])
+        for s in range(x.shape[0]):
+            assert texts[s] == whole_t[s], (variant, s)
+            assert np.array_equal(np.concatenate(traces[s]).view(np.uint8), whole_tr[s].view(np.uint8)), (variant, s)
+        live.close()
+    assert sum(m in t for m, t in zip(msgs, whole_t)) >= 5      # (with dropped blocks; tracking states were visited)
+    e.close()
+
+
 def test_plain_c_host_runs_live_microphones(tmp_path):
     """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
     call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream

@@ -137,6 +137,7 @@ struct uc_ctx {
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
   bool cic_tickets = false;
+  bool rx_poison = false;   // (env UC_RX_POISON=1, tests) the statistics the live receivers pass over are huge instead of zero
   int compress_chunk = 8;   // (env UC_COMPRESS_CHUNK) frame pairs per hand-out chunk of the compress kernel: a power of two >= 2
   int stream_chunk = 2;     // (env UC_STREAM_CHUNK) blocks per hand-out chunk of the stream kernel: a power of two
   int iq_group = 16;        // (env UC_IQ_GROUP) frames per hand-out group of the IQ kernels: a power of two <= 64
@@ -341,6 +342,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
       if (v >= 2 && v <= 4) { c->band_waves = v; c->band_waves_set = true; }
     }
     if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
+    if (const char* g = getenv("UC_RX_POISON")) c->rx_poison = atoi(g) != 0;
     if (const char* g = getenv("UC_BAND_GROUP")) {
       const int v = atoi(g);
       if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
@@ -1699,6 +1701,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       // acquisition evaluates 4 positions a block, the UP reference only: a stream that is IDLE when its ONE new block arrives
       // gets the 3 or 5 transforms the switch can still look at (SYNC_CPLX: of the UP reference only) instead of 8
       bp.need = (st && nb == 1) ? st->d_need : nullptr;
+      bp.poison = c->rx_poison ? 1u : 0u;
       bp.row_pitch = row_pitch;
       bp.row_blocks = (uint32_t)nb;
       uc::rows_divisor((uint32_t)nb, &bp.div_magic, &bp.div_shift);

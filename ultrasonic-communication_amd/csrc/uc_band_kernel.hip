@@ -758,7 +758,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             __syncthreads();  // (the finaliser reads slot 0 before the entry below overwrites it)
           }
         }
-        if (wave == 0 && lane < kRingStride) ring[ring_n * kRingStride + lane] = 0.f;
+        // (the entry: zeros -- or, under the tests' poison switch, squared magnitudes no signal reaches: fields 0 .. 3 of each
+        // wave's six words are magnitudes in the complex build, 0 and 1 in the real ones; the others indices or edge values)
+        if (wave == 0 && lane < kRingStride)
+          ring[ring_n * kRingStride + lane] = (p.poison && (lane % 6) < (MODE == kModeCplx ? 4 : 2) && lane < 12) ? 1e30f : 0.f;
         ring_n++;
         if (!has_next) break;
         if (dyn && (fnext & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       if (ROWS && MODE == kModeCplx && run == 1 && skip_down) {  // (uniform over the workgroup: no barrier is left behind)
         float* e = ring + ring_n * kRingStride + wave * 6;
         if (lane == 0) {
-          e[0] = pv[0]; e[1] = pv[1]; e[2] = 0.f; e[3] = 0.f;
+          e[0] = pv[0]; e[1] = pv[1]; e[2] = p.poison ? 1e30f : 0.f; e[3] = e[2];
           e[4] = __uint_as_float(WIDE ? kpw[0] : kpack);
           e[5] = __uint_as_float(WIDE ? 0u : flags);
         }

@@ -59,6 +59,8 @@ struct BandParams {
                               // block -- bits 0 .. 7: FIFO offset m = 1 .. 8 is needed, bit 8: the DOWN statistics are needed
                               // (uc_rx.hpp: RxParams::need; main.c:447-451).  nullptr = everything for every row
   uint32_t save;
+  uint32_t poison;            // tests only (UC_TUNING=1 UC_RX_POISON=1): what is passed over gets a HUGE statistic instead of zero, so that
+                              // a switch that looked at it after all could not fail to show in the trace (tests/test_gpu_receive_many.py)
   uint32_t row_blocks;
   uint32_t div_magic, div_shift;  // u / row_blocks for u < 2^31: (mulhi(u, div_magic) + u) >> div_shift (uc::rows_divisor)
 };

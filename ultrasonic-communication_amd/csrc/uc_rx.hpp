@@ -73,7 +73,10 @@ struct RxParams {
   // adds, the pass of THAT block reads those <= 11 of its set, the pass of the block after it those >= 12 of the other set, and
   // nothing later can read them (SYNCHRONIZED is three evaluations = five blocks away; by then the block has left the FIFO):
   //   turn 0: offsets m = 2, 5, 7 (0x052)    turn 1: m = 1, 3, 4, 6, 8 (0x0AD)    bit 8 (DOWN statistics): 0
-  // every other state: 0x1FF.  nullptr: none.
+  // SYNCHRONIZING: 0x1FF (the lock may fall on any position).  SYNCHRONIZED / DATA_RECEIVING at sync_position = 256 ks: the
+  // offsets ks - 1 .. ks + 1 of the next block's pass, ks + 6 .. ks + 10 (= ks - 2 .. ks + 2 one block later, resync moves one
+  // step a block), the acquisition set the stream would use if it fell back to IDLE, and k = 16 when ks <= 3; both references:
+  // 5 or 6 of the 8.  (uc_rx_kernel.hip: need_word.)  nullptr: none.
   uint32_t* need;
 };
 
