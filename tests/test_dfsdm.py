@@ -183,7 +183,7 @@ def test_oracle_silent_history_is_silence():
 @pytest.mark.parametrize("n_streams", [1, 64, 4096])
 def test_sinc5_streams_with_carried_history_bit_exact(uchirp, n_streams):
     """uc_dfsdm_sinc5_streams: many microphones, chunk after chunk, the 4-word filter history of every stream carried in an
-    array the call reads and brings up to date.  Chunks of ANY sizes -- one word, sizes around the 252-output tile, one
+    array the call reads and brings up to date.  Chunks of ANY sizes -- one word, sizes around the tile (256 words; 252 outputs in rounds 1-4), one
     2048-word block, sizes that are not multiples of 4 -- give, stream by stream, exactly the oracle's DFSDM words of the
     whole stream behind its first history; host arrays and device tensors; no stream's output touches its neighbour's."""
     import torch
@@ -255,6 +255,30 @@ def test_sinc5_streams_with_carried_history_bit_exact(uchirp, n_streams):
     # refused: misaligned device rows, overlapping streams
     with pytest.raises(uchirp.UchirpError):
         e.dfsdm_streams(wd[:, 1:7].contiguous()[:, :5].contiguous(), hist_d)     # 5-word rows: stride not a multiple of 4
+    e.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_streams,n_words", [(300000, 8), (5000, 5000), (8192, 2052), (3, 70001), (700, 12292), (1, 600003),
+                                               (4097, 2048), (33, 257)])
+def test_sinc5_segment_geometries(uchirp, n_streams, n_words):
+    """The kernel walks a stream in SEGMENTS of up to 8 tiles of 256 words, one wave per segment, the tile-to-tile carry in
+    scalar registers, and looks up what lies in front of 64 of a wave's segments at once: shapes with more than 64 segments
+    per wave (300 000 short streams), several segments per stream with a short last one (5000, 12 292, 70 001 words), a
+    one-word ninth tile (2052), fewer segments than waves (3 streams: segments shortened to fill the grid), one long ragged
+    stream, 257 words (a second tile of one word).  Random histories; every checked stream bit-exact against the oracle; the
+    history array ends as the last four words of every stream."""
+    e = uchirp.Engine(uchirp.RX_REAL)
+    rng = np.random.default_rng(n_streams * 31 + n_words)
+    w = rng.integers(0, 1 << 32, size=(n_streams, n_words), dtype=np.uint64).astype(np.uint32)
+    hist = rng.integers(0, 1 << 32, size=(n_streams, 4), dtype=np.uint64).astype(np.uint32)
+    hist0 = hist.copy()
+    got = e.dfsdm_streams(w, hist)
+    check = range(n_streams) if n_streams <= 64 else sorted(set(rng.integers(0, n_streams, size=60).tolist()) | {0, n_streams - 1})
+    for s in check:
+        assert np.array_equal(got[s], _sinc5_with_history(w[s], hist0[s])), s
+    tail = np.concatenate([hist0, w], axis=1)[:, -4:]
+    assert np.array_equal(hist, tail)
     e.close()
 
 

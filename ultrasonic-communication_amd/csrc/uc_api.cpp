@@ -136,7 +136,6 @@ struct uc_ctx {
   int grid_override = 0;
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
-  bool cic_tickets = false;
   bool rx_poison = false;   // (env UC_RX_POISON=1, tests) the statistics the live receivers pass over are huge instead of zero
   int compress_chunk = 8;   // (env UC_COMPRESS_CHUNK) frame pairs per hand-out chunk of the compress kernel: a power of two >= 2
   int stream_chunk = 2;     // (env UC_STREAM_CHUNK) blocks per hand-out chunk of the stream kernel: a power of two
@@ -149,8 +148,6 @@ struct uc_ctx {
   bool iq_fir_mfma = false;
   // work counters for the dynamic group hand-out: one word per launch, a ring so that launches of one context that
   // overlap on different streams never share one (each word sits in its own 128-byte line)
-  unsigned int* d_cic_ctr = nullptr;  // sinc5: tile tickets, one word per workgroup x 4 launches
-  size_t cic_ctr_cap = 0;
   unsigned int* d_work = nullptr;
   void* h_slot = nullptr;  // uc_process_frame: pinned, device-mapped host memory for one frame and its results
   unsigned work_next = 0;
@@ -349,7 +346,6 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     }
     if (const char* g = getenv("UC_STATIC_DEAL")) c->static_deal = atoi(g) != 0;
     if (const char* g = getenv("UC_SLOT_EVENTS")) c->multi_stream = atoi(g) != 0;  // record an event behind every launch
-    if (const char* g = getenv("UC_CIC_TICKETS")) c->cic_tickets = atoi(g) != 0;
     if (const char* g = getenv("UC_IQ_FIR")) c->iq_fir_mfma = strcmp(g, "mfma") == 0;
     if (const char* g = getenv("UC_IQ_STAGGER")) c->iq_stagger = (unsigned)atoi(g);
     if (const char* g = getenv("UC_COMPRESS_CHUNK")) {
@@ -464,7 +460,6 @@ void uc_destroy(uc_ctx* c) {
     if (c->work_ev[i]) (void)hipEventDestroy(c->work_ev[i]);
   if (c->switch_ev) (void)hipEventDestroy(c->switch_ev);
   if (c->h_slot) (void)hipHostFree(c->h_slot);
-  if (c->d_cic_ctr) (void)hipFree(c->d_cic_ctr);
   if (c->d_aux) (void)hipFree(c->d_aux);
   if (c->d_cic4) (void)hipFree(c->d_cic4);
   if (c->d_cic1) (void)hipFree(c->d_cic1);
@@ -1096,10 +1091,13 @@ static int sinc5_prepare(uc_ctx* c) {
 }
 
 // uc_dfsdm_sinc5_streams on device buffers: n_words NEW words of every stream, history carried in d_hist ([n_streams][4])
+// (update_hist false: d_hist is only read -- uc_dfsdm_sinc5, where it is the head of the caller's input)
 static int sinc5_streams_launch(uc_ctx* c, const uint32_t* d_pdm, size_t n_streams, size_t n_words, size_t stride,
-                                uint32_t* d_hist, int32_t* d_out, size_t out_stride, hipStream_t stream) {
+                                const uint32_t* d_hist, bool update_hist, int32_t* d_out, size_t out_stride,
+                                hipStream_t stream) {
   if (n_streams == 0 || n_words == 0) return 0;
-  if ((((uintptr_t)d_pdm | (uintptr_t)d_out | (uintptr_t)d_hist) & 15u) != 0 || (stride & 3u) != 0 || (out_stride & 3u) != 0)
+  if ((((uintptr_t)d_pdm | (uintptr_t)d_out | (uintptr_t)d_hist) & 15u) != 0 ||
+      (n_streams > 1 && ((stride & 3u) != 0 || (out_stride & 3u) != 0)))
     return fail(-EINVAL, "uc_dfsdm_sinc5_streams: device buffers must be 16-byte aligned and the strides multiples of 4 words");
   if (int rc = sinc5_prepare(c)) return rc;
   uc::CicParams cp;
@@ -1113,14 +1111,24 @@ static int sinc5_streams_launch(uc_ctx* c, const uint32_t* d_pdm, size_t n_strea
   cp.stride = stride;
   cp.out_stride = out_stride;
   cp.hist = d_hist;
-  const size_t tps = (n_words + 251) / 252;  // (uc::sinc5_tile_outputs() / waves per block: 252 outputs per tile)
-  if (tps * n_streams >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_dfsdm_sinc5_streams: too many tiles in one call");
-  cp.tps = (uint32_t)tps;
-  uc::rows_divisor(cp.tps, &cp.div_magic, &cp.div_shift);
+  cp.update_hist = update_hist ? 1u : 0u;
   size_t grid = (size_t)c->num_cu * (size_t)c->cic_blocks_per_cu;
   if (c->grid_override > 0) grid = (size_t)c->grid_override;
   const size_t per_block = (size_t)uc::sinc5_waves_per_block();
-  const size_t need = (tps * n_streams + per_block - 1) / per_block;
+  // Tiles of 256 words; one wave walks a SEGMENT of up to 8 tiles front to back (uc_cic_kernel.hip).  A live block (2048
+  // words) is one segment.  Few streams: shorter segments, so that every wave of the grid has one.
+  const size_t tiles = (n_words + 255) / 256;
+  size_t nseg = (tiles + 7) / 8;
+  const size_t spread = (grid * per_block + n_streams - 1) / n_streams;  // segments per stream that fill the grid
+  if (nseg < spread) nseg = spread < tiles ? spread : tiles;
+  const size_t tps = (tiles + nseg - 1) / nseg;
+  nseg = (tiles + tps - 1) / tps;
+  if (nseg * n_streams >= ((size_t)1 << 31)) return fail(-EINVAL, "uc_dfsdm_sinc5_streams: too many segments in one call");
+  cp.tps = (uint32_t)tps;
+  cp.nseg = (uint32_t)nseg;
+  cp.units = (uint32_t)(nseg * n_streams);
+  uc::rows_divisor(cp.nseg, &cp.div_magic, &cp.div_shift);
+  const size_t need = ((size_t)cp.units + per_block - 1) / per_block;
   if (grid > need) grid = need;
   if (c->clock_probe) {
     if (c->clk_cic_blocks == 0) c->clk_cic_blocks = uc::clk::sinc5_max_blocks_per_cu();  // (the twin needs the same LDS opt-in)
@@ -1169,7 +1177,7 @@ int uc_dfsdm_sinc5_streams(uc_ctx* c, const uint32_t* pdm_words, size_t n_stream
     if (int rc = c->s_cic_out.ensure(n_streams * o_stride * 4)) return rc;
     d_out = (int32_t*)c->s_cic_out.p;
   }
-  if (int rc = sinc5_streams_launch(c, d_in, n_streams, n_words, in_stride, d_hist, d_out, o_stride, stream)) return rc;
+  if (int rc = sinc5_streams_launch(c, d_in, n_streams, n_words, in_stride, d_hist, true, d_out, o_stride, stream)) return rc;
   if (out_host || hist_host) {
     if (out_host) {
       e = hipMemcpy2DAsync(words_out, out_stride_words * 4, d_out, o_stride * 4, n_words * 4, n_streams, hipMemcpyDeviceToHost, stream);
@@ -1192,7 +1200,6 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
   hipStream_t stream = (hipStream_t)hip_stream;
-  if (int prc = sinc5_prepare(c)) return prc;
   const size_t n_out = n_words - 4;
   const uint32_t* d_in = pdm_words;
   if (!is_device_ptr(pdm_words)) {
@@ -1213,44 +1220,8 @@ int uc_dfsdm_sinc5(uc_ctx* c, const uint32_t* pdm_words, size_t n_words, int32_t
   } else if (((uintptr_t)words_out & 15u) != 0) {
     return fail(-EINVAL, "uc_dfsdm_sinc5: a device `words_out` pointer must be 16-byte aligned");
   }
-  uc::CicParams cp;
-  memset(&cp, 0, sizeof(cp));
-  cp.pdm = d_in;
-  cp.n_words = n_words;
-  cp.out = d_out;
-  cp.t4 = c->d_cic4;
-  cp.t1 = c->d_cic1;
-  cp.ctr = nullptr;
-  cp.debug = nullptr;
-  size_t grid = (size_t)c->num_cu * (size_t)c->cic_blocks_per_cu;
-  if (c->grid_override > 0) grid = (size_t)c->grid_override;
-  const size_t need = (n_out + uc::sinc5_tile_outputs() - 1) / uc::sinc5_tile_outputs();
-  if (grid > need) grid = need;
-  if (c->cic_tickets) {
-    // (opt-in, env UC_CIC_TICKETS=1: measured no faster than the static deal, profiles/r02_sinc5_notes.txt)
-    // EXPERIMENT ONLY (needs UC_TUNING=1): the ring below is not guarded by events as take_work_counter's is -- at most
-    // four sinc5 launches of one context may overlap in this mode.  The default (static deal) has no such limit.
-    // ticket counters of this launch (one per workgroup), zeroed on the stream right before it
-    const size_t bytes = grid * sizeof(unsigned int);
-    if (bytes > c->cic_ctr_cap) {
-      if (c->d_cic_ctr) (void)hipFree(c->d_cic_ctr);
-      c->d_cic_ctr = nullptr;
-      c->cic_ctr_cap = 0;
-      e = hipMalloc((void**)&c->d_cic_ctr, 4 * bytes);   // a ring of four launches (overlapping streams)
-      if (e != hipSuccess) return hip_fail(e, "hipMalloc(sinc5 tickets)");
-      c->cic_ctr_cap = bytes;
-    }
-    cp.ctr = c->d_cic_ctr + (size_t)(c->work_next++ % 4) * grid;
-    e = hipMemsetAsync(cp.ctr, 0, bytes, stream);
-    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(sinc5 tickets)");
-  }
-  if (c->clock_probe) {
-    if (c->clk_cic_blocks == 0) c->clk_cic_blocks = uc::clk::sinc5_max_blocks_per_cu();  // (the twin needs the same LDS opt-in)
-    if (c->clk_cic_blocks <= 0) return fail(-ENOMEM, "uc_dfsdm_sinc5: the clock-stamped kernel's LDS tables do not fit");
-    if (int crc = clock_buffer(c, grid, uc::clk::sinc5_waves_per_block(), stream, &cp.debug)) return crc;
-  }
-  int lrc = (c->clock_probe ? uc::clk::launch_sinc5 : uc::launch_sinc5)(cp, (int)grid, stream);
-  if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "sinc5 kernel launch");
+  // one stream whose history lies in front of it: words 0 .. 3 are the history, words 4 .. the stream
+  if (int rc = sinc5_streams_launch(c, d_in + 4, 1, n_out, n_out, d_in, false, d_out, n_out, stream)) return rc;
   if (host_out) {
     e = hipMemcpyAsync(words_out, d_out, n_out * 4, hipMemcpyDeviceToHost, stream);
     if (e != hipSuccess) return hip_fail(e, "hipMemcpyAsync(words_out)");
@@ -1644,7 +1615,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
         if (e != hipSuccess) return hip_fail(e, "hipMemsetD32Async(pdm history)");
       }
       if (int rc = sc.pcm.ensure(n_streams * nb * (size_t)n * 4)) return rc;
-      if (int rc = sinc5_streams_launch(c, (const uint32_t*)d_in, n_streams, nb * (size_t)n, stream_stride_elems, d_hist,
+      if (int rc = sinc5_streams_launch(c, (const uint32_t*)d_in, n_streams, nb * (size_t)n, stream_stride_elems, d_hist, true,
                                         (int32_t*)sc.pcm.p, nb * (size_t)n, stream))
         return rc;
       d_in = sc.pcm.p;

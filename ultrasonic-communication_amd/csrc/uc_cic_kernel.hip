@@ -11,8 +11,10 @@
 // the contribution of that byte to each of the five outputs the word takes part in (a 20 KiB
 // table in LDS: [byte position][byte value] -> 5 partial sums, read as one b128 + one b32), adds
 // them up, and passes the four partial sums that belong to the NEXT lane's outputs along with one
-// DPP wave shift each.  A wave covers 256 words and stores 252 outputs (lane 0 only feeds lane 1:
-// its own outputs belong to the previous tile), coalesced 16-byte stores.
+// DPP wave shift each.  A wave covers a tile of 256 words and stores 256 outputs, coalesced 16-byte
+// stores; what the tile's last four words add to the next tile travels in four SGPRs (the same wave
+// works on that tile next), what lies in front of a wave's first tile is looked up for 64 such
+// places at once.
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 
@@ -20,15 +22,14 @@ namespace uc {
 
 namespace {
 
-#ifndef UC_CIC_KNOCK
-#define UC_CIC_KNOCK 0  // diagnostic builds: 1 = no stores, 2 = no HBM reads (profiles/r02_sinc5_notes.txt)
+#ifndef UC_CIC_LOAD_CPOL
+#define UC_CIC_LOAD_CPOL UC_STREAM_CPOL
 #endif
 #ifndef UC_CIC_THREADS
 #define UC_CIC_THREADS 1024
 #endif
 constexpr int TC = UC_CIC_THREADS;  // one workgroup per CU shares one set of tables
-constexpr int kTileWords = 256;     // words one wave loads
-constexpr int kTileOut = 252;       // outputs one wave stores
+constexpr int kTileWords = 256;     // words one wave loads = outputs it stores
 // The lookups are indexed by DATA bytes, so with a plain table the bank a lane hits is random (58 % of the LDS
 // cycles were bank conflicts, r01).  Here the bank is a function of the LANE alone:
 //   * every entry is replicated (4 times in the 16-byte table, 8 times in the 4-byte table), a lane reads replica
@@ -57,28 +58,27 @@ __device__ __forceinline__ const __attribute__((address_space(3))) V* lds_at(uns
   return reinterpret_cast<const __attribute__((address_space(3))) V*>(static_cast<uintptr_t>(byte_address));
 }
 
-// value of lane - 1 (lane 0 receives 0)
-__device__ __forceinline__ int from_prev_lane(int v) {
-  return __builtin_amdgcn_update_dpp(0, v, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+// what every lane carries: step i of a word handles byte b = (i + (lane >> 3)) & 3.  Both addresses of a
+// step are v_perm_b32(word, constant, selector): byte 0 and byte 2 from the lane's constant (slot inside the row, table
+// base), byte 1 = data byte b, byte 3 = 0.
+struct Steer {
+  unsigned sel[4], c4[4], c1[4];
+};
+__device__ __forceinline__ Steer make_steer(int lane) {
+  Steer st;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const unsigned b = (unsigned)(i + (lane >> 3)) & 3u;
+    st.sel[i] = 0x0c020000u | ((4u + b) << 8);              // {0, const.byte2, word.byte b, const.byte0}
+    st.c4[i] = (4u * b + ((unsigned)lane & 3u)) << 4;
+    st.c1[i] = (unsigned)kT1Base | ((8u * b + ((unsigned)lane & 7u)) << 2);
+  }
+  return st;
 }
 
-// MULTI (uc_dfsdm_sinc5_streams): many microphones at once, the filter history of every one CARRIED between calls instead
-// of lying in front of the samples.  Stream s = p.n_words new words at p.pdm + s * p.stride, its four history words at
-// p.hist + 4 s, its p.n_words outputs at p.out + s * p.out_stride.  A stream is cut into tiles of 252 outputs as the single
-// stream is; tile T = (stream T / tps, tile T % tps); lane 0 of a stream's FIRST tile takes its four words from the
-// history array (a second, 16-byte resource: every other lane is out of its range and reads zeros, lane 0 is out of range
-// of the sample resource -- the two loads are OR-ed, no branch), everything behind the load is the single-stream code.
-// (The history array is brought up to date by hist_kernel behind this launch: no tile reads what another one writes.)
-template <bool MULTI>
-__global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
-#ifdef UC_CLOCKSTAMP
-  const unsigned long long clk0_ = __builtin_readcyclecounter();
-  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
-#endif
-  extern __shared__ __attribute__((aligned(16))) unsigned char cic_lds[];
-  if ((unsigned)reinterpret_cast<uintptr_t>(cic_lds) != 0u) __builtin_trap();  // (low half of a flat LDS address = the LDS offset)
-  // entry e = 256 b + v of the host tables -> the replicated, bank-steered LDS layout.  The -2^24 of
-  // y = 2 B - 2^25 rides in the table: every output sums exactly one "word m, byte 0, output m" entry.
+// entry e = 256 b + v of the host tables -> the replicated, bank-steered LDS layout.  The -2^24 of y = 2 B - 2^25 rides in
+// the table: every output sums exactly one "word m, byte 0, output m" entry.
+__device__ __forceinline__ void fill_tables(const CicParams& p, unsigned char* cic_lds) {
   for (int i = threadIdx.x; i < 1024 * R1; i += TC) {
     const int e = i >> 3, r = i & 7, b = e >> 8, v = e & 255;
     if (r < R4) {
@@ -89,183 +89,169 @@ __global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
     *reinterpret_cast<int*>(cic_lds + kT1Base + v * 256 + (8 * b + r) * 4) = p.t1[e];
   }
   __syncthreads();
+}
+
+// The lookups of a lane's four words w: y[k] = what they add to the lane's own output k, c[k] = what they add to output k
+// of the NEXT four words (the next lane's, or the next tile's first lane's).
+__device__ __forceinline__ void lookups(const v4u w, const Steer& st, int y[4], int c[4]) {
+  const unsigned wd[4] = {w.x, w.y, w.z, w.w};
+  int g[4][5];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const v4i q = *lds_at<v4i>(__builtin_amdgcn_perm(wd[k], st.c4[i], st.sel[i]));
+      a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
+      a4 += *lds_at<int>(__builtin_amdgcn_perm(wd[k], st.c1[i], st.sel[i]));
+    }
+    g[k][0] = a0; g[k][1] = a1; g[k][2] = a2; g[k][3] = a3; g[k][4] = a4;
+    if (k & 1) __builtin_amdgcn_sched_barrier(0);  // two words' lookups (16 reads, 40 result registers) at a time
+  }
+  y[0] = g[0][0];
+  y[1] = g[1][0] + g[0][1];
+  y[2] = g[2][0] + g[1][1] + g[0][2];
+  y[3] = g[3][0] + g[2][1] + g[1][2] + g[0][3];
+  c[0] = g[3][1] + g[2][2] + g[1][3] + g[0][4];
+  c[1] = g[3][2] + g[2][3] + g[1][4];
+  c[2] = g[3][3] + g[2][4];
+  c[3] = g[3][4];
+}
+
+// B = sum of the taps that met a 1 bit: y = 2 B - 2^25; result = clip(y >> 2) << 8  (bsum = B - 2^24: see fill_tables)
+__device__ __forceinline__ unsigned word24(int bsum) {
+  int v = bsum >> 1;
+  v = v > 8388607 ? 8388607 : v;
+  v = v < -8388608 ? -8388608 : v;
+  return (unsigned)(v * 256);
+}
+
+// Streams s = 0 .. p.n_streams - 1: p.n_words new words at p.pdm + s * p.stride, the four words in front of them -- the
+// filter history, CARRIED between calls instead of lying in front of the samples -- at p.hist + 4 s, p.n_words outputs at
+// p.out + s * p.out_stride.  (uc_dfsdm_sinc5, one recorded stream whose first four words are its history, is the case
+// n_streams = 1, hist = the buffer, pdm = the buffer + 4.)
+//
+// No overlap between tiles: a live block is 2048 words = EIGHT tiles of 256 (tiles that overlap by the four words of
+// history, rounds 1-4, made it eight tiles of 252 and a ninth that carried 32: 11 % of the lookups on lanes without
+// outputs).  A stream is cut into SEGMENTS of p.tps tiles (<= 8) and ONE wave walks a segment front to back: what the last
+// four words of a tile add to the next four outputs (lane 63's c[]) goes to lane 0 of the next tile through four SGPRs.
+// What the four words IN FRONT of a segment add to its first four outputs -- the carried history (segment 0) or the tail
+// of the segment before -- a wave works out for 64 of its segments at a time, one per lane (the boundary pass: one extra
+// tile's worth of lookups per 64 segments), and hands to lane 0 of each segment's first tile with a v_readlane.
+// Segments are dealt statically: wave w of W takes segments w, w + W, ...  (The history array is brought up to date by
+// hist_kernel behind this launch: no wave reads what another one writes.)
+__global__ __launch_bounds__(TC) void sinc5_kernel(const CicParams p) {
+#ifdef UC_CLOCKSTAMP
+  const unsigned long long clk0_ = __builtin_readcyclecounter();
+  const unsigned long long rt0_ = __builtin_amdgcn_s_memrealtime();
+#endif
+  extern __shared__ __attribute__((aligned(16))) unsigned char cic_lds[];
+  if ((unsigned)reinterpret_cast<uintptr_t>(cic_lds) != 0u) __builtin_trap();
+  fill_tables(p, cic_lds);
 
   const int lane = threadIdx.x & 63;
-  // step i of a word: byte b = (i + (lane >> 3)) & 3.  Both addresses are v_perm_b32(word, constant, selector):
-  // byte 0 and byte 2 from the lane's constant (slot inside the row, table base), byte 1 = data byte b, byte 3 = 0.
-  unsigned sel[4], c4[4], c1[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const unsigned b = (unsigned)(i + (lane >> 3)) & 3u;
-    sel[i] = 0x0c020000u | ((4u + b) << 8);              // {0, const.byte2, word.byte b, const.byte0}
-    c4[i] = (4u * b + ((unsigned)lane & 3u)) << 4;
-    c1[i] = (unsigned)kT1Base | ((8u * b + ((unsigned)lane & 7u)) << 2);
-  }
-  const size_t n_out = MULTI ? p.n_words : p.n_words - 4;  // (MULTI: per stream)
-  const size_t tiles = MULTI ? (size_t)p.tps * p.n_streams : (n_out + kTileOut - 1) / kTileOut;
-  // MULTI: tile -> (stream, tile of the stream), tile < 2^31
-  auto split = [&](size_t tile, size_t& s, size_t& t) {
-    const unsigned u = (unsigned)tile;
-    const unsigned q = (__umulhi(u, p.div_magic) + u) >> p.div_shift;
-    s = q;
-    t = u - q * p.tps;
+  const Steer st = make_steer(lane);
+  const unsigned W = gridDim.x * (unsigned)(TC / 64);
+  const unsigned wave = blockIdx.x * (unsigned)(TC / 64) + (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const unsigned mine = wave < p.units ? (p.units - wave + W - 1) / W : 0;  // segments of this wave: wave + i W, i < mine
+  const unsigned tp = p.tps;
+  // segment u -> (stream, segment of the stream); u < 2^31
+  auto split = [&](unsigned u, unsigned& s, unsigned& g) {
+    s = (__umulhi(u, p.div_magic) + u) >> p.div_shift;
+    g = u - s * p.nseg;
   };
-  // (readfirstlane: the compiler cannot see that threadIdx.x >> 6 is the same in every lane; without it the tile
-  // index, the buffer resources and all the 64-bit address arithmetic live in VGPRs and every buffer access is
-  // wrapped in a waterfall loop)
-  const size_t wave0 = (size_t)blockIdx.x * (TC / 64) + (size_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const size_t nwaves = (size_t)gridDim.x * (TC / 64);
+  // tile slot j of this wave's i-th segment: where its words and outputs lie and how many there are (0: none -- the
+  // slot lies behind the end of the stream, or the wave has run out of segments)
+  struct Slot {
+    const uint32_t* in;
+    int32_t* out;
+    int recs;
+  };
+  auto slot = [&](unsigned i, unsigned j) -> Slot {
+    Slot r{p.pdm, p.out, 0};
+    if (i < mine) {
+      unsigned s, g;
+      split(wave + i * W, s, g);
+      const size_t first = ((size_t)g * tp + j) * kTileWords;
+      if (first < p.n_words) {
+        const size_t left = p.n_words - first;
+        r.recs = left < (size_t)kTileWords ? (int)left : kTileWords;
+        r.in = p.pdm + (size_t)s * p.stride + first;
+        r.out = p.out + (size_t)s * p.out_stride + first;
+      }
+    }
+    return r;
+  };
+  auto advance = [&](unsigned& i, unsigned& j) {
+    if (++j == tp) {
+      j = 0;
+      i++;
+    }
+  };
+  // words 4 lane .. 4 lane + 3 of a slot; behind the end of the stream (and in an empty slot) the resource returns 0
+  auto load = [&](unsigned i, unsigned j) -> v4u {
+    const Slot t = slot(i, j);
+    const __amdgpu_buffer_rsrc_t rin = make_rsrc(t.in, t.recs * 4);
+    return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, UC_CIC_LOAD_CPOL);
+  };
 
-  // words base + 4 lane .. + 3 of a tile; past the end of the buffer the resource returns 0 (those outputs
-  // are not stored), and so does a tile beyond the last one
-  auto load_tile = [&](size_t tile) -> v4u {
-    if constexpr (MULTI) {
-      if (tile >= tiles) return v4u{0u, 0u, 0u, 0u};
-      size_t s, t;
-      split(tile, s, t);
-      const uint32_t* stream = p.pdm + s * p.stride;
-      if (t == 0) {
-        // words -4 .. -1 of the stream are its carried history: lane 0 reads them, lanes 1 .. 63 read words 4 (lane - 1) ..
-        const int recs = p.n_words < (size_t)kTileOut ? (int)p.n_words : kTileOut;
-        const __amdgpu_buffer_rsrc_t rin = make_rsrc(stream, recs * 4);
-        const __amdgpu_buffer_rsrc_t rh = make_rsrc(p.hist + 4 * s, 16);
-        const v4u a = __builtin_amdgcn_raw_buffer_load_b128(rin, (lane - 1) * 16, 0, UC_STREAM_CPOL);
-        const v4u h = __builtin_amdgcn_raw_buffer_load_b128(rh, lane * 16, 0, 0);
-        return a | h;
+  int cin[4] = {0, 0, 0, 0};    // lane l: what lies in front of segment (i & ~63) + l adds to its first four outputs
+  int carry[4] = {0, 0, 0, 0};  // scalars: lane 63's c[] of the tile before
+  unsigned il = 0, jl = 0;      // the slot of the next load: two ahead of the one being worked on
+  unsigned i = 0, j = 0;        // the slot being worked on
+  // one slot: start the load two slots ahead into `fill` (the register set whose tile was consumed last), work on `w`
+  auto step = [&](const v4u& w, v4u& fill) -> bool {
+    advance(il, jl);
+    fill = load(il, jl);
+    if (j == 0 && (i & 63u) == 0) {
+      // boundary pass: lane l looks at the four words in front of segment i + l
+      const unsigned k = i + (unsigned)lane;
+      v4u b = {0u, 0u, 0u, 0u};
+      if (k < mine) {
+        unsigned s, g;
+        split(wave + k * W, s, g);
+        const uint32_t* src = g ? p.pdm + (size_t)s * p.stride + (size_t)g * tp * kTileWords - 4 : p.hist + 4 * (size_t)s;
+        b = *reinterpret_cast<const v4u*>(src);
       }
-      const size_t first = t * kTileOut - 4;
-      const size_t left = p.n_words - first;
-      const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
-      const __amdgpu_buffer_rsrc_t rin = make_rsrc(stream + first, recs * 4);
-      return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, UC_STREAM_CPOL);
+      int y[4];
+      lookups(b, st, y, cin);
     }
-    const size_t base = tile * kTileOut;  // first word of the tile = first output of the tile + 4 - 4
-    const size_t left = tile < tiles ? p.n_words - base : 0;
-    const int recs = left < (size_t)kTileWords ? (int)left : kTileWords;
-    const __amdgpu_buffer_rsrc_t rin = make_rsrc(p.pdm + (tile < tiles ? base : 0), recs * 4);
-#if UC_CIC_KNOCK == 2  // (knock-out build: every tile re-reads the stream's first KiB -- no HBM reads)
-    const __amdgpu_buffer_rsrc_t rin0 = make_rsrc(p.pdm, recs * 4);
-    return __builtin_amdgcn_raw_buffer_load_b128(rin0, lane * 16, 0, 0);
-#else
-    return __builtin_amdgcn_raw_buffer_load_b128(rin, lane * 16, 0, UC_STREAM_CPOL);
-#endif
-  };
-  // One tile of a wave: 256 words in, 252 outputs out.
-  auto process = [&](const v4u w, size_t tile) {
-    size_t base = tile * kTileOut;
-    const int32_t* out_base = p.out;
-    if constexpr (MULTI) {
-      size_t s = 0, t = 0;
-      if (tile < tiles) split(tile, s, t);
-      base = t * kTileOut;
-      out_base = p.out + s * p.out_stride;
-    }
-    const unsigned wd[4] = {w.x, w.y, w.z, w.w};
-    int g[4][5];
+    const Slot t = slot(i, j);
+    if (t.recs) {
+      int y[4], c[4];
+      lookups(w, st, y, c);
+      v4u r;
+      unsigned out[4];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      int a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const v4i q = *lds_at<v4i>(__builtin_amdgcn_perm(wd[c], c4[i], sel[i]));
-        a0 += q.x; a1 += q.y; a2 += q.z; a3 += q.w;
-        a4 += *lds_at<int>(__builtin_amdgcn_perm(wd[c], c1[i], sel[i]));
+      for (int k = 0; k < 4; k++) {
+        const int in = j == 0 ? __builtin_amdgcn_readlane(cin[k], (int)(i & 63u)) : carry[k];
+        // lane l > 0 takes c[k] of lane l - 1; lane 0 has no source lane and keeps the DPP's `old` operand: `in`
+        y[k] += __builtin_amdgcn_update_dpp(in, c[k], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        carry[k] = __builtin_amdgcn_readlane(c[k], 63);
+        out[k] = word24(y[k]);
       }
-      g[c][0] = a0; g[c][1] = a1; g[c][2] = a2; g[c][3] = a3; g[c][4] = a4;
-      if (c & 1) __builtin_amdgcn_sched_barrier(0);  // two words' lookups (16 reads, 40 result registers) at a time
+      r.x = out[0]; r.y = out[1]; r.z = out[2]; r.w = out[3];
+      // The hardware contract this rests on (raw buffer, num_records in bytes): the range check of a b128 store is made PER
+      // DWORD, so a lane whose four words straddle the end of a ragged stream (n_words % 4 != 0) stores the words inside and
+      // drops the rest; lanes behind the end store nothing -- no branch, no 64-bit address registers.  Pinned by
+      // tests/test_dfsdm.py::test_sinc5_ragged_tails_on_the_device_never_write_past_the_end (guard words).
+      const __amdgpu_buffer_rsrc_t rout = make_rsrc(t.out, t.recs * 4);
+      __builtin_amdgcn_raw_buffer_store_b128(r, rout, lane * 16, 0, UC_STREAM_CPOL);
     }
-    // sums over this lane's own words, and what its words add to the next lane's four outputs
-    int y0 = g[0][0];
-    int y1 = g[1][0] + g[0][1];
-    int y2 = g[2][0] + g[1][1] + g[0][2];
-    int y3 = g[3][0] + g[2][1] + g[1][2] + g[0][3];
-    const int c0 = g[3][1] + g[2][2] + g[1][3] + g[0][4];
-    const int c1 = g[3][2] + g[2][3] + g[1][4];
-    const int c2 = g[3][3] + g[2][4];
-    const int c3 = g[3][4];
-    y0 += from_prev_lane(c0);
-    y1 += from_prev_lane(c1);
-    y2 += from_prev_lane(c2);
-    y3 += from_prev_lane(c3);
-    // B = sum of the taps that met a 1 bit: y = 2 B - 2^25; result = clip(y >> 2) << 8  (bsum = B - 2^24: see the fill)
-    auto word = [](int bsum) {
-      int v = bsum >> 1;
-      v = v > 8388607 ? 8388607 : v;
-      v = v < -8388608 ? -8388608 : v;
-      return v * 256;
-    };
-    // outputs base + 4 (lane - 1) .. + 3 through a buffer resource over this tile's outputs: lane 0 (its outputs
-    // belong to the previous tile), lanes past the end of the stream and tiles past the last one fall outside the
-    // resource and are dropped by the range check -- no branch, no 64-bit address registers.
-    // The hardware contract this rests on (raw buffer, num_records in bytes): the range check of a b128 store is made
-    // PER DWORD, so a lane whose four words straddle the end of a ragged stream (n_out % 4 != 0) stores the words
-    // inside and drops the rest; lane 0's offset (lane - 1) * 16 = 0xFFFFFFF0 is out of range on purpose.
-    // Pinned by tests/test_dfsdm.py::test_sinc5_ragged_tails_on_the_device_never_write_past_the_end (guard words).
-    const size_t left = tile < tiles ? n_out - base : 0;
-    const int recs = left < (size_t)kTileOut ? (int)left : kTileOut;
-    const __amdgpu_buffer_rsrc_t rout = make_rsrc(out_base + (tile < tiles ? base : 0), recs * 4);
-    v4u r;
-    r.x = (unsigned)word(y0); r.y = (unsigned)word(y1); r.z = (unsigned)word(y2); r.w = (unsigned)word(y3);
-#if UC_CIC_KNOCK == 1  // (knock-out build: one lane of 63 stores)
-    if (lane == 1) __builtin_amdgcn_raw_buffer_store_b128(r, rout, (lane - 1) * 16, 0, UC_STREAM_CPOL);  // 1/63 of the bytes
-#else
-    __builtin_amdgcn_raw_buffer_store_b128(r, rout, (lane - 1) * 16, 0, UC_STREAM_CPOL);  // written once, never read here
-#endif
+    __builtin_amdgcn_sched_barrier(0);
+    advance(i, j);
+    return i < mine;
   };
-  // Workgroup b owns the tiles b, b + B, b + 2 B, ... (B workgroups); its 16 waves do NOT run at the same speed (the
-  // SIMD arbitration favours the older wave: with equal static shares the slowest wave of a workgroup ran 1.5 x as
-  // long as the fastest, profiles/r02_sinc5_skew_static.json), so they draw tickets k = 0, 1, 2, ... from the
-  // workgroup's counter in global memory (p.ctr[b], zero at launch; LDS is full): ticket k = tile b + k B.
-  // The loads run two tiles ahead, the ticket for the next load one iteration ahead of its use; the returning
-  // atomic is always OLDER than the loads still in flight, so reading it never drains the load pipeline.
-  const size_t nblocks = gridDim.x;
-  const unsigned my_tiles = (unsigned)((tiles - blockIdx.x + nblocks - 1) / nblocks);  // tickets of this workgroup
-  auto tile_of = [&](unsigned k) { return k < my_tiles ? (size_t)blockIdx.x + (size_t)k * nblocks : tiles; };
-  unsigned* ctr = p.ctr ? p.ctr + blockIdx.x : nullptr;
-  const unsigned wv = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  // one ticket = kTicket consecutive tiles of the workgroup (an atomic takes several microseconds to return while
-  // the chip streams: with a ticket per tile every iteration waited for its atomic, 1.3 ms instead of 0.49 ms)
-  constexpr unsigned kTicket = 4;
-  auto ticket = [&]() -> unsigned {  // returns in lane 0 of a VGPR; made scalar when it is used
-    return (lane == 0) ? atomicAdd(ctr, 1u) + (unsigned)(TC / 64) : 0u;
-  };
-  if (ctr) {
-    unsigned kl = kTicket * wv;     // tile (ticket-local numbering) of the next LOAD; every wave's first ticket is fixed
-    unsigned kn_v = ticket();       // the ticket after it, in flight (issued before the loads: see below)
-    auto next_k = [&]() {           // advance kl; at a ticket boundary take the ticket in flight and ask for another
-      if (((kl + 1) & (kTicket - 1)) != 0) {
-        kl++;
-      } else {
-        kl = kTicket * (unsigned)__builtin_amdgcn_readfirstlane((int)kn_v);
-        kn_v = ticket();            // BEFORE the next load: vector-memory operations return in order, so reading
-      }                             // this ticket later must not have to wait for loads issued after it
-    };
-    unsigned k0 = kl;
-    v4u q0 = load_tile(tile_of(kl));
-    next_k();
-    unsigned k1 = kl;
-    v4u q1 = load_tile(tile_of(kl));
+  // three register sets in rotation (a loop that hands q1 to q0 to w by copies has to wait for ALL loads in flight
+  // before it may copy: the load just started would be waited for at once)
+  v4u qa = load(il, jl), qb, qc;
+  advance(il, jl);
+  qb = load(il, jl);
+  if (mine) {
     for (;;) {
-      if (k0 >= my_tiles) break;
-      const v4u w = q0;
-      q0 = q1;
-      next_k();
-      const unsigned kn = kl;
-      q1 = load_tile(tile_of(kn));
-      process(w, tile_of(k0));
-      __builtin_amdgcn_sched_barrier(0);
-      k0 = k1;
-      k1 = kn;
-    }
-  } else {
-    // static deal (no counter): tiles wave, wave + W, ... of all W waves of the grid, loads two tiles ahead
-    v4u q0 = load_tile(wave0), q1 = load_tile(wave0 + nwaves);
-    for (size_t tile = wave0; tile < tiles; tile += nwaves) {
-      const v4u w = q0;
-      q0 = q1;
-      q1 = load_tile(tile + 2 * nwaves);
-      process(w, tile);
-      __builtin_amdgcn_sched_barrier(0);
+      if (!step(qa, qc)) break;
+      if (!step(qb, qa)) break;
+      if (!step(qc, qb)) break;
     }
   }
 #ifdef UC_CLOCKSTAMP
@@ -300,33 +286,25 @@ __global__ __launch_bounds__(256) void hist_kernel(const CicParams p) {
 
 UC_LAUNCH_BEGIN
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream) {
-  if (p.n_streams) {  // uc_dfsdm_sinc5_streams
-    if (grid <= 0 || p.n_words == 0) return (int)hipSuccess;
-    hipLaunchKernelGGL(sinc5_kernel<true>, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((p.n_streams + 255) / 256)), dim3(256), 0, stream, p);
-    return (int)hipGetLastError();
-  }
-  if (grid <= 0 || p.n_words <= 4) return (int)hipSuccess;
-  hipLaunchKernelGGL(sinc5_kernel<false>, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
+  if (grid <= 0 || p.n_words == 0 || p.n_streams == 0) return (int)hipSuccess;
+  hipLaunchKernelGGL(sinc5_kernel, dim3((unsigned)grid), dim3((unsigned)TC), kCicLdsBytes, stream, p);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || !p.update_hist) return (int)e;
+  hipLaunchKernelGGL(hist_kernel, dim3((unsigned)((p.n_streams + 255) / 256)), dim3(256), 0, stream, p);
   return (int)hipGetLastError();
 }
 
 // Called once per context on its device, before the first launch: more than the default 64 KiB of
 // dynamic LDS needs the opt-in; returns the resident workgroups per CU (0 if the opt-in fails).
 int sinc5_max_blocks_per_cu() {
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          (int)kCicLdsBytes) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(sinc5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                           (int)kCicLdsBytes) != hipSuccess)
     return 0;
   int nb = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel<false>, TC, kCicLdsBytes) != hipSuccess || nb <= 0) nb = 1;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, sinc5_kernel, TC, kCicLdsBytes) != hipSuccess || nb <= 0) nb = 1;
   return nb;
 }
 
-int sinc5_tile_outputs() { return kTileOut * (TC / 64); }
 int sinc5_waves_per_block() { return TC / 64; }
 
 UC_LAUNCH_END

@@ -167,24 +167,26 @@ int stream_max_blocks_per_cu(int dtype, int decim);
 
 // DFSDM model: sinc^5, decimate by 32, of a packed 1-bit PDM stream (receiver/Src/dfsdm.c:59-61,69,78).
 struct CicParams {
-  const uint32_t* pdm;   // device, 16-byte aligned; bit t of the stream = bit (t & 31) of word t >> 5
-  size_t n_words;        // the first 4 words are history
-  int32_t* out;          // device, 16-byte aligned, n_words - 4 words: 24-bit result in bits 31:8
+  // stream s = n_words NEW words at pdm + s * stride (bit t of a stream = bit (t & 31) of word t >> 5), n_words outputs
+  // (24-bit result in bits 31:8) at out + s * out_stride; everything device memory, 16-byte aligned
+  const uint32_t* pdm;
+  size_t n_words;
+  int32_t* out;
   const int32_t* t4;     // [4][256][4] per-byte contributions to outputs m .. m+3 of word m
   const int32_t* t1;     // [4][256]    per-byte contribution to output m+4
-  unsigned int* ctr;     // one word per workgroup, zero at launch: the tile tickets its waves draw; nullptr = static deal
   unsigned long long* debug;  // diagnostic builds only (UC_CLOCKSTAMP), else nullptr
-  // uc_dfsdm_sinc5_streams (n_streams != 0): stream s = n_words NEW words at pdm + s * stride (no history in the buffer),
-  // n_words outputs at out + s * out_stride; hist = [n_streams][4] words, the filter history of every stream: read by the
-  // streams' first tiles, then brought up to date (the last four words of [history | new words]) by a second small kernel
   size_t n_streams, stride, out_stride;
+  // [n_streams][4] words, the filter history of every stream (the four words in front of its new ones): read by the
+  // streams' first segments, then -- update_hist -- brought up to date (the last four words of [history | new words]) by a
+  // second small kernel
   const uint32_t* hist;
-  uint32_t tps;                    // tiles per stream: ceil(n_words / 252)
-  uint32_t div_magic, div_shift;   // tile / tps (uc::rows_divisor)
+  uint32_t update_hist;
+  // a stream is cut into nseg SEGMENTS of tps tiles of 256 words (the last one may be shorter); one wave walks a segment
+  uint32_t tps, nseg, units;       // units = n_streams * nseg < 2^31
+  uint32_t div_magic, div_shift;   // unit / nseg (uc::rows_divisor)
 };
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
 int sinc5_max_blocks_per_cu();
-int sinc5_tile_outputs();
 int sinc5_waves_per_block();
 
 // ---- the clock-stamped twin of every kernel (diagnostic, shipped, costs nothing when off) ----------------------------
@@ -213,7 +215,6 @@ int launch_stream(int dtype, int decim, const StreamParams& p, int grid, hipStre
 int stream_max_blocks_per_cu(int dtype, int decim);
 int launch_sinc5(const CicParams& p, int grid, hipStream_t stream);
 int sinc5_max_blocks_per_cu();
-int sinc5_tile_outputs();
 int sinc5_waves_per_block();
 }  // namespace clk
 
