@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for cmd in "tools/fuzz_parity.py 900 141" "tools/fuzz_strides.py 700 143" "tools/fuzz_receive.py 900 145" "tools/fuzz_live.py 600 155" "tools/fuzz_iq.py 500 147" "tools/fuzz_stream.py 240 149" "tools/fuzz_spectrum.py 500 151"; do
+for cmd in "tools/fuzz_dfsdm.py 200 7" "tools/fuzz_parity.py 900 141" "tools/fuzz_strides.py 700 143" "tools/fuzz_receive.py 900 145" "tools/fuzz_live.py 600 155" "tools/fuzz_iq.py 500 147" "tools/fuzz_stream.py 240 149" "tools/fuzz_spectrum.py 500 151"; do
   echo "== python $cmd"
   timeout -k 10 1000 python $cmd 2>&1 | tail -1
 done
