@@ -720,7 +720,12 @@ static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stre
   // before the skew between workgroups that the tickets even out has built up, and pays for them -- 32 768 frames (the new
   // FIFO offsets of 4096 live streams): 0.101 ms dealt statically, 0.166 ms with tickets; 131 072: 0.309 / 0.322; from
   // 524 288 on the same (profiles/r05_live_deal.txt)
-  if (!c->static_deal && group >= 2 && group == group_cap && ngroups > grid) {
+  // ... and not for the masked steps of live RX_REAL receivers (p.need: most frame indices are passed over, a group lasts 20-40 us
+  // and 16 384 tickets on one word are felt): 65 536 idle streams 0.663 -> 0.627 ms, with a transmission in every stream 0.813 ->
+  // 0.776; SYNC_CPLX (twice the work per frame) gains 0.6 % idle and loses 1.2 % with transmissions, and keeps its tickets
+  // (profiles/r05_live_idle.txt)
+  const bool masked_real = rows && p.need != nullptr && mode == uc::kModeRxReal;
+  if (!c->static_deal && !masked_real && group >= 2 && group == group_cap && ngroups > grid) {
     const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
     if (wrc) return wrc;
   }
