@@ -308,7 +308,8 @@ def test_live_receivers_fed_with_the_microphones_bit_streams(uchirp, variant):
     """UC_DTYPE_PDM: the live chain of a node starts at the microphones' 1-bit PDM streams (receiver/Src/dfsdm.c:59-61,69,78 ->
     main.c:659-668 -> 417-554).  The DFSDM runs on the device in front of the ISR's FIFO, its filter history travels in the
     uc_rx_state.  Texts and traces -- block by block, in ragged chunks, with dropped blocks, recorded in one call -- equal,
-    bit for bit, the receiver fed with the ORACLE's DFSDM words of the same bit streams; the messages decode."""
+    bit for bit, the receiver fed with the ORACLE's DFSDM words of the same bit streams; the messages decode.  The live step
+    from bits also replays from one captured hipGraph."""
     import torch
     N = 2048
     blocks, ns = 112, 5
@@ -343,6 +344,33 @@ def test_live_receivers_fed_with_the_microphones_bit_streams(uchirp, variant):
             assert texts[s] == want_t[s], s
             assert np.array_equal(np.concatenate(traces[s]).view(np.uint8), want_tr[s].view(np.uint8)), s
         live.close()
+    # the same step -- DFSDM, history update, ROWS band launch, replay: four launches -- captured ONCE into a hipGraph and
+    # replayed for every block of bits that arrives (one eager step first: tables and scratch are allocated by it)
+    dev = torch.device("cuda:0")
+    pd = torch.from_numpy(pdm.view(np.int32)).to(dev)
+    live = e.live(ns)
+    chunk = torch.zeros((ns, N), dtype=torch.int32, device=dev)
+    text = torch.zeros((ns, 8), dtype=torch.uint8, device=dev)
+    ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
+    live.next_into(chunk, text, ntext, pdm=True)
+    live.reset()
+    torch.cuda.synchronize()
+    gr = torch.cuda.CUDAGraph()
+    cs = torch.cuda.Stream()
+    cs.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(cs):
+        with torch.cuda.graph(gr, stream=cs):
+            live.next_into(chunk, text, ntext, stream=cs.cuda_stream, pdm=True)
+    texts = [b""] * ns
+    for b in range(blocks):
+        chunk.copy_(pd[:, b * N:(b + 1) * N])
+        gr.replay()
+        torch.cuda.synchronize()
+        nt, tt = ntext.cpu().numpy(), text.cpu().numpy()
+        for k in range(ns):
+            texts[k] += bytes(tt[k, :nt[k]])
+    assert [t.decode("latin-1") for t in texts] == ref_t
+    live.close()
     # the node's form: uc_group_receive_streams_next takes the bit streams too (world size 1 here: a rank's whole code path)
     g = uchirp.Group(variant, devices=[0])
     st = g.rx_state(0, ns)
