@@ -510,7 +510,8 @@ int uc_group_synchronize(uc_group* g);
  *   n_text      (nullable; all ranks alike) n_text[l]: n_streams_total uint32 on that device (or host), characters per stream
  * A stream's text is the one uc_receive_stream[_isr] gives for it alone, bit for bit, wherever it ran.
  * uc_group_receive_streams_next is the LIVE form (uc_receive_streams_next): states[l] = uc_rx_state_create(uc_group_ctx(g, l),
- * count of rank first + l) holds that share's receivers between calls; text receives what was decoded during THIS call.
+ * count of rank first + l) holds that share's receivers between calls (NULL for a rank that owns no stream: fewer streams than
+ * GPUs); text receives what was decoded during THIS call.
  * (A block completes at most ONE character per stream, plus the newline that ends a message: for one-block calls text_cap = 4
  * is plenty and keeps what is gathered per step at 8 bytes per stream of the node.)
  */

@@ -523,7 +523,8 @@ static int group_receive(uc_group* g, uc_rx_state* const* states, const void* co
     if (n_text && !n_text[l]) return fail(-EINVAL, "%s: n_text[%d] is NULL", who, l);
     if (count && n_samples >= (size_t)2048 && !samples[l]) return fail(-EINVAL, "%s: samples[%d] is NULL", who, l);
     if (states) {
-      if (!states[l]) return fail(-EINVAL, "%s: states[%d] is NULL", who, l);
+      // (a rank that owns no stream -- fewer streams than GPUs -- has no state to bring: NULL)
+      if (count && !states[l]) return fail(-EINVAL, "%s: states[%d] is NULL", who, l);
       if (uc_rx_state_streams(states[l]) != count)
         return fail(-EINVAL, "%s: states[%d] holds %zu streams, rank %d owns %zu of %zu", who, l, uc_rx_state_streams(states[l]),
                     g->first_rank + l, count, n_streams_total);
@@ -536,7 +537,8 @@ static int group_receive(uc_group* g, uc_rx_state* const* states, const void* co
     uc_partition(n_streams_total, g->world, g->first_rank + l, &first, &count);
     if (!text[l]) return fail(-EINVAL, "%s: text[%d] is NULL", who, l);
     if (states) {
-      if (!states[l]) return fail(-EINVAL, "%s: states[%d] is NULL", who, l);
+      // (a rank that owns no stream -- fewer streams than GPUs -- has no state to bring: NULL)
+      if (count && !states[l]) return fail(-EINVAL, "%s: states[%d] is NULL", who, l);
       if (uc_rx_state_streams(states[l]) != count)
         return fail(-EINVAL, "%s: states[%d] holds %zu streams, rank %d owns %zu of %zu", who, l, uc_rx_state_streams(states[l]),
                     g->first_rank + l, count, n_streams_total);
