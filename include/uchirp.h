@@ -52,7 +52,7 @@
 extern "C" {
 #endif
 
-#define UC_ABI_VERSION 6
+#define UC_ABI_VERSION 7
 
 /* pipeline variants */
 enum {
@@ -326,7 +326,9 @@ int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_str
  * chunk's blocks).  One new block of every stream costs at most 8 transforms per stream and reference; one-block calls evaluate
  * only the offsets main()'s switch can still look at -- an IDLE stream the 3 - 5 of the 8 that acquisition reaches, the UP
  * reference only (receiver/Src/main.c:447-453), a SYNCHRONIZED / DATA_RECEIVING stream the 5 - 6 around its sync_position
- * (main.c:491-550, 243-273) --, 2 kernel launches (5 with a busy mask, +2 for UC_DTYPE_PDM), no copy.
+ * (main.c:491-550, 243-273); what the switch cannot look at costs nothing (no loads, no transform, no loop iteration: the kernel
+ * walks the wanted offsets of a group of streams by bit scans of ONE word) --, 2 kernel launches (5 with a busy mask, +2 for
+ * UC_DTYPE_PDM), no copy kernel; see uc_rx_state_keep_previous for the one copy that is left.
  * Everything a step carries lives on the device, so with device pointers the call can be captured into a hipGraph and the
  * graph replayed for every block that arrives (make one eager call of the same shape first: it sizes the scratch; nothing is
  * allocated during a capture; uc_rx_state_reset puts the receivers back to power-on).
@@ -339,6 +341,21 @@ int uc_rx_state_create(uc_ctx* ctx, size_t n_streams, uc_rx_state** out);   /* e
 int uc_rx_state_reset(uc_rx_state* st, void* hip_stream);                   /* back to power-on */
 void uc_rx_state_destroy(uc_rx_state* st);
 size_t uc_rx_state_streams(const uc_rx_state* st);                          /* how many receivers it holds (0 for NULL) */
+/*
+ * "The caller keeps the previous chunk" (on != 0; off by default).  What a call's first new FIFO offsets still read of the call
+ * before it is that call's last block of every stream (the ISR keeps it in fifo_queue, receiver/Src/main.c:662).  By default
+ * the library copies that block into the state on its way through the kernel (8 KiB read once more + 8 KiB written per stream
+ * and call) because the caller may overwrite `samples` as soon as the call has been enqueued.  A caller that receives into a
+ * ring of two or more chunk buffers -- what a DMA engine fills anyway -- can promise instead that the `samples` of every call
+ * stay where they are, UNCHANGED, until the NEXT uc_receive_streams_next on the state has completed on the device: the next
+ * call then reads "the block in front" from where the previous call's samples lie, and nothing is copied.  Results are the
+ * same bit for bit.  The promise covers calls on device memory without a busy mask; a call on host memory (the library stages
+ * it), from UC_DTYPE_PDM bits (the DFSDM words are the library's) or with a busy mask is served as ever -- such calls may
+ * be mixed in freely (a busy-masked call first copies the kept blocks into the state: one more kernel).  Switching the
+ * contract off takes effect with the chunk of the next call (which still reads the kept one).  Captured steps bake the
+ * two addresses in: capture one step per buffer of the ring (A after B, B after A) and replay them in that order.
+ */
+int uc_rx_state_keep_previous(uc_rx_state* st, int on);
 int uc_receive_streams_next(uc_ctx* ctx, uc_rx_state* st, const void* samples, int dtype, size_t n_samples,
                             size_t stream_stride_elems, const uint8_t* busy /*nullable*/, char* text, size_t text_cap,
                             uint32_t* n_text /*nullable*/, uc_rx_event* trace /*nullable*/, size_t trace_cap,

@@ -32,7 +32,7 @@ def test_every_declared_symbol_is_exported(uchirp):
     missing = [s for s in decl if not hasattr(L, s)]
     assert not missing, missing
     assert sorted(uchirp.EXPORTS) == decl
-    assert L.uc_abi_version() == 6
+    assert L.uc_abi_version() == 7
 
 
 def test_struct_layouts(uchirp):
@@ -92,4 +92,4 @@ def test_header_is_plain_c_and_a_c_host_fails_loudly_without_a_gpu(uchirp, tmp_p
     out = subprocess.run([exe], capture_output=True, timeout=120)
     assert out.returncode == 0
     text = out.stdout.decode()
-    assert "uc_abi_version 6 (header 6)" in text and "uc_create: -19" in text and "no CPU path" in text
+    assert "uc_abi_version 7 (header 7)" in text and "uc_create: -19" in text and "no CPU path" in text

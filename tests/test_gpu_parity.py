@@ -741,7 +741,7 @@ def test_plain_c_host_through_the_c_abi(uchirp, tmp_path):
     out = subprocess.run([exe, "9"], capture_output=True, timeout=300)
     assert out.returncode == 0, out.stdout.decode() + out.stderr.decode()
     lines = out.stdout.decode().splitlines()
-    assert lines[0].startswith("uc_abi_version 6 (header 6)")
+    assert lines[0].startswith("uc_abi_version 7 (header 7)")
     assert lines[1].startswith("frame up  : symbol 1") and lines[2].startswith("frame down: symbol 0")
     assert lines[3] == "batch: 0 1 0 1 0 1 0 1 0"
 

@@ -332,6 +332,145 @@ def test_what_live_receivers_pass_over_is_never_looked_at(uchirp, monkeypatch, v
     e.close()
 
 
+@pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX])
+def test_live_receivers_whose_caller_keeps_the_previous_chunk(uchirp, monkeypatch, variant):
+    """uc_rx_state_keep_previous: the caller receives into a ring of chunk buffers and leaves every chunk where it is until the
+    next call has completed, so the block in front of a call's first block (what the ISR keeps in fifo_queue, main.c:662) is
+    read from the previous chunk and nothing is copied into the state.  Texts and traces equal the recorded call bit for bit:
+    one block per call (the masked walk) and chunks of any sizes, float32 and int32 words, rings of two and three buffers with
+    strides larger than the chunk, under the poison switch, with busy-masked calls, calls on host memory and a switched-off
+    contract mixed in, and after a reset."""
+    import torch
+    monkeypatch.setenv("UC_TUNING", "1")
+    monkeypatch.setenv("UC_RX_POISON", "1")
+    dev = torch.device("cuda:0")
+    blocks = 150
+    x, busy, msgs = _transmissions(37, seed=900 + variant, blocks=blocks)
+    ns = x.shape[0]
+    e = uchirp.Engine(variant)
+    rng = np.random.default_rng(5)
+    for data in (x, (np.round(x).astype(np.int64) * 256).astype(np.int32)):
+        whole_t, whole_tr = e.receive_many(data)
+        xd = torch.from_numpy(data).to(dev)
+        for ring_n, sizes in ((2, [1] * blocks), (3, [1] * blocks), (2, [5, 1, 1, 40, 2, 1, 1, 1, 98]),
+                              (3, list(rng.integers(1, 9, size=80)))):
+            sizes = list(int(v) for v in sizes)
+            while sum(sizes) > blocks:
+                sizes.pop()
+            if sum(sizes) < blocks:
+                sizes.append(blocks - sum(sizes))
+            cap = max(sizes)
+            # a ring of buffers wider than the chunk (row stride > chunk): what lies beyond a chunk is never read
+            ring = [torch.full((ns, cap * N + 64), 7, dtype=xd.dtype, device=dev) for _ in range(ring_n)]
+            live = e.live(ns)
+            live.keep_previous(True)
+            texts, traces = [""] * ns, [[] for _ in range(ns)]
+            b0 = 0
+            for k, nb in enumerate(sizes):
+                buf = ring[k % ring_n]
+                buf[:, :nb * N].copy_(xd[:, b0 * N:(b0 + nb) * N])
+                t, tr = live.next(buf[:, :nb * N])
+                for s_ in range(ns):
+                    texts[s_] += t[s_]
+                    traces[s_].append(tr[s_])
+                b0 += nb
+            for s_ in range(ns):
+                assert texts[s_] == whole_t[s_], (ring_n, sizes[:6], s_)
+                assert np.array_equal(np.concatenate(traces[s_]).view(np.uint8), whole_tr[s_].view(np.uint8)), (ring_n, sizes[:6], s_)
+            live.close()
+    assert sum(m in t for m, t in zip(msgs, whole_t)) >= 10
+    # mixed: kept device chunks, busy-masked calls, host chunks (staged by the library), the contract switched off and on again,
+    # one block per call -- against the recorded call with the same busy mask
+    whole_t, whole_tr = e.receive_many(x, busy=busy)
+    xd = torch.from_numpy(x).to(dev)
+    ring = [torch.zeros((ns, N), dtype=torch.float32, device=dev) for _ in range(2)]
+    live = e.live(ns)
+    live.keep_previous(True)
+    texts, traces = [""] * ns, [[] for _ in range(ns)]
+    for b in range(blocks):
+        bz = np.ascontiguousarray(busy[:, b:b + 1])
+        if b == 60:
+            live.keep_previous(False)
+        if b == 75:
+            live.keep_previous(True)
+        if b % 7 == 3:
+            arg = np.ascontiguousarray(x[:, b * N:(b + 1) * N])     # host memory
+        else:
+            arg = ring[b % 2]
+            arg.copy_(xd[:, b * N:(b + 1) * N])
+        t, tr = live.next(arg, busy=bz if bz.any() else None)
+        for s_ in range(ns):
+            texts[s_] += t[s_]
+            traces[s_].append(tr[s_])
+    for s_ in range(ns):
+        assert texts[s_] == whole_t[s_], s_
+        assert np.array_equal(np.concatenate(traces[s_]).view(np.uint8), whole_tr[s_].view(np.uint8)), s_
+    # reset = power-on again, also for what is kept
+    live.reset()
+    t2, tr2 = live.next(xd[:, :40 * N].contiguous())
+    t1, tr1 = e.receive_many(x[:, :40 * N])
+    assert t1 == t2 and all(np.array_equal(a.view(np.uint8), b_.view(np.uint8)) for a, b_ in zip(tr1, tr2))
+    live.close()
+    e.close()
+
+
+@pytest.mark.parametrize("variant", [uco.RX_REAL, uco.SYNC_CPLX])
+def test_kept_chunks_two_captured_steps_replayed_in_turn(uchirp, variant):
+    """With uc_rx_state_keep_previous a captured step bakes in where its chunk and the chunk in front of it lie: a ring of two
+    buffers is two graphs (A after B, B after A) replayed in turn.  Texts and traces equal the recorded call bit for bit."""
+    import torch
+    dev = torch.device("cuda:0")
+    blocks, ns = 121, 24
+    x, busy, msgs = _transmissions(ns, seed=171 + variant, blocks=blocks)
+    e = uchirp.Engine(variant)
+    whole_t, whole_tr = e.receive_many(x)
+    xd = torch.from_numpy(x).to(dev)
+    live = e.live(ns)
+    live.keep_previous(True)
+    ring = [torch.zeros((ns, N), dtype=torch.float32, device=dev) for _ in range(2)]
+    text = torch.zeros((ns, 8), dtype=torch.uint8, device=dev)
+    ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
+    trace = torch.zeros((ns, 1, uchirp.RX_EVENT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
+    ntrace = torch.zeros(ns, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    texts, traces = [b""] * ns, [[] for _ in range(ns)]
+
+    def collect():
+        torch.cuda.synchronize()
+        nt, tt = ntext.cpu().numpy(), text.cpu().numpy()
+        ntr = ntrace.cpu().numpy()
+        tr = trace.cpu().numpy().reshape(ns, -1).view(uchirp.RX_EVENT_DTYPE)
+        for k in range(ns):
+            texts[k] += bytes(tt[k, :nt[k]])
+            if ntr[k]:
+                traces[k].append(tr[k, :1].copy())
+
+    # block 0 eagerly (it sizes the scratch; the block in front of it is the state's power-on FIFO), then the two captures --
+    # each capture IS a step: blocks 1 and 2 are in the buffers while the captures are made, and are run by the first replays
+    ring[0].copy_(xd[:, :N])
+    live.next_into(ring[0], text, ntext, trace=trace, n_trace=ntrace)
+    collect()
+    graphs = []
+    s.wait_stream(torch.cuda.current_stream())
+    for k in (1, 0):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                live.next_into(ring[k], text, ntext, trace=trace, n_trace=ntrace, stream=s.cuda_stream)
+        graphs.append(g)                # graphs[0]: chunk in ring[1] behind ring[0]; graphs[1]: ring[0] behind ring[1]
+    for b in range(1, blocks):
+        ring[b % 2].copy_(xd[:, b * N:(b + 1) * N])
+        graphs[(b + 1) % 2].replay()
+        collect()
+    for k in range(ns):
+        assert texts[k].decode("latin-1") == whole_t[k], k
+        got = np.concatenate(traces[k]) if traces[k] else np.zeros(0, whole_tr[k].dtype)
+        assert np.array_equal(got.view(np.uint8), whole_tr[k].view(np.uint8)), k
+    assert sum(m in t for m, t in zip(msgs, whole_t)) >= 6
+    live.close()
+    e.close()
+
+
 def test_plain_c_host_runs_live_microphones(tmp_path):
     """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
     call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream

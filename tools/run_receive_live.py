@@ -34,6 +34,8 @@ for variant, vname in ((uchirp.SYNC_CPLX, "sync_cplx"), (uchirp.RX_REAL, "rx_rea
         lead = 40 * N + 777
         x[:, lead:lead + tone.numel()] += tone
         live = eng.live(ns)
+        if os.environ.get("UC_KEEP") == "1":     # uc_rx_state_keep_previous: every chunk here is a buffer of its own, never rewritten
+            live.keep_previous(True)
         cap = 16
         text = torch.zeros((ns, cap), dtype=torch.uint8, device=dev)
         ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
@@ -54,7 +56,7 @@ for variant, vname in ((uchirp.SYNC_CPLX, "sync_cplx"), (uchirp.RX_REAL, "rx_rea
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / len(chunks)
         ok = sum(1 for b in got if b"Hello World!" in bytes(b))
-        print(json.dumps({"variant": vname, "streams": ns, "blocks_per_call": per_call, "calls": len(chunks), "ms_per_call": dt * 1e3,
+        print(json.dumps({"variant": vname, "streams": ns, "keep_previous": os.environ.get("UC_KEEP") == "1", "blocks_per_call": per_call, "calls": len(chunks), "ms_per_call": dt * 1e3,
                           "real_time_ms_per_call": per_call * N / FS * 1e3,
                           "headroom_x_real_time": per_call * N / FS / dt,
                           "microphones_served_in_real_time": int(ns * per_call * N / FS / dt),

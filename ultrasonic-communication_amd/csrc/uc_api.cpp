@@ -708,8 +708,12 @@ static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stre
   const size_t units = (mode == uc::kModePair && !p.unpaired) ? (n_frames + 1) / 2 : n_frames;
   uint32_t group = (uint32_t)c->band_group;
   if (waves >= 4 && group > 32) group = 32;  // (the ring of the 4-waves-per-SIMD build holds 32 frames)
+  if (rows && group > 32) group = 32;        // (the ROWS build describes a group's units by ONE 32-bit word)
   const uint32_t group_cap = group;
-  while (group > 1 && units < (size_t)group * grid * 4) group >>= 1;
+  // (one-block calls of a live state, p.need: groups of whole rows -- the walk reads a group's need words as bytes of one word)
+  const uint32_t group_min = (rows && p.need) ? 8u : 1u;
+  if (group < group_min) group = group_min;
+  while (group > group_min && units < (size_t)group * grid * 4) group >>= 1;
   const size_t ngroups = (units + group - 1) / group;
   if (grid > ngroups) grid = ngroups;
   p.group_log2 = 0;
@@ -720,12 +724,12 @@ static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stre
   // before the skew between workgroups that the tickets even out has built up, and pays for them -- 32 768 frames (the new
   // FIFO offsets of 4096 live streams): 0.101 ms dealt statically, 0.166 ms with tickets; 131 072: 0.309 / 0.322; from
   // 524 288 on the same (profiles/r05_live_deal.txt)
-  // ... and not for the masked steps of live RX_REAL receivers (p.need: most frame indices are passed over, a group lasts 20-40 us
-  // and 16 384 tickets on one word are felt): 65 536 idle streams 0.663 -> 0.627 ms, with a transmission in every stream 0.813 ->
-  // 0.776; SYNC_CPLX (twice the work per frame) gains 0.6 % idle and loses 1.2 % with transmissions, and keeps its tickets
-  // (profiles/r05_live_idle.txt)
-  const bool masked_real = rows && p.need != nullptr && mode == uc::kModeRxReal;
-  if (!c->static_deal && !masked_real && group >= 2 && group == group_cap && ngroups > grid) {
+  // ... and not for the masked steps of live receivers (p.need): the walk of the ROWS build fetches the need words of the group
+  // that FOLLOWS while it works on a group, which it can only do when it knows which group that is (g + gridDim.x); a masked
+  // group lasts 20-40 us and 16 384 tickets on one word were felt (r5: 65 536 idle RX_REAL streams 0.663 -> 0.627 ms dealt
+  // statically, profiles/r05_live_idle.txt)
+  const bool masked = rows && p.need != nullptr;
+  if (!c->static_deal && !masked && group >= 2 && group == group_cap && ngroups > grid) {
     const int wrc = take_work_counter(c, stream, &p.work_ctr, &wslot);  // dynamic hand-out
     if (wrc) return wrc;
   }
@@ -1515,6 +1519,14 @@ struct uc_rx_state {
   RxScratch rx;                 // scratch of the call in flight
   uint64_t blocks_seen = 0;     // host mirror of the block count (the overflow check only; a replayed graph does not bump it)
   int dtype = -1;               // of the words in d_last (the first call decides)
+  // uc_rx_state_keep_previous: the caller keeps the chunk of every call alive and unchanged until the NEXT call on the state has
+  // completed, so "the block in front" of a call's first block is read where the previous call's samples lie -- nothing is
+  // saved into d_last.  kept = the last block of stream 0 of the previous call's chunk (device memory of the caller),
+  // kept_pitch elements from stream to stream; nullptr: the FIFO's newest block is in d_last (power-on, after a busy-masked
+  // call, after a call on host memory).
+  bool keep = false;
+  const void* kept = nullptr;
+  size_t kept_pitch = 0;
 };
 
 static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples, int dtype, size_t n_streams, size_t n_samples,
@@ -1531,6 +1543,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
   const uint32_t per_block = n / 256;  // new FIFO offsets per accepted block
   const bool pdm = dtype == UC_DTYPE_PDM;
   const int dtype_in = dtype;
+  const size_t stream_stride_in = stream_stride_elems ? stream_stride_elems : n_samples;
   if (stream_stride_elems == 0) stream_stride_elems = n_samples;
   if (stream_stride_elems < n_samples) return fail(-EINVAL, "uc_receive_streams: streams overlap (stride %zu < %zu samples)",
                                                    stream_stride_elems, n_samples);
@@ -1634,6 +1647,19 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     size_t row_pitch = stream_stride_elems;
     const uint32_t* d_acc = nullptr;
     const uint32_t* d_na = nullptr;
+    // uc_rx_state_keep_previous holds for chunks the caller owns on the device and calls that accept every block; a call on
+    // host memory (staged by the library), from PDM bits (the DFSDM words are the library's) or with a busy mask (the newest
+    // ACCEPTED block differs by stream) hands the FIFO's newest block to the state as ever
+    const bool keep_next = st && st->keep && !busy && !pdm && d_in == samples;
+    if (st && st->kept && busy) {
+      // a busy-masked call behind kept chunks: a stream whose blocks are all dropped keeps its FIFO, so the kept blocks go
+      // into the state's current half first -- from here on this call is an ordinary one
+      const bool al16 = (((uintptr_t)st->kept | (uintptr_t)st->d_last) & 15u) == 0 && (st->kept_pitch & 3u) == 0 && (n & 3u) == 0;
+      const int lrc = uc::launch_rx_keep(st->kept, st->kept_pitch, n, n_streams, st->d_last, st->d_parity, al16, stream);
+      if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx keep kernel launch");
+      st->kept = nullptr;
+      st->kept_pitch = 0;
+    }
     if (busy) {
       const uint8_t* d_busy = busy;
       if (!is_device_ptr(busy)) {
@@ -1667,13 +1693,21 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       memset(&bp, 0, sizeof(bp));
       bp.frames = rows;
       bp.n_frames = n_frames;
-      bp.stride = 256;
       bp.magmax = (float2*)sc.rec.p;
       bp.prev = st ? (const void*)st->d_last : (const void*)c->d_zero_block;
       bp.prev_pitch = st ? (size_t)n : 0;
       bp.prev_half = st ? n_streams * (size_t)n : 0;
       bp.parity = st ? st->d_parity : nullptr;
       bp.save = (st && !busy) ? 1u : 0u;  // (with a busy mask the last ACCEPTED block differs by stream: launch_rx_last)
+      bp.save_to = st ? (void*)st->d_last : nullptr;
+      bp.save_half = bp.prev_half;
+      if (st && st->kept) {
+        // the caller has kept the previous chunk (uc_rx_state_keep_previous): the block in front is read where it lies
+        bp.prev = st->kept;
+        bp.prev_pitch = st->kept_pitch;
+        bp.prev_half = 0;
+      }
+      if (keep_next) bp.save = 0u;  // ... and this call's chunk will be kept for the next one: nothing to hand over
       // acquisition evaluates 4 positions a block, the UP reference only: a stream that is IDLE when its ONE new block arrives
       // gets the 3 or 5 transforms the switch can still look at (SYNC_CPLX: of the UP reference only) instead of 8
       bp.need = (st && nb == 1) ? st->d_need : nullptr;
@@ -1717,6 +1751,8 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     if (st) {
       st->blocks_seen += nb;
       st->dtype = dtype_in;
+      st->kept = keep_next ? (const void*)((const char*)samples + (nb - 1) * (size_t)n * 4) : nullptr;
+      st->kept_pitch = keep_next ? stream_stride_in : 0;
     }
   }
   if (host_out) {
@@ -1769,6 +1805,12 @@ extern "C" void uc_rx_state_destroy(uc_rx_state* st) {
 
 extern "C" size_t uc_rx_state_streams(const uc_rx_state* st) { return st ? st->n_streams : 0; }
 
+extern "C" int uc_rx_state_keep_previous(uc_rx_state* st, int on) {
+  if (!st) return fail(-EINVAL, "uc_rx_state_keep_previous: NULL state");
+  st->keep = on != 0;  // (switched off: the NEXT call still reads the kept chunk in front of its own, and saves its own)
+  return 0;
+}
+
 extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   if (!st) return fail(-EINVAL, "uc_rx_state_reset: NULL state");
   uc_ctx* c = st->c;
@@ -1786,6 +1828,8 @@ extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx state init kernel launch");
   st->blocks_seen = 0;
   st->dtype = -1;
+  st->kept = nullptr;
+  st->kept_pitch = 0;
   return 0;
 }
 

@@ -350,6 +350,8 @@ __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
 // fetched again by each of the up to 8 frames that share them (6384 instead of 1025 B of HBM traffic per frame at stride 256),
 // and that traffic is power the clock does not get (profiles/r05_stride_power.txt: +18-23 % frames/s).  Nothing else differs.
 enum { kFramesBatch = 0, kFramesRows = 1, kFramesOverlap = 2 };
+// a frame's ring slot: the next free one -- ROWS: the frame's index in its group (the walk passes over units)
+#define UC_RSLOT (ROWS ? (int)(f & gmask) : ring_n)
 template <int MODE, int DTYPE, int WAVES, bool WIDE = false, bool SPEC = false, int FRAMES = kFramesBatch>
 __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   constexpr bool ROWS = FRAMES == kFramesRows;
@@ -480,15 +482,57 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
   if (ROWS) {
     const unsigned par = p.parity ? (unsigned)__builtin_amdgcn_readfirstlane((int)*p.parity) & 1u : 0u;
     prev_rd = reinterpret_cast<const char*>(p.prev) + (size_t)par * p.prev_half * 4;
-    prev_wr = const_cast<char*>(reinterpret_cast<const char*>(p.prev)) + (size_t)(par ^ 1u) * p.prev_half * 4;
+    prev_wr = reinterpret_cast<char*>(p.save_to) + (size_t)(par ^ 1u) * p.save_half * 4;
   }
-  // ROWS, one-block live calls (p.need): what the switch can still look at of the row's new block (uc_rx.hpp: RxParams::need).
-  // rows_need = the word of the unit last handed to load_unit (read at the top of the frame loop, BEFORE the next unit is
-  // loaded); the word of a row is fetched once, when the row's first unit is loaded
-  unsigned rows_need = 0x1ffu, need_row = 0xffffffffu, need_word = 0x1ffu;
-  // ... and the units whose loads are already out: a unit that is not needed hands its turn to the next needed unit of its row
-  // (inside the group), so that a frame behind skipped ones still has its samples requested a whole computed frame ahead
-  unsigned span_lo = 1u, span_hi = 0u;
+  // ROWS: the walk visits only the units that are WANTED.  A group (<= 32 units here: the host caps it; whole rows when there
+  // are need words) is described by two uniform words: rw_eval -- bit i: unit (group base + i) is transformed;
+  // rw_dn -- bit r: row r of the group needs its DOWN statistics (SYNC_CPLX).  Without need words (recorded calls, chunks of
+  // several blocks) every unit of the batch is transformed.  With them (one-block calls of a live state: row = stream) a
+  // unit the switch cannot look at costs NOTHING: the successor of a unit is the next wanted bit of its group's word or
+  // the first wanted bit of the next group's (the group's want bits in ONE scalar, fetched by scalar loads: no vector
+  // memory wait), so every transformed frame asks for the samples of the next transformed frame -- of the same row or not --
+  // a whole computed frame ahead; the ring slot of a frame is its index in the group and the finaliser writes zeros for
+  // the slots nothing was stored to.  Masked launches are dealt statically (group g + gridDim.x follows g).
+  unsigned rw_eval = 0xffffffffu, rw_dn = 0xfu;
+  unsigned ring_eval = 0xffffffffu;  // rw_eval of the group whose entries the ring holds
+  typedef const __attribute__((address_space(4))) unsigned int* need_ptr;  // (scalar loads: s_load_dword, lgkmcnt)
+  const need_ptr need_c = (need_ptr)(unsigned long long)p.need;
+  // the need words of the (up to four) rows of group g: requested here, combined by rows_masks() -- the caller puts work in between
+  auto rows_fetch = [&](unsigned g, unsigned (&nw)[4]) {
+    if constexpr (ROWS) {  // (the other builds capture nothing: their code is what it was)
+    nw[0] = nw[1] = nw[2] = nw[3] = 0u;
+    if (!p.need) return;
+    const unsigned s0 = (g << gsh) >> 3, ns = nfr >> 3;
+    nw[0] = need_c[s0];
+    if (gsh > 3 && s0 + 1 < ns) nw[1] = need_c[s0 + 1];
+    if (gsh > 4 && s0 + 2 < ns) nw[2] = need_c[s0 + 2];
+    if (gsh > 4 && s0 + 3 < ns) nw[3] = need_c[s0 + 3];
+    }
+  };
+  // the units of the group that starts at unit `base` (a multiple of the group size)
+  auto rows_valid = [&](unsigned base) -> unsigned {
+    const unsigned cnt = nfr - base;  // units from the group's first one to the end of the batch (>= 1)
+    const unsigned gm = gsh >= 5u ? 0xffffffffu : (1u << (1u << gsh)) - 1u;
+    return cnt >= 32u ? gm : (gm & ((1u << cnt) - 1u));
+  };
+  auto rows_masks = [&](unsigned g, const unsigned (&nw)[4], unsigned& ev, unsigned& dn) {
+    if constexpr (ROWS) {
+    const unsigned base = g << gsh;
+    const unsigned valid = rows_valid(base);
+    if (!p.need) {
+      ev = valid; dn = 0xfu;
+      return;
+    }
+    unsigned e = (nw[0] & 0xffu) | ((nw[1] & 0xffu) << 8) | ((nw[2] & 0xffu) << 16) | ((nw[3] & 0xffu) << 24);
+    // The block a row hands to the state (p.save) rides on the row's m = 8 frame, or on its m = 7 frame plus two loads
+    // (below): every need word the replay writes holds one of the two (uc_rx_kernel.hip: need_word -- the acquisition set of
+    // either turn reaches m = 7 or 8); a word that held neither would get its m = 8 frame transformed for nothing.
+    if (p.save) e |= (~(e | (e << 1)) & 0x80808080u);
+    ev = e & valid;
+    dn = ((nw[0] >> 8) & 1u) | (((nw[1] >> 8) & 1u) << 1) | (((nw[2] >> 8) & 1u) << 2) | (((nw[3] >> 8) & 1u) << 3);
+    }
+  };
+  v2f xs = mkv(0.f, 0.f);  // ROWS: the last 256 samples of a block its m = 7 frame hands to the state (below)
   auto load_unit = [&](size_t u, v2f (&xp)[NX]) {
     if (kPair) {
       const size_t fa = u << psh;
@@ -499,33 +543,11 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
 #pragma unroll
       for (int t = 0; t < NX; t++) xp[t] = mkv(buf_ld32_stream(ra, voff4, T * 4 * t), buf_ld32_stream(rb, voff4, T * 4 * t));
     } else if (ROWS) {
-      // (requested when an earlier unit of the row was loaded -- same row, so rows_need stands: nothing to do, and no
-      // address arithmetic spent on a unit that is passed over)
-      if (p.need && (unsigned)u >= span_lo && (unsigned)u <= span_hi) return;
       // unit u = (row s, block jb, m): samples [256 m, n) of the block in front of block jb, then [0, 256 m) of block jb
       const unsigned g8 = (unsigned)u >> 3;
-      unsigned m8 = ((unsigned)u & 7u) + 1u;
+      const unsigned m8 = ((unsigned)u & 7u) + 1u;
       const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
       const unsigned jb = g8 - s * p.row_blocks;
-      if (p.need) {
-        if (s != need_row) {
-          need_word = (unsigned)__builtin_amdgcn_readfirstlane((int)p.need[s]);
-          need_row = s;
-        }
-        rows_need = need_word;
-        // An offset the switch cannot look at is neither loaded nor transformed -- except the m = 8 frame of a row's last
-        // block when it is the one that hands the block to the state (p.save): loaded, stored, not transformed.  The loads
-        // that go out now are those of the NEXT unit of the row that needs its samples (inside this group of units).
-        unsigned want = need_word & 0xffu;
-        if (p.save && jb == p.row_blocks - 1u) want |= 0x80u;
-        const unsigned rem = want >> (m8 - 1u);
-        if (rem == 0u) return;
-        const unsigned ahead = (unsigned)__builtin_ctz(rem);
-        if (((unsigned)u + ahead) > ((unsigned)u | gmask)) return;  // (that unit belongs to another group)
-        span_lo = (unsigned)u;
-        span_hi = (unsigned)u + ahead;
-        m8 += ahead;
-      }
       const char* blk = reinterpret_cast<const char*>(p.frames) + ((size_t)s * p.row_pitch + (size_t)jb * kN) * 4;
       const char* before = jb ? blk - kN * 4 : prev_rd + (size_t)s * p.prev_pitch * 4;
       // sample 0 of the frame as if the whole frame lay in the one block / in the other; load t covers samples
@@ -540,6 +562,12 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         const __amdgpu_buffer_rsrc_t ra = make_rsrc(before + 1024 * m8, kN * 4);
         const __amdgpu_buffer_rsrc_t rb = make_rsrc(blk - (kN * 4 - 1024 * (int)m8), kN * 4);
         const int tsplit = 16 - 2 * (int)m8;
+        // (one-block calls) the m = 7 frame of a row whose m = 8 frame is passed over hands the row's block to the state: the
+        // block's last 256 samples come along (rw_eval describes u's group by now)
+        if (p.need && p.save && m8 == 7u && !((rw_eval >> (((unsigned)u & gmask) + 1u)) & 1u)) {
+          const __amdgpu_buffer_rsrc_t rl = make_rsrc(blk, kN * 4);
+          xs = mkv(buf_ld32_rows(rl, voff4, T * 4 * 14), buf_ld32_rows(rl, voff4, T * 4 * 15));
+        }
 #pragma unroll
         for (int m = 0; m < 8; m++)
           xp[m] = mkv(buf_ld32_rows(2 * m < tsplit ? ra : rb, voff4, T * 4 * (2 * m)),
@@ -556,11 +584,78 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
     }
   };
+  if constexpr (ROWS) {
+    // the first wanted unit of this workgroup's first group (a group nothing is wanted of still gets its zero records: its
+    // first unit is then transformed for nothing -- no need word the replay writes is empty)
+    unsigned nw[4];
+    rows_fetch(grp, nw);
+    rows_masks(grp, nw, rw_eval, rw_dn);
+    if (!rw_eval) rw_eval = 1u;
+    const unsigned want = rw_eval;
+    f += (unsigned)__builtin_ctz(want);
+  }
   load_unit(f, xp);
 
+  // ROWS: the same finaliser for the launches of uc_receive_streams[_next], which take (up, down) mag_max and nothing else
+  // (receiver/Src/main.c:209-215: the larger of the two window maxima, the right one on a tie).  It runs once per group: its
+  // lane, addresses and constants are derived when it runs -- hoisted out of the frame loop they would sit in registers the
+  // 168-register build does not have.
+  auto rows_finalise = [&](size_t f0, int count, unsigned evalmask) {
+    if constexpr (ROWS) {
+      int ln = lane;
+      unsigned poison = p.poison;
+      asm volatile("" : "+v"(ln), "+s"(poison));
+      if (ln >= count) return;
+      float2 out;
+      if (!((evalmask >> ln) & 1u)) {
+        // a slot nothing was stored to (a unit the switch cannot look at): a zero record -- or, under the tests' poison
+        // switch, statistics no signal reaches
+        out.x = out.y = poison ? 1e15f : 0.f;
+      } else {
+        const float* e = ring + ln * kRingStride;
+        const float mscale = kReal ? 0.5f : 1.0f;  // the ring holds squared magnitudes (x4 for RX_REAL)
+        float mr[2], ml[2];
+        int kr, kl;
+        if (WIDE) {
+          const unsigned a0 = __float_as_uint(e[4]), a1 = __float_as_uint(e[6 + 4]);
+          const unsigned b0 = __float_as_uint(e[5]), b1 = __float_as_uint(e[6 + 5]);
+          merge_window(e[0], a0 & 0x7fff, e[6 + 0], a1 & 0x7fff, true, ((a0 | a1) >> 15) & 1u, 0, mr[0], kr);
+          merge_window(e[1], (a0 >> 16) & 0x7fff, e[6 + 1], (a1 >> 16) & 0x7fff, false, ((a0 | a1) >> 31) & 1u, bw2, ml[0], kl);
+          merge_window(e[2], b0 & 0x7fff, e[6 + 2], b1 & 0x7fff, true, ((b0 | b1) >> 15) & 1u, 0, mr[1], kr);
+          merge_window(e[3], (b0 >> 16) & 0x7fff, e[6 + 3], (b1 >> 16) & 0x7fff, false, ((b0 | b1) >> 31) & 1u, bw2, ml[1], kl);
+        } else if (kReal) {
+          const unsigned kp0 = __float_as_uint(e[2]), kp1 = __float_as_uint(e[6 + 2]);
+          resolve_windows(e[0], kp0 & 255, (kp0 >> 8) & 255, e[6 + 0], kp1 & 255, (kp1 >> 8) & 255, e[3], e[6 + 3], bw2,
+                          mr[0], kr, ml[0], kl);
+          resolve_windows(e[1], (kp0 >> 16) & 255, (kp0 >> 24) & 255, e[6 + 1], (kp1 >> 16) & 255, (kp1 >> 24) & 255, e[4],
+                          e[6 + 4], bw2, mr[1], kr, ml[1], kl);
+        } else {
+          const unsigned kp0 = __float_as_uint(e[4]), kp1 = __float_as_uint(e[6 + 4]);
+          const unsigned fl = __float_as_uint(e[5]) | __float_as_uint(e[6 + 5]);
+          merge_window(e[0], kp0 & 255, e[6 + 0], kp1 & 255, true, fl & 1u, 0, mr[0], kr);
+          merge_window(e[1], (kp0 >> 8) & 255, e[6 + 1], (kp1 >> 8) & 255, false, fl & 2u, bw2, ml[0], kl);
+          merge_window(e[2], (kp0 >> 16) & 255, e[6 + 2], (kp1 >> 16) & 255, true, fl & 4u, 0, mr[1], kr);
+          merge_window(e[3], (kp0 >> 24) & 255, e[6 + 3], (kp1 >> 24) & 255, false, fl & 8u, bw2, ml[1], kl);
+        }
+        float mx[2];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const float r = mscale * sqrtf(mr[h]), l = mscale * sqrtf(ml[h]);
+          mx[h] = (l > r) ? l : r;  // make_hist: mag_max
+        }
+        out.x = mx[0];
+        out.y = mx[1];
+      }
+      p.magmax[f0 + (size_t)ln] = out;
+    }
+  };
   // Finaliser, vectorised over frames: lane L turns ring slot L into history[0],
   // history[1] and the symbol of frame f0 + L (receiver/Src/main.c:209-229, 518-531).
   auto finalise = [&](size_t f0, int count) {
+    if constexpr (ROWS) {
+      rows_finalise(f0, count, ring_eval);
+      return;
+    }
     if (lane < count) {
       const float* e = ring + lane * kRingStride;
       const size_t ff = f0 + (size_t)lane;
@@ -675,12 +770,60 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
     }
   };
 
-  unsigned ring_f0 = f;  // frame held by ring slot 0
-  int ring_n = 0;        // slots filled
+  unsigned ring_f0 = ROWS ? 0xffffffffu : f;  // frame held by ring slot 0 (ROWS: the first unit of the group the ring serves)
+  int ring_n = 0;        // slots filled (ROWS: the slots of the group in the ring, set when the group is entered)
 
   for (;;) {
     // successor of frame f in this workgroup's visiting order
     unsigned fnext = f + 1;
+    // ROWS: the group fnext opens -- its need words are requested here and combined (rows_masks) where the loads of fnext
+    // go out, a first radix-16 half later: nothing waits for them
+    bool next_first = false, nx_pending = false;
+    unsigned nx_nw[4] = {0u, 0u, 0u, 0u};
+    // ... and the group f opens (the first unit this workgroup visits of it): the ring changes hands here; what it held is
+    // finalised behind the frame's first barrier
+    bool grp_first = false, skip_down = false, save7 = false;
+    unsigned old_f0 = 0u, old_eval = 0u;
+    int old_n = 0;
+    if constexpr (ROWS) {
+      const unsigned fbase = f & ~gmask, bit = f & gmask;
+      grp_first = ring_f0 != fbase;
+      // the row's block goes to the state from its m = 7 frame when its m = 8 frame is not transformed (one-block calls)
+      save7 = p.need && p.save && (bit & 7u) == 6u && !((rw_eval >> (bit + 1u)) & 1u);
+      // SYNC_CPLX live receivers: acquisition looks at the UP reference only (receiver/Src/main.c:447-451); a stream that is
+      // IDLE when its block arrives cannot read a DOWN statistic of that block before the block has left the FIFO (it takes
+      // three evaluations, five blocks, to reach SYNCHRONIZED), so the second transform of its new offsets is skipped -- bit 8
+      // of the row's need word, written by the replay kernel of the previous call (one-block calls only)
+      skip_down = MODE == kModeCplx && !((rw_dn >> (bit >> 3)) & 1u);
+      const unsigned rem = rw_eval & ~((2u << bit) - 1u);
+      if (grp_first) {
+        old_f0 = ring_f0;
+        old_eval = ring_eval;
+        old_n = ring_n;
+        ring_f0 = fbase;
+        ring_eval = rw_eval;
+        ring_n = (int)(nfr - fbase < (1u << gsh) ? nfr - fbase : (1u << gsh));
+      }
+      if (rem) {
+        fnext = fbase + (unsigned)__builtin_ctz(rem);
+      } else {
+        next_first = true;
+        if (dyn) {
+          if (grp_first) {  // (a group of one unit: the id parked in the very frame that reads it)
+            if (j == 0) *next_slot = fetched;
+            __syncthreads();
+          }
+          grp = (unsigned)__builtin_amdgcn_readfirstlane((int)*next_slot) + gridDim.x;
+        } else {
+          grp += gridDim.x;
+        }
+        fnext = grp << gsh;  // (the group's first WANTED unit once its masks are known: resolve_next)
+        if (grp < ngroups) {
+          rows_fetch(grp, nx_nw);
+          nx_pending = true;
+        }
+      }
+    } else {
     if ((fnext & gmask) == 0 || fnext >= nfr) {
       if (dyn) {
         // normally the slot was written several barriers ago; only a one-frame group (the ragged end of the
@@ -695,7 +838,20 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       fnext = grp << gsh;
     }
+    }
     const bool has_next = grp < ngroups;
+    // (from here on rw_eval / rw_dn describe the group of fnext: everything this frame needs of its own group is in the
+    // flags above)
+    auto resolve_next = [&]() {
+      if constexpr (ROWS) {
+        if (nx_pending) {
+          rows_masks(grp, nx_nw, rw_eval, rw_dn);
+          if (!rw_eval) rw_eval = 1u;  // (nothing wanted of a whole group: its first unit is transformed for nothing)
+          fnext = (grp << gsh) + (unsigned)__builtin_ctz(rw_eval);
+          nx_pending = false;
+        }
+      }
+    };
     // Opaque re-definitions: stop LICM from hoisting the 16 swizzled store
     // addresses and the derived pass-3 twiddles out of the frame loop (they
     // would sit in registers for the whole batch).
@@ -721,7 +877,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         const unsigned g8 = f >> 3;
         const unsigned s = (__umulhi(g8, p.div_magic) + g8) >> p.div_shift;
         if (g8 - s * p.row_blocks == p.row_blocks - 1u) {
-          const __amdgpu_buffer_rsrc_t rw = make_rsrc(prev_wr + (size_t)s * p.prev_pitch * 4, kN * 4);
+          const __amdgpu_buffer_rsrc_t rw = make_rsrc(prev_wr + (size_t)s * kN * 4, kN * 4);
 #pragma unroll
           for (int m = 0; m < 8; m++) {
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xp[m].x), rw, voff4, T * 4 * (2 * m), 0);
@@ -729,56 +885,29 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
           }
         }
       }
-    }
-    // SYNC_CPLX live receivers: acquisition looks at the UP reference only (receiver/Src/main.c:447-451); a stream that is
-    // IDLE when its block arrives cannot read a DOWN statistic of that block before the block has left the FIFO (it takes
-    // three evaluations, five blocks, to reach SYNCHRONIZED), so the second transform of its 8 new offsets is skipped --
-    // bit 8 of the row's need word, written by the replay kernel of the previous call (one-block calls only; nullptr: never)
-    bool skip_down = false;
-    if (ROWS && p.need) {
-      const unsigned cur_need = rows_need;  // of frame f: load_unit has not been called for the next frame yet
-      skip_down = MODE == kModeCplx && !((cur_need >> 8) & 1u);
-      if (!((cur_need >> (f & 7u)) & 1u)) {
-        // An offset the switch cannot look at (an IDLE stream: 3 or 5 of the 8 are evaluated, main.c:447-453): everything the
-        // frame body does besides the transform -- park the next group's id, prefetch, drain the ring at a group start,
-        // one zero ring entry (the record is never read) -- then on to the next frame.  Uniform over the workgroup.
-        if (dyn && (f & gmask) == 0 && j == 0) *next_slot = fetched;
-        // (straight into xp also in the double-buffered build: this frame does not use its samples, and whatever is already
-        // requested for a later unit of the row sits in xp -- the tail's copy from xq has run, or the first load went there)
-        if (has_next) load_unit(fnext, xp);
-        if ((f & gmask) == 0) {
-          // a group starts here: the parked id must be visible to both waves before the group's last frame reads it, and
-          // the previous group's ring entries are drained (behind a barrier, as in the frame body).  Elsewhere in a group
-          // the passed-over frame needs no barrier at all: wave 1 has nothing to do in it.
-          __syncthreads();
-          if (ring_n > 0) {
-            if (wave == 0) finalise(ring_f0, ring_n);
-            ring_f0 = f;
-            ring_n = 0;
-            __syncthreads();  // (the finaliser reads slot 0 before the entry below overwrites it)
-          }
+      // ... and where the switch cannot look at that frame (one-block calls of a live state), the m = 7 frame hands the block
+      // over: its last 14 loads ARE the block's first 1792 samples, the last 256 came with its loads in two registers more
+      if (save7) {
+        const unsigned s = f >> 3;  // (one-block calls: row = stream)
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(prev_wr + (size_t)s * kN * 4, kN * 4);
+#pragma unroll
+        for (int m = 1; m < 8; m++) {
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xp[m].x), rw, voff4, T * 4 * (2 * m - 2), 0);
+          __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xp[m].y), rw, voff4, T * 4 * (2 * m - 1), 0);
         }
-        // (the entry: zeros -- or, under the tests' poison switch, squared magnitudes no signal reaches: fields 0 .. 3 of each
-        // wave's six words are magnitudes in the complex build, 0 and 1 in the real ones; the others indices or edge values)
-        if (wave == 0 && lane < kRingStride)
-          ring[ring_n * kRingStride + lane] = (p.poison && (lane % 6) < (MODE == kModeCplx ? 4 : 2) && lane < 12) ? 1e30f : 0.f;
-        ring_n++;
-        if (!has_next) break;
-        if (dyn && (fnext & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);
-        f = fnext;
-        continue;
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xs.x), rw, voff4, T * 4 * 14, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(xs.y), rw, voff4, T * 4 * 15, 0);
       }
     }
 #pragma unroll
     for (int run = 0; run < kRuns; run++) {
       if (ROWS && MODE == kModeCplx && run == 1 && skip_down) {  // (uniform over the workgroup: no barrier is left behind)
-        float* e = ring + ring_n * kRingStride + wave * 6;
+        float* e = ring + UC_RSLOT * kRingStride + wave * 6;
         if (lane == 0) {
           e[0] = pv[0]; e[1] = pv[1]; e[2] = p.poison ? 1e30f : 0.f; e[3] = e[2];
           e[4] = __uint_as_float(WIDE ? kpw[0] : kpack);
           e[5] = __uint_as_float(WIDE ? 0u : flags);
         }
-        ring_n++;
         continue;
       }
       v2f v[16];
@@ -836,16 +965,22 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       // prefetch the next frame a whole frame time ahead (HBM latency under load is
       // microseconds; at 3 waves/SIMD the 16 registers are free)
-      if (run == 0 && dyn && (f & gmask) == 0) {
+      if (run == 0 && dyn && (ROWS ? grp_first : (f & gmask) == 0)) {
         // first frame of a group: every load of this frame has been consumed above, so the atomic issued behind
         // them has returned too (a one-frame group parked it at the loop top already: same value again)
         if (j == 0) *next_slot = fetched;
       }
 #ifndef UC_KNOCK_NOLOAD  // (knock-out build: every frame re-uses the first frame's samples -- what the loop costs without HBM)
       if constexpr (kDblX) {
-        if (run == 0 && has_next) load_unit(fnext, xq);
+        if (run == 0 && has_next) {
+          resolve_next();
+          load_unit(fnext, xq);
+        }
       } else {
-        if (run == kRuns - 1 && has_next) load_unit(fnext, xp);
+        if (run == kRuns - 1 && has_next) {
+          resolve_next();
+          load_unit(fnext, xp);
+        }
       }
 #endif
       if (MODE == kModeRxReal && (UC_BAND_KNOCK & 2)) { }
@@ -859,10 +994,15 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       __syncthreads();
 #endif
       UC_STAMP(7);
+      if constexpr (ROWS) {
+        // a new group starts: drain the last one
+        if (run == 0 && grp_first && old_n > 0 && wave == 0) rows_finalise(old_f0, old_n, old_eval);
+      } else {
       if (run == 0 && ring_n > 0 && (f & gmask) == 0) {  // a new group starts: drain the last one
         if (wave == 0) finalise(ring_f0, ring_n);
         ring_f0 = f;
         ring_n = 0;
+      }
       }
       // (wave priority: low while it issues a burst of LDS stores, raised otherwise -- the SIMD's other waves get their
       // arithmetic issued ahead of the store burst; measured +0.5-0.7 %, the opposite assignment -1.5 %)
@@ -973,7 +1113,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
         auto pack16 = [](const Partial& q) {
           return ((unsigned)q.kr | ((q.nan_first & 1u) << 15)) | (((unsigned)q.kl | ((q.nan_first & 2u) << 14)) << 16);
         };
-        float* e = ring + ring_n * kRingStride + wave * 6;
+        float* e = ring + UC_RSLOT * kRingStride + wave * 6;
         if (kReal) {
           // the up history looks at qa in both windows, the down history at qb
           const Partial qu = window_partial_n<3>(qa, qa, kb, bw2);
@@ -1094,7 +1234,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       // ---- windows: this wave's partial arm_max_f32 results, in registers -----
       // (bins beyond bw2 fail the window predicates inside window_partial)
       const int k1 = 128 + lane;
-      float* e = ring + ring_n * kRingStride + wave * 6;
+      float* e = ring + UC_RSLOT * kRingStride + wave * 6;
       if (kReal) {
         // up history looks at m_a, down history at m_b; wave 1 also holds slot 1
         Common up, dn;
@@ -1112,7 +1252,7 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
                                  ((unsigned)dn.kl << 24));
         }
         // edge bins go straight to the ring from the lanes that own them
-        float* e0 = ring + ring_n * kRingStride;
+        float* e0 = ring + UC_RSLOT * kRingStride;
         if (j == 0) { e0[3] = m_a[0]; e0[4] = m_b[0]; }
         if (j == bw2) { e0[6 + 3] = m_a[0]; e0[6 + 4] = m_b[0]; }
         if (wave == 1 && k1 == bw2) { e0[6 + 3] = m_a[1]; e0[6 + 4] = m_b[1]; }
@@ -1134,10 +1274,10 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
       }
       UC_STAMP(8);
       __builtin_amdgcn_s_setprio(2);
-      if (run == kRuns - 1) ring_n++;
+      if (!ROWS && run == kRuns - 1) ring_n++;
     }
     if (!has_next) break;
-    if (dyn && (fnext & gmask) == 0 && j == 0) {
+    if (dyn && (ROWS ? next_first : (fnext & gmask) == 0) && j == 0) {
       // a new group was taken: ask for the one after it.  Issued here, where few registers are live.
       fetched = atomicAdd(p.work_ctr, 1u);
     }

@@ -18,13 +18,19 @@ constexpr int kBandWideMax = 319;   // ... of the WIDE build (three rounds), the
 struct BandParams {
   const void* frames;     // device, int32 or float
   size_t n_frames;
-  size_t stride;          // elements between frame starts
+  union {
+    size_t stride;        // elements between frame starts
+    size_t save_half;     // the ROWS build (frames are not a strided batch there): see save_to
+  };
   const float2* tab0;     // RX_REAL: (up*hann, down*hann)[n]   CPLX: (cos,sin)*hann of UP   PAIR: (down*hann, 0)
   const float2* tab1;     // CPLX: (cos,sin)*hann of DOWN
   const float2* tw;       // exp(-2 pi i k / 2048), k < 2048
   const float* mag_mean;  // device, 2 per frame {up,down}, or nullptr
   uint8_t* symbols;       // device or nullptr
-  uc_stats* stats;        // device or nullptr
+  union {
+    uc_stats* stats;      // device or nullptr
+    void* save_to;        // the ROWS build (writes magmax only): (save != 0) the state's two halves, save_half elements apart,
+  };                      // rows kN words apart -- a row's newest block goes to half (1 - *parity)
   float2* magmax;         // device or nullptr: (up, down) mag_max of every frame only (uc_receive_stream's replay needs no
                           // more: 8 instead of 64 bytes per frame to bring back); RX_REAL / SYNC_CPLX
   float* spectrum;        // device or nullptr: |X| of the window bins -bw2 .. +bw2 of every history,
@@ -47,11 +53,14 @@ struct BandParams {
   // ((s * row_blocks + jb) * 8 + m - 1) is the frame that starts 256 m samples into the block IN FRONT of block jb and ends
   // 256 m samples into block jb.  In front of block 0 of row s lies prev + s * prev_pitch (the newest block the FIFO
   // held before this call; prev_pitch = 0: one block of zeros for every row, the FIFO at power-on, main.c:94).
-  // n_frames = rows * row_blocks * 8; `stride` is not used.
+  // n_frames = rows * row_blocks * 8; `stride` and `stats` are not used (their slots carry save_half / save_to).
   // A live state keeps that block in TWO halves, prev_half elements apart, and one device word *parity says which half is
   // current: rows read half *parity, and (save != 0) the frame m = 8 of a row's last block -- which is that block, whole --
   // stores its raw words into the OTHER half of its row on the way through (the replay kernel behind the launch flips
   // *parity).  Nothing is copied by a kernel of its own, no frame reads what another one writes.  parity == nullptr: half 0.
+  // Where the block is READ and where it is SAVED are named apart: a caller that keeps its previous chunk alive
+  // (uc_rx_state_keep_previous) has the block in front read from that chunk (prev = its last block, prev_half = 0) and
+  // nothing saved; save_to / save_half name the state's two halves (rows kN words apart).
   const void* prev;
   size_t row_pitch, prev_pitch, prev_half;
   const unsigned int* parity;

@@ -95,5 +95,9 @@ int launch_rx_state_init(uint32_t* loop_state, size_t n_streams, uint32_t n, flo
 // current half holds.  Must run BEFORE the replay kernel of the call (which flips *parity).
 int launch_rx_last(const void* base, size_t pitch, const uint32_t* na, uint32_t nb, uint32_t n, size_t n_streams,
                    void* last, const unsigned int* parity, bool aligned16, hipStream_t stream);
+// uc_rx_state_keep_previous, ahead of a busy-masked call: the block every stream's FIFO holds last lies in the caller's kept
+// chunk (n words at kept + s * pitch); it goes into the CURRENT half of `last` (half *parity), where such a call looks for it.
+int launch_rx_keep(const void* kept, size_t pitch, uint32_t n, size_t n_streams, void* last, const unsigned int* parity,
+                   bool aligned16, hipStream_t stream);
 
 }  // namespace uc

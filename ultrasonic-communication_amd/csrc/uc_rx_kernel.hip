@@ -319,7 +319,35 @@ __global__ __launch_bounds__(kPackThreads) void last_kernel(const uint32_t* base
   }
 }
 
+// uc_rx_state_keep_previous ahead of a busy-masked call (uc_rx.hpp: launch_rx_keep)
+template <int VEC>
+__global__ __launch_bounds__(kPackThreads) void keep_kernel(const uint32_t* kept, size_t pitch, uint32_t n, uint32_t* last,
+                                                            const unsigned int* parity, size_t half) {
+  const size_t s = blockIdx.x;
+  const uint32_t* from = kept + s * pitch;
+  uint32_t* d = last + (*parity & 1u) * half + s * (size_t)n;
+  if (VEC == 4) {
+    typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+    for (uint32_t i = threadIdx.x; i < n / 4; i += kPackThreads) reinterpret_cast<v4u*>(d)[i] = reinterpret_cast<const v4u*>(from)[i];
+  } else {
+    for (uint32_t i = threadIdx.x; i < n; i += kPackThreads) d[i] = from[i];
+  }
+}
+
 }  // namespace
+
+int launch_rx_keep(const void* kept, size_t pitch, uint32_t n, size_t n_streams, void* last, const unsigned int* parity,
+                   bool aligned16, hipStream_t stream) {
+  if (n_streams == 0) return (int)hipSuccess;
+  const size_t half = n_streams * (size_t)n;
+  if (aligned16)
+    hipLaunchKernelGGL(keep_kernel<4>, dim3((unsigned)n_streams), dim3(kPackThreads), 0, stream, (const uint32_t*)kept, pitch, n,
+                       (uint32_t*)last, parity, half);
+  else
+    hipLaunchKernelGGL(keep_kernel<1>, dim3((unsigned)n_streams), dim3(kPackThreads), 0, stream, (const uint32_t*)kept, pitch, n,
+                       (uint32_t*)last, parity, half);
+  return (int)hipGetLastError();
+}
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream) {
   if (n_streams == 0) return (int)hipSuccess;

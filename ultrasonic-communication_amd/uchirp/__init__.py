@@ -38,7 +38,7 @@ EXPORTS = ["uc_abi_version", "uc_last_error", "uc_default_config", "uc_create", 
            "uc_group_process_batch", "uc_group_wait_gather", "uc_group_synchronize",
            "uc_device_count", "uc_device_malloc", "uc_device_free", "uc_device_copy", "uc_clock_probe", "uc_clock_read", "uc_clock_stamps", "uc_receive_streams", "uc_debug_busy_counters",
            "uc_rx_state_create", "uc_rx_state_reset", "uc_rx_state_destroy", "uc_receive_streams_next",
-           "uc_rx_state_streams", "uc_group_receive_streams", "uc_group_receive_streams_next", "uc_group_process_stream",
+           "uc_rx_state_streams", "uc_rx_state_keep_previous", "uc_group_receive_streams", "uc_group_receive_streams_next", "uc_group_process_stream",
            "uc_dfsdm_sinc5_streams", "uc_group_preflight"]
 GROUP_ID_BYTES = 128
 
@@ -156,6 +156,7 @@ def lib():
     L.uc_rx_state_destroy.argtypes = [C.c_void_p]
     L.uc_rx_state_destroy.restype = None
     L.uc_rx_state_streams.argtypes = [C.c_void_p]
+    L.uc_rx_state_keep_previous.argtypes = [C.c_void_p, C.c_int]
     L.uc_rx_state_streams.restype = C.c_size_t
     VPP = C.POINTER(C.c_void_p)
     L.uc_group_receive_streams.argtypes = [C.c_void_p, VPP, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, VPP, VPP, C.c_size_t,
@@ -330,6 +331,17 @@ class Engine:
         """uc_rx_state_create: n_streams live receivers at power-on; feed them chunk after chunk with LiveStreams.next()."""
         return LiveStreams(self, n_streams)
 
+    @staticmethod
+    def _rows_of(t):
+        """(n_streams, n_samples, stream stride in elements) of a 2-d GPU tensor whose rows are contiguous: a contiguous tensor, or
+        the first columns of a wider one (a chunk inside a ring buffer: stream_stride_elems > n_samples)."""
+        import torch
+        if (t.dim() != 2 or t.dtype not in (torch.int32, torch.float32) or t.device.type != "cuda" or
+                (t.shape[1] > 1 and t.stride(1) != 1) or (t.shape[0] > 1 and t.stride(0) < t.shape[1])):
+            raise ValueError("samples must be a 2-d int32 / float32 GPU tensor with contiguous rows")
+        ns, nsmp = int(t.shape[0]), int(t.shape[1])
+        return ns, nsmp, (int(t.stride(0)) if ns > 1 and t.stride(0) != nsmp else 0)
+
     def receive_many(self, samples, busy=None, text_cap=64, want_trace=True, stream=None, _state=None, pdm=False):
         """uc_receive_streams: samples [n_streams, n_samples] (numpy int32 / float32, or a contiguous torch device tensor);
         busy [n_streams, n_samples // n] or None.  Returns (texts: list of str, traces: list of RX_EVENT_DTYPE arrays or
@@ -338,10 +350,8 @@ class Engine:
         if _is_torch(samples):
             import torch
             t = samples
-            if t.dim() != 2 or not t.is_contiguous() or t.dtype not in (torch.int32, torch.float32) or t.device.type != "cuda":
-                raise ValueError("samples must be a contiguous 2-d int32 / float32 GPU tensor")
+            ns, nsmp, sstride = self._rows_of(t)
             dt = DTYPE_I32 if t.dtype == torch.int32 else DTYPE_F32
-            ns, nsmp = int(t.shape[0]), int(t.shape[1])
             ptr = C.c_void_p(t.data_ptr())
             if stream is None:
                 stream = torch.cuda.current_stream(t.device).cuda_stream
@@ -353,6 +363,7 @@ class Engine:
                 raise TypeError("samples must be a 2-d int32 / float32 array")
             dt = DTYPE_I32 if a.dtype == np.int32 else DTYPE_F32
             ns, nsmp = a.shape
+            sstride = 0
             ptr = a.ctypes.data_as(C.c_void_p)
         if pdm:
             if dt != DTYPE_I32:
@@ -372,11 +383,11 @@ class Engine:
                 ntext.ctypes.data_as(C.c_void_p), trace.ctypes.data_as(C.c_void_p) if trace is not None else None, max(nb, 1),
                 ntrace.ctypes.data_as(C.c_void_p), C.c_void_p(stream) if stream else None)
         if _state is None:
-            _check(lib().uc_receive_streams(self._h, ptr, dt, ns, nsmp, 0, *tail), "uc_receive_streams")
+            _check(lib().uc_receive_streams(self._h, ptr, dt, ns, nsmp, sstride, *tail), "uc_receive_streams")
         else:
             if ns != _state.n_streams:
                 raise ValueError("this state holds %d streams" % _state.n_streams)
-            _check(lib().uc_receive_streams_next(self._h, _state._h, ptr, dt, nsmp, 0, *tail), "uc_receive_streams_next")
+            _check(lib().uc_receive_streams_next(self._h, _state._h, ptr, dt, nsmp, sstride, *tail), "uc_receive_streams_next")
         texts = [bytes(text[i, :ntext[i]]).decode("latin-1") for i in range(ns)]
         traces = [trace[i, :ntrace[i]] for i in range(ns)] if want_trace else None
         return texts, traces
@@ -390,8 +401,7 @@ class Engine:
         busy (optional) uint8 [n_streams, k]."""
         import torch
         t = samples
-        if t.dim() != 2 or not t.is_contiguous() or t.dtype not in (torch.int32, torch.float32) or t.device.type != "cuda":
-            raise ValueError("samples must be a contiguous 2-d int32 / float32 GPU tensor")
+        ns, nsmp, sstride = self._rows_of(t)
         for name, x in (("text", text), ("n_text", n_text), ("trace", trace), ("n_trace", n_trace), ("busy", busy)):
             if x is not None and (x.device.type != "cuda" or not x.is_contiguous()):
                 raise ValueError("%s must be a contiguous GPU tensor" % name)
@@ -400,7 +410,6 @@ class Engine:
             if dt != DTYPE_I32:
                 raise TypeError("PDM words are 32-bit integers")
             dt = DTYPE_PDM
-        ns, nsmp = int(t.shape[0]), int(t.shape[1])
         if text.shape[0] != ns or n_text.numel() != ns or (busy is not None and tuple(busy.shape) != (ns, nsmp // self.n)):
             raise ValueError("output / busy shapes do not match %d streams" % ns)
         trace_cap = int(trace.shape[1]) if trace is not None else 0
@@ -411,11 +420,11 @@ class Engine:
         p = lambda x: C.c_void_p(x.data_ptr()) if x is not None else None
         tail = (p(busy), p(text), int(text.shape[1]), p(n_text), p(trace), trace_cap, p(n_trace), C.c_void_p(stream) if stream else None)
         if _state is None:
-            _check(lib().uc_receive_streams(self._h, p(t), dt, ns, nsmp, 0, *tail), "uc_receive_streams")
+            _check(lib().uc_receive_streams(self._h, p(t), dt, ns, nsmp, sstride, *tail), "uc_receive_streams")
         else:
             if ns != _state.n_streams:
                 raise ValueError("this state holds %d streams" % _state.n_streams)
-            _check(lib().uc_receive_streams_next(self._h, _state._h, p(t), dt, nsmp, 0, *tail), "uc_receive_streams_next")
+            _check(lib().uc_receive_streams_next(self._h, _state._h, p(t), dt, nsmp, sstride, *tail), "uc_receive_streams_next")
 
     def stream_geometry(self, n_samples):
         """uc_stream_geometry -> (halo, n_out, n_blocks, hop) for a buffer of n_samples (UC_STREAM)."""
@@ -821,6 +830,11 @@ class LiveStreams:
 
     def reset(self, stream=None):
         _check(lib().uc_rx_state_reset(self._h, C.c_void_p(stream) if stream else None), "uc_rx_state_reset")
+
+    def keep_previous(self, on=True):
+        """uc_rx_state_keep_previous: the caller promises to leave the samples of every call where they are, unchanged, until the
+        next call on this state has completed (a ring of >= 2 chunk buffers): nothing is copied into the state."""
+        _check(lib().uc_rx_state_keep_previous(self._h, 1 if on else 0), "uc_rx_state_keep_previous")
 
     def close(self):
         if getattr(self, "_h", None):
