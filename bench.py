@@ -685,8 +685,20 @@ def receive_leg(args, device, torch):
                 e1.record(side)
                 e1.synchronize()
                 graph_ms = e0.elapsed_time(e1) / reps_a
+            live.reset()
+            live.keep_previous(True)       # (every chunk is a buffer of its own here: uc_rx_state_keep_previous holds)
+            with torch.cuda.stream(side):
+                for k in range(10):
+                    live.next_into(chunks[k], text, ntext, stream=side.cuda_stream)
+                e0.record(side)
+                for k in range(reps_a):
+                    live.next_into(chunks[10 + k], text, ntext, stream=side.cuda_stream)
+                e1.record(side)
+                e1.synchronize()
+                keep_ms = e0.elapsed_time(e1) / reps_a
             live.close()
             out["live_4096_streams"].update({"ms_per_call_back_to_back": eager_ms, "ms_per_call_graph_replay": graph_ms,
+                                             "ms_per_call_back_to_back_keep_previous": keep_ms,
                                              "microphones_served_in_real_time_back_to_back": int(ns * N / fs / (eager_ms * 1e-3))})
             live = eng.live(ns)
             gp = torch.Generator(device=device)
@@ -723,22 +735,35 @@ def receive_leg(args, device, torch):
     text = torch.zeros((ns, 8), dtype=torch.uint8, device=device)
     ntext = torch.zeros(ns, dtype=torch.int32, device=device)
     side = torch.cuda.Stream(device)
-    with torch.cuda.stream(side):
-        for k in range(12):
-            live.next_into(bufs[k % 3], text, ntext, stream=side.cuda_stream)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(side)
-        for k in range(60):
-            live.next_into(bufs[k % 3], text, ntext, stream=side.cuda_stream)
-        e1.record(side)
-        e1.synchronize()
-    ms = e0.elapsed_time(e1) / 60
+    ms_by_contract = {}
+    for contract in ("default", "keep_previous"):
+        # default: the library copies every stream's newest block into the state on its way through the kernel (the caller may
+        # overwrite `samples` at once); keep_previous: the caller leaves a chunk alone until the NEXT call has completed -- a ring
+        # of >= 2 buffers, which this loop's three are -- and nothing is copied (uc_rx_state_keep_previous)
+        live.reset()
+        live.keep_previous(contract == "keep_previous")
+        with torch.cuda.stream(side):
+            for k in range(12):
+                live.next_into(bufs[k % 3], text, ntext, stream=side.cuda_stream)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(side)
+            for k in range(60):
+                live.next_into(bufs[k % 3], text, ntext, stream=side.cuda_stream)
+            e1.record(side)
+            e1.synchronize()
+        ms_by_contract[contract] = e0.elapsed_time(e1) / 60
+    ms, ms_keep = ms_by_contract["default"], ms_by_contract["keep_previous"]
     live.close()
     eng.close()
-    out["live_idle_rx_real_65536_streams"] = {"streams": ns, "ms_per_call_back_to_back": ms, "real_time_ms_per_call": N / fs * 1e3,
+    out["live_idle_rx_real_65536_streams"] = {"streams": ns, "ms_per_call_back_to_back": ms,
+                                              "ms_per_call_back_to_back_keep_previous": ms_keep,
+                                              "real_time_ms_per_call": N / fs * 1e3,
                                               "microphones_served_in_real_time": int(ns * N / fs / (ms * 1e-3)),
+                                              "microphones_served_in_real_time_keep_previous": int(ns * N / fs / (ms_keep * 1e-3)),
                                               "what": "uc_receive_streams_next, one new block of each of 65 536 silent microphones "
-                                                      "per call (IDLE streams: 3 or 5 of the 8 new FIFO offsets are evaluated)"}
+                                                      "per call (IDLE streams: 3 or 5 of the 8 new FIFO offsets are evaluated, the "
+                                                      "others cost nothing); keep_previous = uc_rx_state_keep_previous: the caller's "
+                                                      "ring of chunk buffers is read in place, no block is copied into the state"}
     del bufs
     return out
 

@@ -88,3 +88,25 @@ def test_register_budgets_the_design_rests_on(tmp_path):
     for k, v in pick(r"band_kernelILi0ELi1ELi3ELb0ELb0ELi0EE").items():
         assert all(e["group_segment_fixed_size"] <= 160 * 1024 // 6 for e in v), (k, v)
     assert max(e["vgpr_count"] for v in ks.values() for e in v) <= 256
+
+
+def test_machine_code_of_every_kernel_is_the_recorded_one():
+    """tests/golden/kernel_digests.json holds the sha256 of every kernel's machine code (tools/kernel_digest.py).  A change that is
+    not meant to touch a kernel -- a host-side refactoring, work on a sibling instantiation of the same template -- must leave the
+    digests alone; one that is meant to re-records them (`python tools/kernel_digest.py --update`) and says so in its commit.
+    Round 6: the batch builds of the band kernel (the headline kernel among them) are byte for byte what round 5 shipped while the
+    ROWS builds next to them were rebuilt."""
+    import importlib.util
+    import json
+    if not os.path.exists(LIB):
+        pytest.skip("libuchirp.so not built")
+    if not os.path.exists(os.path.join(LLVM, "llvm-objdump")):
+        pytest.skip("ROCm's llvm-objdump not found")
+    spec = importlib.util.spec_from_file_location("kernel_digest", os.path.join(ROOT, "tools", "kernel_digest.py"))
+    kd = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(kd)
+    with open(kd.RECORD) as f:
+        recorded = json.load(f)
+    built = kd.digests(LIB)
+    changed = sorted(k for k in set(recorded) | set(built) if recorded.get(k) != built.get(k))
+    assert not changed, "kernels whose machine code differs from tests/golden/kernel_digests.json: %s" % changed[:8]

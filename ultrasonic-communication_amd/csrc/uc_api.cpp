@@ -136,6 +136,7 @@ struct uc_ctx {
   int grid_override = 0;
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
+  uint32_t rx_need_force = 0;  // (env UC_RX_NEED_FORCE=0x1..: pricing runs only) every stream's need word is this one: WRONG results
   bool rx_poison = false;   // (env UC_RX_POISON=1, tests) the statistics the live receivers pass over are huge instead of zero
   int compress_chunk = 8;   // (env UC_COMPRESS_CHUNK) frame pairs per hand-out chunk of the compress kernel: a power of two >= 2
   int stream_chunk = 2;     // (env UC_STREAM_CHUNK) blocks per hand-out chunk of the stream kernel: a power of two
@@ -340,6 +341,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     }
     if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
     if (const char* g = getenv("UC_RX_POISON")) c->rx_poison = atoi(g) != 0;
+    if (const char* g = getenv("UC_RX_NEED_FORCE")) c->rx_need_force = (uint32_t)strtoul(g, nullptr, 0) | 0x80000000u;
     if (const char* g = getenv("UC_BAND_GROUP")) {
       const int v = atoi(g);
       if (v >= 1 && v <= 64 && (v & (v - 1)) == 0) c->band_group = v;
@@ -1739,6 +1741,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     rp.loop_state = st ? st->d_loop : nullptr;
     rp.parity = st ? st->d_parity : nullptr;
     rp.need = st ? st->d_need : nullptr;
+    rp.need_force = c->rx_need_force;
     int lrc;
     if (st && busy) {
       // what the next call's new offsets still read of this one: every stream's newest ACCEPTED block

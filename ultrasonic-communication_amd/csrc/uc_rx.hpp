@@ -78,6 +78,7 @@ struct RxParams {
   // step a block), the acquisition set the stream would use if it fell back to IDLE, and k = 16 when ks <= 3; both references:
   // 5 or 6 of the 8.  (uc_rx_kernel.hip: need_word.)  nullptr: none.
   uint32_t* need;
+  uint32_t need_force;   // pricing runs only (UC_TUNING=1 UC_RX_NEED_FORCE): bit 31 set = every stream's word is the low 9 bits of this
 };
 
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);

@@ -174,7 +174,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
     p.loop_state[s * kImageWords + kStateWords] = block_base + p.nb;
   }
   if (p.parity && s == 0) *p.parity ^= 1u;  // (nothing of this launch reads it)
-  if (p.need) p.need[s] = need_word(loop.state(), loop.turn(), loop.sync_position());
+  if (p.need) p.need[s] = p.need_force ? (p.need_force & 0x1ffu) : need_word(loop.state(), loop.turn(), loop.sync_position());
   if (p.carry_out && count) {
     // the FIFO after the call's last accepted block: its last 9 records are what the next block's FIFO starts with
     float2 keep[9];
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
     if (p.n_trace) p.n_trace[s] = nt;
     loop_mem[kStateWords] = block_base + p.nb;
     if (p.parity && s == 0) *p.parity ^= 1u;  // (nothing of this launch reads it)
-    if (p.need) p.need[s] = need_word(loop.state(), loop.turn(), loop.sync_position());
+    if (p.need) p.need[s] = p.need_force ? (p.need_force & 0x1ffu) : need_word(loop.state(), loop.turn(), loop.sync_position());
   }
   __syncthreads();
   if (p.loop_state && lane < kImageWords) p.loop_state[s * kImageWords + lane] = loop_mem[lane];
