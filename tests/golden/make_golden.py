@@ -19,6 +19,7 @@ writes are committed, the reference never travels.  What it does:
  * K6: copies three on-device capture triplets (agent/, data files) and parses ALL 24 into one .npz.
  * K7: sha256 + head of generator/ChirpTone.wav and the regeneration recipe's
    parameters.
+ * K8: the eight `history` rows of the on-device sync log in experiments/EXPERIMENT3.md:50-59 (the lab note's text: data).
 """
 import hashlib
 import importlib.util
@@ -173,6 +174,20 @@ def main():
     L = st.chirp_orth(updown="down")
     known["ChirpTone"]["H_head_int16"] = [int(v) for v in H.astype(np.int16)[:6]]
     known["ChirpTone"]["L_head_int16"] = [int(v) for v in L.astype(np.int16)[:6]]
+    # ---- K8: the on-device sync log (experiments/EXPERIMENT3.md:50-59) -------------------------------------
+    # eight rows of `struct history`, printed by a revision of the complex-FFT build (experiments/synchronization) that is not
+    # in the checkout: one row per FIFO offset (pos = N/2 + 256 k), fields as printed
+    rows = []
+    with open(os.path.join(REF, "experiments/EXPERIMENT3.md")) as f:
+        for ln, line in enumerate(f, 1):
+            m = re.match(r"max: ([\d.]+), max_r: ([\d.]+), max_l: ([\d.]+), s_time: (\d+), f_time: (\d+), i: (\d+), "
+                         r"i_left: (\d+), i_right: (\d+)", line.strip())
+            if m:
+                g = m.groups()
+                rows.append({"line": ln, "max": float(g[0]), "max_r": float(g[1]), "max_l": float(g[2]), "s_time": int(g[3]),
+                             "f_time": int(g[4]), "i": int(g[5]), "i_left": int(g[6]), "i_right": int(g[7])})
+    assert len(rows) == 8 and rows[0]["line"] == 51 and rows[-1]["line"] == 58, rows
+    known["EXPERIMENT3_sync_log"] = {"source": "experiments/EXPERIMENT3.md:50-59", "rows": rows}
     json.dump(known, open(os.path.join(OUT, "known_answers.json"), "w"), indent=1, sort_keys=True)
 
     # ---- K6: on-device captures (data files) ---------------------------------
