@@ -655,7 +655,7 @@ def receive_leg(args, device, torch):
                                         "real_time_ms_per_call": N / fs * 1e3, "headroom_x_real_time": N / fs / dt_live,
                                         "microphones_served_in_real_time": int(ns * N / fs / dt_live),
                                         "streams_whose_chunks_add_up_to_the_recorded_call": same,
-                                        "kernel_launches_per_call": 2, "new_dsp_frames_per_call": ns * 8,
+                                        "new_dsp_frames_per_call": ns * 8,
                                         "what": "one new block of every stream per call, the host reads the counts back after "
                                                 "every call (a sync per block)"}
             # the same step with no host in the loop: back to back on one stream, and replayed from ONE captured hipGraph
@@ -715,7 +715,6 @@ def receive_leg(args, device, torch):
                 e1.synchronize()
             live.close()
             out["live_pdm_4096_streams"] = {"streams": ns, "ms_per_call_back_to_back": e0.elapsed_time(e1) / reps_a,
-                                            "kernel_launches_per_call": 4,
                                             "what": "one new block of every microphone per call as 2048 x 32 PDM bits "
                                                     "(UC_DTYPE_PDM, random bits: timing only; parity: tests/test_dfsdm.py): "
                                                     "sinc5 + history, ROWS band launch, replay"}
@@ -862,8 +861,9 @@ class Watchdog:
     soon, not sit until the driver's own limit kills it without a line of output.  Every rank starts one: the main thread
     marks its progress (`mark`), a daemon thread checks the clock; past the limit it prints which rank, in which phase, after
     which step, for how long -- and ends the process with status 4 (os._exit: a thread cannot unblock a collective; the
-    launcher then ends the other ranks).  UC_BENCH_TIMEOUT seconds for the whole run (default 300: well inside the driver's
-    600 s), never a retry."""
+    launcher then ends the other ranks).  UC_BENCH_TIMEOUT seconds WITHOUT PROGRESS (default 300: no phase of a healthy run --
+    the first `import torch` on a fresh box, the rendezvous, a timed step -- takes that long; a slow but healthy 8-rank run
+    keeps marking progress and is not cut off) and three times that for the whole run; never a retry."""
 
     def __init__(self, rank, world, limit_s):
         import threading
@@ -883,7 +883,7 @@ class Watchdog:
     def _run(self):
         while not self._stop.wait(0.5):
             now = time.time()
-            if now - self.t0 > self.limit:
+            if now - self.t_mark > self.limit or now - self.t0 > 3.0 * self.limit:
                 sys.stderr.write("bench.py WATCHDOG: rank %d of %d gave up after %.0f s (UC_BENCH_TIMEOUT): last progress %.1f s ago, "
                                  "phase '%s'%s -- a peer has probably died or never arrived; exiting with status 4\n"
                                  % (self.rank, self.world, now - self.t0, now - self.t_mark, self.phase,
@@ -916,9 +916,9 @@ def launch_ranks(args):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else sys.stderr))
-    # every rank carries a watchdog of its own (UC_BENCH_TIMEOUT, default 300 s) and reports where it hung; this parent
-    # waits a little longer, then says which ranks were still alive and ends exactly those
-    deadline = time.time() + bench_timeout() + 15.0
+    # every rank carries a watchdog of its own (UC_BENCH_TIMEOUT: 300 s without progress, 900 s in all) and reports where it hung;
+    # this parent waits a little longer than the ranks' own cap, then says which ranks were still alive and ends exactly those
+    deadline = time.time() + 3.0 * bench_timeout() + 15.0
     rc = 0
     while rc == 0 and any(p.poll() is None for p in procs):
         time.sleep(0.2)
@@ -1447,6 +1447,10 @@ def main():
                                "kernel_ms_by_rank": [float(v) for v in km]}
             # what a step costs beyond the kernel on the slowest rank: the gather that the next kernel does not hide,
             # launch gaps, and (N > 1) waiting for the slowest rank inside the collective
+            out["kernel_ms_covers"] = ("[e0, e1] on the group's launch stream around uc_group_process_batch ALONE: the "
+                                       "write-after-gather wait for the buffer's previous gather is enqueued in FRONT of e0 "
+                                       "(uc_group_wait_gather) since round 5 -- not comparable with kernel_ms of rounds 1-4, "
+                                       "which included it; gather_ms_exposed = ms_per_step - kernel_ms carries it now")
             out["gather_ms_exposed"] = float((sm - km).max()) if have_gpu else None
             out["gather_ms_exposed_by_rank"] = [float(v) for v in (sm - km)] if have_gpu else None
             # the world size the C group's RCCL communicator reports (n_gpus above is torch.distributed's)

@@ -308,6 +308,8 @@ int uc_receive_stream_isr(uc_ctx* ctx, const void* samples, int dtype, size_t n_
  * 8 bytes per 256 samples of statistics are parked in the context between the kernels of a call.  That scratch serves one
  * call at a time: calls of one context on DIFFERENT streams are ordered by the library (the later one waits, on the device,
  * for the earlier one's kernels) -- use one context per stream, or live states, for calls that should overlap.
+ * For the same reason the state-less call cannot be captured into a hipGraph (-ENOTSUP while hip_stream is capturing): the
+ * live form below can.
  */
 int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_streams, size_t n_samples,
                        size_t stream_stride_elems, const uint8_t* busy /*nullable*/, char* text, size_t text_cap,
@@ -331,7 +333,8 @@ int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_str
  * UC_DTYPE_PDM), no copy kernel; see uc_rx_state_keep_previous for the one copy that is left.
  * Everything a step carries lives on the device, so with device pointers the call can be captured into a hipGraph and the
  * graph replayed for every block that arrives (make one eager call of the same shape first: it sizes the scratch; nothing is
- * allocated during a capture; uc_rx_state_reset puts the receivers back to power-on).
+ * allocated during a capture -- a call that would have to answers -ENOBUFS and records nothing; uc_rx_state_reset puts the
+ * receivers back to power-on).
  * A state belongs to the context that made it and must be destroyed BEFORE that context (uc_destroy / uc_group_destroy);
  * calls on different states of one context may be in flight on different streams at once, calls on one state are the
  * caller's to order (one stream).
@@ -499,8 +502,10 @@ uc_ctx* uc_group_ctx(uc_group* g, int local); /* the context of local device l (
  * Host pointers: the shard is staged through the context (synchronous copy-in), the stream is gathered in a device
  * buffer of the group and copied out; the call then blocks until gathered[l] is complete.
  * All ranks of the communicator must make the same sequence of calls (it is a collective).  Arguments are checked for EVERY
- * local device before anything is enqueued: a call refused for its arguments (-EINVAL: a NULL shard or buffer, a bad dtype, a
- * state of the wrong size) has touched no stream and started no collective -- the group is as it was and stays usable.
+ * local device before anything is enqueued: a call refused for its arguments (a NULL shard or buffer, a bad dtype, a state of
+ * the wrong size or of another context, and everything uc_receive_streams[_next] itself refuses a share for: partial blocks,
+ * overlapping streams, the state's dtype lock, a misaligned UC_DTYPE_PDM buffer ... -- the group runs that call's own argument
+ * check for every local device first) has touched no stream and started no collective -- the group is as it was and stays usable.
  * Any other negative return (a HIP or RCCL error in mid-step) may leave this rank's part of the step half enqueued (the other
  * ranks then wait in the collective): treat it as fatal for the group -- uc_group_destroy (which never waits for a peer) and
  * rebuild -- not as something to retry.

@@ -112,6 +112,42 @@ for world in (2, 3):
     g.process([x.data_ptr() for x in shards], nf, outs)
     g.synchronize()
     assert all(torch.equal(o, want) for o in outs)
+    # refusals of uc_receive_streams_next ITSELF that only the LAST local device's arguments earn (they used to come
+    # back after the kernels of the devices before it were enqueued): partial blocks, overlapping streams, a state of another
+    # context, a misaligned UC_DTYPE_PDM buffer.  Nothing may have run: the text buffers keep their fill, and the states are
+    # still at power-on (the live run behind it decodes from block 0)
+    ns_l = 2 * world
+    sts = [g.rx_state(l, 2) for l in range(world)]
+    alien = g.rx_state(0, 2)                                       # two streams, but of local device 0's context
+    xs = [torch.randn((2, N + 8), device=dev) * 50.0 for _ in range(world)]
+    fill = [torch.full((ns_l, 8), 0x33, dtype=torch.uint8, device=dev) for _ in range(world)]
+    last = world - 1
+    for what in ("partial", "overlap", "alien", "pdm"):
+        kw = dict(n_samples=N, stride=N + 8, dtype=uchirp.DTYPE_F32)
+        st_, x_ = list(sts), [x.data_ptr() for x in xs]
+        if what == "partial":
+            kw["n_samples"] = N + 4
+        elif what == "overlap":
+            kw["stride"] = N - 4
+        elif what == "alien":
+            st_[last] = alien
+        else:
+            kw["dtype"] = uchirp.DTYPE_PDM
+            x_[last] += 4                                          # 4 bytes off a 16-byte boundary
+        try:
+            g.receive_streams(x_, ns_l, kw["n_samples"], fill, 8, stride=kw["stride"], dtype=kw["dtype"], states=st_)
+            raise SystemExit("uc_group_receive_streams_next accepted a %s call" % what)
+        except uchirp.UchirpError:
+            pass
+        g.synchronize()
+        assert all(bool((f == 0x33).all()) for f in fill), (world, what)
+        checks += 1
+    alien.close()
+    for s_ in sts:
+        s_.close()
+    g.process([x.data_ptr() for x in shards], nf, outs)              # ... and the group still works
+    g.synchronize()
+    assert all(torch.equal(o, want) for o in outs)
     g.close()                                                        # returns: nothing is waiting for a peer
     checks += 1
 

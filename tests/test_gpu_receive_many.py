@@ -471,6 +471,52 @@ def test_kept_chunks_two_captured_steps_replayed_in_turn(uchirp, variant):
     e.close()
 
 
+def test_what_cannot_be_captured_is_refused_not_recorded(uchirp):
+    """Only uc_receive_streams_next can be captured (a uc_rx_state owns its scratch): the state-less call shares the context's
+    scratch through an event a capture cannot carry and answers -ENOTSUP; a live step whose scratch has not been sized by an
+    eager call of the same shape would have to allocate inside the capture and answers -ENOBUFS.  Neither records anything, and
+    the same objects work afterwards."""
+    import torch
+    dev = torch.device("cuda:0")
+    ns = 6
+    e = uchirp.Engine(uco.RX_REAL)
+    x = torch.randn((ns, N), device=dev) * 50.0
+    text = torch.zeros((ns, 8), dtype=torch.uint8, device=dev)
+    ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    live = e.live(ns)
+    seen = []
+    for what in ("stateless", "unsized"):
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(s):
+            with torch.cuda.graph(g, stream=s):
+                try:
+                    if what == "stateless":
+                        e.receive_many_into(x, text, ntext, stream=s.cuda_stream)
+                    else:
+                        live.next_into(x, text, ntext, stream=s.cuda_stream)
+                    seen.append((what, "accepted"))
+                except uchirp.UchirpError as ex:
+                    seen.append((what, str(ex)))
+    assert "captured" in seen[0][1] and "ENOTSUP" not in seen[0][0], seen
+    assert "eager call" in seen[1][1], seen
+    torch.cuda.synchronize()
+    # both forms still work eagerly, and the live step is capturable once sized
+    e.receive_many_into(x, text, ntext)
+    live.next_into(x, text, ntext)
+    live.reset()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            live.next_into(x, text, ntext, stream=s.cuda_stream)
+    g.replay()
+    torch.cuda.synchronize()
+    live.close()
+    e.close()
+
+
 def test_plain_c_host_runs_live_microphones(tmp_path):
     """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
     call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream

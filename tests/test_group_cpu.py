@@ -121,6 +121,24 @@ def test_rows_divisor_is_exact_for_every_dividend_below_2_to_31(tmp_path):
     assert out.returncode == 0 and "rows_divisor ok" in out.stdout, out.stdout[-2000:]
 
 
+def test_need_words_cover_everything_the_switch_reads(tmp_path):
+    """uc::need_word (csrc/uc_rx.hpp) tells a live receiver's band launch which of a block's 8 new FIFO offsets (and whether the DOWN
+    statistics) may be skipped.  tests/cpp/need_check.cpp runs main()'s switch (include/uchirp_mainloop.hpp) over random
+    statistics with a dsp() that records every position it is asked for: each read must lie inside the need word emitted when
+    its block was still to come (1, 2 or 3 blocks earlier), every word holds m = 7 or m = 8 (the frame that hands the block to
+    the state), and uc_rx_state_reset's power-on word is need_word(IDLE, 0, 0).  A deliberately wrong mask (-DUC_NEED_BREAK: the
+    "one block later" term dropped) must FAIL the same harness."""
+    src = os.path.join(ROOT, "tests", "cpp", "need_check.cpp")
+    for flags, ok in (([], True), (["-DUC_NEED_BREAK"], False)):
+        exe = str(tmp_path / ("need_check" + ("_broken" if flags else "")))
+        subprocess.check_call(["g++", "-std=c++17", "-O2", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include"] + flags + [src, "-o", exe])
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+        if ok:
+            assert out.returncode == 0 and "need_word ok" in out.stdout, (out.stdout[-500:], out.stderr[-500:])
+        else:
+            assert out.returncode != 0 and "passes its offset" in out.stderr, (out.stdout[-500:], out.stderr[-500:])
+
+
 def test_bench_watchdog_ends_a_hung_rank_loudly():
     """bench.py's Watchdog: a rank that makes no progress past UC_BENCH_TIMEOUT prints which rank, which phase, which step --
     and exits with status 4 (the launcher then ends the others); a rank that finishes in time is left alone."""

@@ -33,11 +33,14 @@ $LLVM/clang++ -std=c++17 -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $SAN -
    "$ROOT/tests/stubs/loopback_rccl.cpp" -L/opt/rocm/lib -lamdhip64 -lrt
 $LLVM/clang++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" $SAN -o "$B/san_host" \
    "$ROOT/tests/cpp/san_host.cpp" "$PKG/csrc/uc_tables.cpp" -L"$B" -luchirp -Wl,-rpath,"$B" -Wl,-rpath,"$(dirname "$RT")"
+$LLVM/clang++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" $SAN -o "$B/need_check" "$ROOT/tests/cpp/need_check.cpp"
 echo "== built: $(ls "$B" | tr '\n' ' ')"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1:strict_string_checks=1:detect_stack_use_after_return=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 echo "== 1. C++ harness (mainloop header with a CPU dsp(), table builders, partition / span functions, C-ABI argument checks)"
 UC_TUNING=1 UC_RCCL_LIB="$B/libloopback_rccl.so" "$B/san_host"
+echo "== 1b. the need words of the live receivers against main()'s switch (tests/cpp/need_check.cpp)"
+"$B/need_check"
 echo "== 2. the CPU test files against the instrumented libraries (UCHIRP_LIB / UCO_LIB), ASan runtime preloaded into python"
 LD_PRELOAD="$RT" UCHIRP_LIB="$B/libuchirp.so" UCO_LIB="$B/libuc_oracle.so"\
   python -m pytest "$ROOT/tests/test_group_cpu.py" "$ROOT/tests/test_oracle_golden.py" "$ROOT/tests/test_abi.py" \

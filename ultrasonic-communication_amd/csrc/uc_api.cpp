@@ -37,11 +37,23 @@ int hip_fail(hipError_t e, const char* what) {
   return fail(-EIO, "%s: %s", what, hipGetErrorString(e));
 }
 
+// set while a call records into a stream capture: scratch must not be (re)allocated there (hipMalloc / hipFree are not
+// capturable, and a freed buffer may be baked into the graph) -- a buffer that would have to grow fails the call instead
+thread_local bool g_capturing = false;
+struct CaptureNoAlloc {
+  const bool prev;
+  explicit CaptureNoAlloc(bool on) : prev(g_capturing) { g_capturing = on || prev; }
+  ~CaptureNoAlloc() { g_capturing = prev; }
+};
+
 struct DevBuf {
   void* p = nullptr;
   size_t cap = 0;
   int ensure(size_t bytes) {
     if (bytes <= cap) return 0;
+    if (g_capturing)
+      return fail(-ENOBUFS, "scratch of %zu bytes would have to be allocated during a stream capture: make one eager call of "
+                            "the same shape first (it sizes the scratch)", bytes);
     if (p) (void)hipFree(p);
     p = nullptr;
     cap = 0;
@@ -118,7 +130,7 @@ struct uc_ctx {
   DevBuf s_cic_in, s_cic_out, s_cic_hist;
   // staging for host-pointer calls
   DevBuf s_frames, s_mm, s_sym, s_stats;
-  int band_blocks_per_cu[5][3][2] = {};  // [default / wide / default + spectrum stores / rows / rows + wide][mode][dtype]: the instantiations differ in registers
+  int band_blocks_per_cu[6][3][2] = {};  // [default / wide / default + spectrum stores / rows / rows + wide / overlapping frames][mode][dtype]: the instantiations differ in registers
   int full_blocks_per_cu[2] = {0, 0};    // [dtype]: the int32 / f32 instantiations differ in registers
   int iq_blocks_per_cu[2] = {0, 0};
   int stream_blocks_per_cu[2] = {0, 0};
@@ -689,15 +701,20 @@ static int band_launch(uc_ctx* c, uc::BandParams& p, int dtype, hipStream_t stre
   // SYNC_CPLX runs two transforms per frame off two complex tables: at 2 waves/SIMD both tables stay in registers (at 3
   // the second one is loaded inside the loop, behind the frame prefetch in the in-order vector-memory queue):
   // 2.59e8 against 2.45e8 frames/s (profiles/r03_sync_cplx_waves.txt)
-  const int waves = rows ? (mode == uc::kModeCplx ? 2 : 3)  // (the ROWS build exists at each mode's default occupancy)
+  // (the ROWS build exists at each mode's default occupancy, its WIDE form at 2 waves/SIMD: the value names the instantiation
+  // that is dispatched -- uc_band_kernel.hip: UC_DISPATCH)
+  const int waves = rows ? ((mode == uc::kModeCplx || p.wide) ? 2 : 3)
                          : (mode == uc::kModeCplx && !c->band_waves_set) ? 2 : c->band_waves;
   // uc_window_spectrum runs the SAME two-round build as the statistics path when the windows fit it (bandwidth2 <= 191): the
   // instantiation that also stores the window bins (uc_band_kernel.hip: SPEC), so that what the device captures are
   // compared with is the arithmetic of the throughput kernel
   const bool spec = p.spectrum != nullptr && !p.wide;
-  // (frames that overlap run the default build with default-policy loads: same registers, same occupancy -- shares the entry)
-  int& bpc = c->band_blocks_per_cu[rows ? (p.wide ? 4 : 3) : (p.wide ? 1 : (spec ? 2 : 0))][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
-  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0, spec, rows);
+  // frames that overlap (stride < n) run the default build with default-policy loads -- a kernel of its own, asked for its own
+  // occupancy (the dispatch takes it for RX_REAL at 3 and SYNC_CPLX at 2 waves/SIMD only)
+  const bool overlap = !rows && !spec && !p.wide && p.stride < (size_t)uc::kN && mode != uc::kModePair &&
+                       ((mode == uc::kModeRxReal && waves == 3) || (mode == uc::kModeCplx && waves == 2));
+  int& bpc = c->band_blocks_per_cu[rows ? (p.wide ? 4 : 3) : (p.wide ? 1 : (spec ? 2 : (overlap ? 5 : 0)))][mode][dtype == UC_DTYPE_I32 ? 0 : 1];
+  if (bpc == 0) bpc = uc::band_max_blocks_per_cu(mode, dtype, waves, p.wide != 0, spec, rows, overlap);
   size_t grid = (size_t)c->num_cu * (size_t)bpc;
   // DECHIRP_DOWN (frame pairs, the HBM-bound one) runs at the loads-only floor of this kernel structure, and that floor is
   // lower with fewer concurrent streams: 5 workgroups per CU instead of the 6 that fit: 7.69 against 7.54e8 frames/s,
@@ -1531,21 +1548,19 @@ struct uc_rx_state {
   size_t kept_pitch = 0;
 };
 
-static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples, int dtype, size_t n_streams, size_t n_samples,
-                                size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
-                                uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
-                                void* hip_stream) {
+// Everything uc_receive_streams[_next] refuses for its ARGUMENTS, and nothing else: no HIP call that enqueues, no allocation.
+// receive_streams_impl runs it first; uc_group_receive_streams[_next] runs it for EVERY local device before it touches a stream
+// (uc_group.cpp: a refused group call has started nothing -- ADVICE r5).  0, or the negative code the call would return.
+int uc::receive_streams_check(uc_ctx* c, uc_rx_state* st, bool live, const void* samples, int dtype, size_t n_streams, size_t n_samples,
+                              size_t stream_stride_elems, const char* text, size_t text_cap, size_t trace_cap) {
   if (!c || !text || text_cap == 0) return fail(-EINVAL, "uc_receive_streams: NULL argument");
+  if (live && (!st || st->c != c)) return fail(-EINVAL, "uc_receive_streams_next: the state belongs to another context");
   if (c->cfg.variant != UC_RX_REAL && c->cfg.variant != UC_SYNC_CPLX)
     return fail(-ENOTSUP, "uc_receive_streams: variant %d has no up/down state machine", (int)c->cfg.variant);
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32 && dtype != UC_DTYPE_PDM)
     return fail(-EINVAL, "uc_receive_streams: bad dtype %d", dtype);
   if (n_streams == 0) return 0;
   const uint32_t n = c->cfg.n;
-  const uint32_t per_block = n / 256;  // new FIFO offsets per accepted block
-  const bool pdm = dtype == UC_DTYPE_PDM;
-  const int dtype_in = dtype;
-  const size_t stream_stride_in = stream_stride_elems ? stream_stride_elems : n_samples;
   if (stream_stride_elems == 0) stream_stride_elems = n_samples;
   if (stream_stride_elems < n_samples) return fail(-EINVAL, "uc_receive_streams: streams overlap (stride %zu < %zu samples)",
                                                    stream_stride_elems, n_samples);
@@ -1558,6 +1573,33 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       return fail(-EINVAL, "uc_receive_streams_next: the streams began as dtype %d", st->dtype);
     if (st->blocks_seen + nb >= ((uint64_t)1 << 32)) return fail(-EOVERFLOW, "uc_receive_streams_next: 2^32 blocks per stream");
   }
+  if (nb) {
+    if (!samples) return fail(-EINVAL, "uc_receive_streams: samples is NULL");
+    if (n_streams * nb * (size_t)(n / 256) >= ((size_t)1 << 31))
+      return fail(-EINVAL, "uc_receive_streams: %zu new FIFO offsets in one call (at most 2^31 - 1)", n_streams * nb * (size_t)(n / 256));
+    // UC_DTYPE_PDM on device memory: the DFSDM kernel's alignment rules (a host buffer is staged into aligned scratch)
+    if (dtype == UC_DTYPE_PDM && is_device_ptr(samples) &&
+        (((uintptr_t)samples & 15u) != 0 || (n_streams > 1 && (stream_stride_elems & 3u) != 0)))
+      return fail(-EINVAL, "uc_receive_streams: UC_DTYPE_PDM device buffers must be 16-byte aligned, the stride a multiple of 4 words");
+  }
+  return 0;
+}
+
+static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples, int dtype, size_t n_streams, size_t n_samples,
+                                size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
+                                uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
+                                void* hip_stream) {
+  if (const int rc = uc::receive_streams_check(c, st, st != nullptr, samples, dtype, n_streams, n_samples, stream_stride_elems, text,
+                                               text_cap, trace_cap))
+    return rc;
+  if (n_streams == 0) return 0;
+  const uint32_t n = c->cfg.n;
+  const uint32_t per_block = n / 256;  // new FIFO offsets per accepted block
+  const bool pdm = dtype == UC_DTYPE_PDM;
+  const int dtype_in = dtype;
+  const size_t stream_stride_in = stream_stride_elems ? stream_stride_elems : n_samples;
+  if (stream_stride_elems == 0) stream_stride_elems = n_samples;
+  const size_t nb = n_samples / n;
   if (trace && trace_cap == 0) trace = nullptr;
   hipError_t e = hipSetDevice(c->device);
   if (e != hipSuccess) return hip_fail(e, "hipSetDevice");
@@ -1566,6 +1608,13 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
   RxScratch& sc = st ? st->rx : c->rx;
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   const bool capturing = stream && hipStreamIsCapturing(stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone;
+  // Capture is the live form's: a uc_rx_state owns its scratch.  The context's scratch serves every state-less call, on any
+  // stream, ordered by an event a capture cannot carry -- a captured state-less call would share it with eager calls and
+  // replays without any ordering
+  if (!st && capturing)
+    return fail(-ENOTSUP, "uc_receive_streams: the stream is being captured -- only uc_receive_streams_next (a uc_rx_state owns "
+                          "its scratch) can be captured into a hipGraph");
+  const CaptureNoAlloc no_alloc(capturing);
   if (!st && !capturing) {
     // the context's scratch serves one call at a time: a call on another stream than the last one waits, ON THE DEVICE, for
     // that one's kernels (a live state has scratch of its own and needs none of this)
@@ -1609,10 +1658,19 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
   }
 
   if (nb) {
-    if (!samples) return fail(-EINVAL, "uc_receive_streams: samples is NULL");
     const size_t n_frames = n_streams * nb * per_block;
-    if (n_frames >= ((size_t)1 << 31))
-      return fail(-EINVAL, "uc_receive_streams: %zu new FIFO offsets in one call (at most 2^31 - 1)", n_frames);
+    // (every scratch buffer of the call is sized before its first launch: a call that cannot be served -- out of memory, or a
+    // capture that would have to allocate -- has enqueued nothing)
+    if (int rc = sc.rec.ensure(n_frames * sizeof(float2))) return rc;
+    if (pdm)
+      if (int rc = sc.pcm.ensure(n_streams * nb * (size_t)n * 4)) return rc;
+    if (busy) {
+      int rc = sc.acc.ensure(n_streams * nb * sizeof(uint32_t));
+      if (!rc) rc = sc.na.ensure(n_streams * sizeof(uint32_t));
+      if (!rc) rc = sc.pad.ensure(n_streams * nb * (size_t)n * 4);
+      if (!rc && !is_device_ptr(busy)) rc = sc.busy.ensure(n_streams * nb);
+      if (rc) return rc;
+    }
     // inputs
     const void* d_in = samples;
     if (!is_device_ptr(samples)) {
@@ -1823,7 +1881,8 @@ extern "C" int uc_rx_state_reset(uc_rx_state* st, void* hip_stream) {
   const uint32_t n = c->cfg.n;
   e = hipMemsetAsync(st->d_last, 0, 2 * st->n_streams * (size_t)n * 4, stream);
   if (e == hipSuccess) e = hipMemsetAsync(st->d_parity, 0, sizeof(unsigned int), stream);
-  if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)st->d_need, 0x052, st->n_streams, stream);  // IDLE, turn 0
+  if (e == hipSuccess)  // (power-on: IDLE, turn 0 -- the word the replay would have left)
+    e = hipMemsetD32Async((hipDeviceptr_t)st->d_need, (int)uc::need_word(UC_STATE_IDLE, 0, 0), st->n_streams, stream);
   if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)st->d_hist, (int)UC_PDM_SILENCE, st->n_streams * 4, stream);
   if (e == hipSuccess) e = hipMemsetAsync(st->d_carry, 0, st->n_streams * (size_t)(n / 256 + 1) * sizeof(float2), stream);
   if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(FIFO state)");
@@ -1877,7 +1936,7 @@ extern "C" int uc_receive_streams_next(uc_ctx* c, uc_rx_state* st, const void* s
                                        size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
                                        uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
                                        void* hip_stream) {
-  if (!st || st->c != c) return fail(-EINVAL, "uc_receive_streams_next: the state belongs to another context");
+  if (!st || !c || st->c != c) return fail(-EINVAL, "uc_receive_streams_next: the state belongs to another context");
   return receive_streams_impl(c, st, samples, dtype, st->n_streams, n_samples, stream_stride_elems, busy, text, text_cap, n_text,
                               trace, trace_cap, n_trace, hip_stream);
 }

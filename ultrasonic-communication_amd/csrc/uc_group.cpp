@@ -21,6 +21,7 @@
 #include <vector>
 
 #include "../../include/uchirp.h"
+#include "uc_rx.hpp"
 
 namespace uc {
 void set_error(const char* msg);  // uc_api.cpp: the thread's uc_last_error() text
@@ -515,13 +516,17 @@ static int group_receive(uc_group* g, uc_rx_state* const* states, const void* co
 
   // every argument of every local device first: a refused call has enqueued nothing (see uc_group_process_batch)
   if (dtype != UC_DTYPE_I32 && dtype != UC_DTYPE_F32 && dtype != UC_DTYPE_PDM) return fail(-EINVAL, "%s: bad dtype %d", who, dtype);
-  if (n_samples >= (size_t)2048 && !samples) return fail(-EINVAL, "%s: samples is NULL", who);
   for (int l = 0; l < nl; l++) {
     size_t first = 0, count = 0;
     uc_partition(n_streams_total, g->world, g->first_rank + l, &first, &count);
     if (!text[l]) return fail(-EINVAL, "%s: text[%d] is NULL", who, l);
     if (n_text && !n_text[l]) return fail(-EINVAL, "%s: n_text[%d] is NULL", who, l);
-    if (count && n_samples >= (size_t)2048 && !samples[l]) return fail(-EINVAL, "%s: samples[%d] is NULL", who, l);
+    // everything uc_receive_streams[_next] itself would refuse this device's share for (whole blocks, the state's dtype lock
+    // and context, overlapping streams, UC_DTYPE_PDM alignment ... -- some of it differs by rank): the same function it runs
+    if (count)
+      if (const int rc = uc::receive_streams_check(g->loc[(size_t)l].ctx, states ? states[l] : nullptr, states != nullptr, samples[l],
+                                                   dtype, count, n_samples, stream_stride_elems, text[l], text_cap, 0))
+        return rc;
     if (states) {
       // (a rank that owns no stream -- fewer streams than GPUs -- has no state to bring: NULL)
       if (count && !states[l]) return fail(-EINVAL, "%s: states[%d] is NULL", who, l);

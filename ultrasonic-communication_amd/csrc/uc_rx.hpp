@@ -81,6 +81,33 @@ struct RxParams {
   uint32_t need_force;   // pricing runs only (UC_TUNING=1 UC_RX_NEED_FORCE): bit 31 set = every stream's word is the low 9 bits of this
 };
 
+// (shared by the replay kernels, uc_rx_state_reset and the CPU harness that ties it to main()'s switch: tests/cpp/san_host.cpp)
+// what the switch can still look at of a stream's NEXT block (uc_rx.hpp: RxParams::need).  FIFO offsets are counted in steps
+// of 256 samples: k = pos / 256 = 0 .. 16; the next block's NEW offsets are k = 9 .. 16 (bit k - 9); one block later they sit at
+// k - 8 = 1 .. 8, two blocks later only k = 16 is left (at 0).
+UC_HD inline uint32_t need_word(int state, uint32_t turn, uint32_t sync_position) {
+  if (state == UC_STATE_IDLE) return turn ? 0x0ADu : 0x052u;  // acquisition: k = 4 + turn + 2 i now, the other set next block
+  if (state == UC_STATE_SYNCHRONIZING) return 0x1FFu;         // may lock onto any of the eight positions: everything
+  // SYNCHRONIZED / DATA_RECEIVING at ks = sync_position / 256 (main.c:491-550, resync 243-273): the pass of the next block reads
+  // ks - 1 .. ks + 1 (both references) and moves by at most one step; the pass after it therefore reads ks - 2 .. ks + 2 of ITS
+  // FIFO = this block's k = ks + 6 .. ks + 10 -- or, if the stream falls back to IDLE in between, the acquisition set of the
+  // turn it kept (k = 12 + turn, 14 + turn, 16 + turn); two blocks on only k = 16 is left, at position 0: reachable from ks <= 3
+  const int ks = (int)(sync_position >> 8), t = (int)turn;
+  uint32_t m = 0x100u;
+  for (int k = 9; k <= 16; k++) {
+    const bool now = k >= ks - 1 && k <= ks + 1;
+    const bool next = k >= ks + 6 && k <= ks + 10;
+    const bool idle_next = k == 12 + t || k == 14 + t || k == 16 + t;
+    const bool later = k == 16 && ks <= 3;
+#ifdef UC_NEED_BREAK  // (a deliberately WRONG mask, to show that the poisoned runs notice: tools/soak_live.py must fail with it)
+    if (now || idle_next || later) m |= 1u << (k - 9);
+#else
+    if (now || next || idle_next || later) m |= 1u << (k - 9);
+#endif
+  }
+  return m;
+}
+
 int launch_rx_accept(const uint8_t* busy, size_t n_streams, uint32_t nb, uint32_t* acc, uint32_t* na, hipStream_t stream);
 // the accepted blocks of every stream laid out one behind the other: dst[s * pitch + k * n ..) = k-th accepted block of
 // stream s (k < na[s]; the rest of the row is left as it is)
@@ -100,5 +127,9 @@ int launch_rx_last(const void* base, size_t pitch, const uint32_t* na, uint32_t 
 // chunk (n words at kept + s * pitch); it goes into the CURRENT half of `last` (half *parity), where such a call looks for it.
 int launch_rx_keep(const void* kept, size_t pitch, uint32_t n, size_t n_streams, void* last, const unsigned int* parity,
                    bool aligned16, hipStream_t stream);
+
+// uc_api.cpp: the argument checks of uc_receive_streams[_next] alone (live: the uc_receive_streams_next form, st required)
+int receive_streams_check(uc_ctx* c, uc_rx_state* st, bool live, const void* samples, int dtype, size_t n_streams, size_t n_samples,
+                          size_t stream_stride_elems, const char* text, size_t text_cap, size_t trace_cap);
 
 }  // namespace uc

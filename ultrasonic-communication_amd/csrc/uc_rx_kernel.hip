@@ -92,32 +92,6 @@ constexpr int kStateWords = (int)((sizeof(SeqLoop) + 3) / 4);
 constexpr int kImageWords = kStateWords + 1;
 static_assert(sizeof(SeqLoop) % 4 == 0, "main()'s locals are whole words");
 
-// what the switch can still look at of a stream's NEXT block (uc_rx.hpp: RxParams::need).  FIFO offsets are counted in steps
-// of 256 samples: k = pos / 256 = 0 .. 16; the next block's NEW offsets are k = 9 .. 16 (bit k - 9); one block later they sit at
-// k - 8 = 1 .. 8, two blocks later only k = 16 is left (at 0).
-__device__ __forceinline__ uint32_t need_word(int state, uint32_t turn, uint32_t sync_position) {
-  if (state == UC_STATE_IDLE) return turn ? 0x0ADu : 0x052u;  // acquisition: k = 4 + turn + 2 i now, the other set next block
-  if (state == UC_STATE_SYNCHRONIZING) return 0x1FFu;         // may lock onto any of the eight positions: everything
-  // SYNCHRONIZED / DATA_RECEIVING at ks = sync_position / 256 (main.c:491-550, resync 243-273): the pass of the next block reads
-  // ks - 1 .. ks + 1 (both references) and moves by at most one step; the pass after it therefore reads ks - 2 .. ks + 2 of ITS
-  // FIFO = this block's k = ks + 6 .. ks + 10 -- or, if the stream falls back to IDLE in between, the acquisition set of the
-  // turn it kept (k = 12 + turn, 14 + turn, 16 + turn); two blocks on only k = 16 is left, at position 0: reachable from ks <= 3
-  const int ks = (int)(sync_position >> 8), t = (int)turn;
-  uint32_t m = 0x100u;
-  for (int k = 9; k <= 16; k++) {
-    const bool now = k >= ks - 1 && k <= ks + 1;
-    const bool next = k >= ks + 6 && k <= ks + 10;
-    const bool idle_next = k == 12 + t || k == 14 + t || k == 16 + t;
-    const bool later = k == 16 && ks <= 3;
-#ifdef UC_NEED_BREAK  // (a deliberately WRONG mask, to show that the poisoned runs notice: tools/soak_live.py must fail with it)
-    if (now || idle_next || later) m |= 1u << (k - 9);
-#else
-    if (now || next || idle_next || later) m |= 1u << (k - 9);
-#endif
-  }
-  return m;
-}
-
 // main()'s loop, one lane per stream
 __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   const size_t s = (size_t)blockIdx.x * 64 + threadIdx.x;
