@@ -33,7 +33,7 @@ $LLVM/clang++ -std=c++17 -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include $SAN -
    "$ROOT/tests/stubs/loopback_rccl.cpp" -L/opt/rocm/lib -lamdhip64 -lrt
 $LLVM/clang++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" $SAN -o "$B/san_host" \
    "$ROOT/tests/cpp/san_host.cpp" "$PKG/csrc/uc_tables.cpp" -L"$B" -luchirp -Wl,-rpath,"$B" -Wl,-rpath,"$(dirname "$RT")"
-$LLVM/clang++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" $SAN -o "$B/need_check" "$ROOT/tests/cpp/need_check.cpp"
+$LLVM/clang++ -std=c++17 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -I"$ROOT/include" $SAN -o "$B/need_check" "$ROOT/tests/cpp/need_check.cpp" -Wl,-rpath,"$(dirname "$RT")"
 echo "== built: $(ls "$B" | tr '\n' ' ')"
 export ASAN_OPTIONS=detect_leaks=0:halt_on_error=1:abort_on_error=1:strict_string_checks=1:detect_stack_use_after_return=1
 export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
