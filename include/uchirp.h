@@ -335,6 +335,11 @@ int uc_receive_streams(uc_ctx* ctx, const void* samples, int dtype, size_t n_str
  * graph replayed for every block that arrives (make one eager call of the same shape first: it sizes the scratch; nothing is
  * allocated during a capture -- a call that would have to answers -ENOBUFS and records nothing; uc_rx_state_reset puts the
  * receivers back to power-on).
+ * Errors: every argument check and every scratch allocation of a call comes before its first launch -- a call refused with
+ * -EINVAL / -ENOTSUP / -EOVERFLOW / -ENOBUFS / -ENOMEM has enqueued nothing and the state is as it was (the next call
+ * continues the streams).  Any OTHER negative return (-EIO: a HIP launch or copy failed in mid-call) leaves the state
+ * UNDEFINED -- some of its kernels may have run, the half-flag and the block counts may not match -- until uc_rx_state_reset
+ * puts every receiver back to power-on; do not continue the streams on it.
  * A state belongs to the context that made it and must be destroyed BEFORE that context (uc_destroy / uc_group_destroy);
  * calls on different states of one context may be in flight on different streams at once, calls on one state are the
  * caller's to order (one stream).

@@ -1,6 +1,6 @@
 // uchirp_mainloop.hpp -- the receiver's `while (1)` (receiver/Src/main.c:417-554) and resync() (main.c:243-273) as
 // ONE header-only implementation over an abstract dsp().  Both users replay exactly this code:
-//   * libuchirp.so's uc_receive_stream (csrc/uc_api.cpp): dsp() looks the frame up in the statistics of one batched
+//   * libuchirp.so's uc_receive_stream (csrc/uc_api_rx.cpp): dsp() looks the frame up in the statistics of one batched
 //     launch over every FIFO offset;
 //   * the C++ host layer (include/uchirp_receiver.hpp, tests/cpp/rx_main.cpp): dsp() is one GPU call per frame;
 //   * uc_receive_streams (csrc/uc_rx_kernel.hip): the SAME code compiled for the device, one lane per recorded stream

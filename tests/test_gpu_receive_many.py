@@ -517,6 +517,46 @@ def test_what_cannot_be_captured_is_refused_not_recorded(uchirp):
     e.close()
 
 
+def test_refused_live_calls_leave_the_state_as_it_was(uchirp):
+    """uc_receive_streams_next checks every argument and sizes all scratch BEFORE its first launch: a refused call (partial blocks,
+    overlapping streams, another dtype in mid-stream, NULL text) has enqueued nothing -- the streams continue behind it exactly
+    as if it had not been made -- and uc_rx_state_reset behind anything puts the receivers back to power-on."""
+    import ctypes as C
+    import torch
+    x, busy, msgs = _transmissions(9, seed=4242, blocks=140)
+    ns = x.shape[0]
+    e = uchirp.Engine(uco.SYNC_CPLX)
+    whole_t, whole_tr = e.receive_many(x)
+    live = e.live(ns)
+    L = uchirp.lib()
+    texts, traces = [""] * ns, [[] for _ in range(ns)]
+    xd = torch.from_numpy(x).to("cuda:0")
+    tbuf = torch.zeros((ns, 8), dtype=torch.uint8, device="cuda:0")
+    for b in range(140):
+        if b % 10 == 5:
+            ch = xd[:, b * N:(b + 1) * N].contiguous()
+            args = dict(samples=C.c_void_p(ch.data_ptr()), dtype=uchirp.DTYPE_F32, nsmp=N, stride=0, text=C.c_void_p(tbuf.data_ptr()))
+            bad = [dict(nsmp=N + 3), dict(stride=N - 1), dict(dtype=uchirp.DTYPE_I32), dict(text=None), dict(dtype=9)]
+            for k in bad:
+                a = dict(args, **k)
+                rc = L.uc_receive_streams_next(e._h, live._h, a["samples"], a["dtype"], a["nsmp"], a["stride"], None, a["text"], 8,
+                                               None, None, 0, None, None)
+                assert rc < 0 and rc != -5, (k, rc)                 # refused for its arguments (never -EIO)
+        t, tr = live.next(np.ascontiguousarray(x[:, b * N:(b + 1) * N]))
+        for s_ in range(ns):
+            texts[s_] += t[s_]
+            traces[s_].append(tr[s_])
+    for s_ in range(ns):
+        assert texts[s_] == whole_t[s_], s_
+        assert np.array_equal(np.concatenate(traces[s_]).view(np.uint8), whole_tr[s_].view(np.uint8)), s_
+    live.reset()
+    t2, tr2 = live.next(x[:, :60 * N])
+    t1, tr1 = e.receive_many(x[:, :60 * N])
+    assert t1 == t2 and all(np.array_equal(a.view(np.uint8), b_.view(np.uint8)) for a, b_ in zip(tr1, tr2))
+    live.close()
+    e.close()
+
+
 def test_plain_c_host_runs_live_microphones(tmp_path):
     """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
     call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream

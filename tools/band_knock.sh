@@ -14,7 +14,7 @@ if [ "$1" = build ]; then
     if [ "$k" = L ]; then def="-DUC_KNOCK_NOLOAD"; else def="-DUC_BAND_KNOCK=$k"; fi
     /opt/rocm/bin/hipcc $FL $def -c csrc/uc_band_kernel.hip -o /tmp/uc_band_k$k.o 2>/dev/null
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libuchirp_bk$k.so /tmp/uc_band_k$k.o csrc/uc_full_kernel.o \
-      csrc/uc_iq_kernel.o csrc/uc_stream_kernel.o csrc/uc_cic_kernel.o csrc/uc_api.o csrc/uc_tables.o
+      csrc/uc_iq_kernel.o csrc/uc_stream_kernel.o csrc/uc_cic_kernel.o csrc/uc_api_core.o csrc/uc_api_rx.o csrc/uc_api_stream.o csrc/uc_api_cic.o csrc/uc_api_clock.o csrc/uc_tables.o
   done
   ls libuchirp_bk*.so
 else

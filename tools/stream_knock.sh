@@ -12,7 +12,7 @@ if [ "$1" = build ]; then
   for k in $KS; do
     /opt/rocm/bin/hipcc $FL -DUC_STREAM_KNOCK=$k -c csrc/uc_stream_kernel.hip -o /tmp/uc_stream_k$k.o
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o libuchirp_sk$k.so csrc/uc_band_kernel.o csrc/uc_full_kernel.o \
-      csrc/uc_iq_kernel.o /tmp/uc_stream_k$k.o csrc/uc_cic_kernel.o csrc/uc_api.o csrc/uc_tables.o
+      csrc/uc_iq_kernel.o /tmp/uc_stream_k$k.o csrc/uc_cic_kernel.o csrc/uc_api_core.o csrc/uc_api_rx.o csrc/uc_api_stream.o csrc/uc_api_cic.o csrc/uc_api_clock.o csrc/uc_tables.o
   done
   ls -la libuchirp_sk*.so
 else

@@ -87,7 +87,7 @@ __device__ __forceinline__ void lds_st(float* lds, int cidx, v2f v) {
 #define UC_CLOCK_END(dbg, waves_per_wg) do { } while (0)
 #endif
 
-// ---- dynamic hand-out counters (uc_api.cpp: take_work_counter) -----------------------------------
+// ---- dynamic hand-out counters (uc_api_core.cpp: take_work_counter) -----------------------------------
 // ctr[0] = the next ticket, ctr[1] = workgroups that have left.  Every workgroup of a dynamically dealt launch calls
 // this ONCE, from one thread, on its way out; the last one to leave puts both words back to zero.  A counter slot is
 // therefore zero whenever no launch is using it: no memset in front of a launch, and none recorded into a captured

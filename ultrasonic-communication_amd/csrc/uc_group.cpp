@@ -24,7 +24,7 @@
 #include "uc_rx.hpp"
 
 namespace uc {
-void set_error(const char* msg);  // uc_api.cpp: the thread's uc_last_error() text
+void set_error(const char* msg);  // uc_api_core.cpp: the thread's uc_last_error() text
 }
 
 namespace {

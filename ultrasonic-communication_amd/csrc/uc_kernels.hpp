@@ -1,4 +1,4 @@
-// uc_kernels.hpp -- launch interface between the C-ABI (uc_api.cpp) and the
+// uc_kernels.hpp -- launch interface between the C-ABI (uc_api_*.cpp) and the
 // gfx950 kernels (uc_band_kernel.hip, uc_full_kernel.hip).
 #pragma once
 #include <hip/hip_runtime.h>

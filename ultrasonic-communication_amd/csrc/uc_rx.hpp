@@ -1,4 +1,4 @@
-// uc_rx.hpp -- what the host replay (uc_api.cpp: uc_receive_stream) and the device replay (uc_rx_kernel.hip:
+// uc_rx.hpp -- what the host replay (uc_api_rx.cpp: uc_receive_stream) and the device replay (uc_rx_kernel.hip:
 // uc_receive_streams) of main()'s switch share: the dsp() stand-in that looks a frame up in the statistics of the batched
 // launch, and the launch interface of the rx kernels.
 #pragma once
@@ -128,7 +128,7 @@ int launch_rx_last(const void* base, size_t pitch, const uint32_t* na, uint32_t 
 int launch_rx_keep(const void* kept, size_t pitch, uint32_t n, size_t n_streams, void* last, const unsigned int* parity,
                    bool aligned16, hipStream_t stream);
 
-// uc_api.cpp: the argument checks of uc_receive_streams[_next] alone (live: the uc_receive_streams_next form, st required)
+// uc_api_rx.cpp: the argument checks of uc_receive_streams[_next] alone (live: the uc_receive_streams_next form, st required)
 int receive_streams_check(uc_ctx* c, uc_rx_state* st, bool live, const void* samples, int dtype, size_t n_streams, size_t n_samples,
                           size_t stream_stride_elems, const char* text, size_t text_cap, size_t trace_cap);
 
