@@ -850,6 +850,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-live-traffic", action="store_true",
                     help="N = 1: do not run the two rocprofv3 --pmc child passes (FETCH_SIZE, WRITE_SIZE); roofline.traffic then "
                          "comes from the committed record and says so")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak (default, the contract's line) = --frames per GPU; strong = --frames IN ALL, uc_partition shares "
+                         "of --frames / N per GPU (N must divide it), the same gather -- the launch, tail and gather costs that a "
+                         "fixed 1 Mi frames per GPU hides show here")
     ap.add_argument("--single-process", action="store_true",
                     help="--gpus N in ONE process: a uc_group over N devices (include/uchirp.h), as a C host would drive the node "
                          "(tests/c/host_multi.c); the default is one process per GPU")
@@ -892,6 +896,16 @@ class Watchdog:
                 os._exit(4)
 
 
+def shard_frames(args, world):
+    """frames per GPU and step: --frames (weak scaling, the contract's line) or --frames / world (strong: --frames in all, the
+    equal uc_partition shares)"""
+    if args.scaling == "strong" and world > 1:
+        if args.frames % world:
+            raise SystemExit("bench.py --scaling strong: %d GPUs do not divide %d frames" % (world, args.frames))
+        return args.frames // world
+    return args.frames
+
+
 def bench_timeout():
     return float(os.environ.get("UC_BENCH_TIMEOUT", "300"))
 
@@ -914,6 +928,7 @@ def launch_ranks(args):
         # (hipIpcGetMemHandle) fails with "invalid argument".  The image exports it already; keep it if a caller's
         # environment dropped it.  (setdefault: an explicit value from the caller wins.)
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("NCCL_DEBUG", "WARN")         # a failing RCCL call says why, on stderr, in the run that failed
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=out0 if r == 0 else sys.stderr))
     # every rank carries a watchdog of its own (UC_BENCH_TIMEOUT: 300 s without progress, 900 s in all) and reports where it hung;
@@ -966,7 +981,7 @@ def single_process(args):
     sys.stdout.flush()
     json_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)                              # RCCL's banner and anything else on descriptor 1 goes to stderr
-    nf, mag_mean = args.frames, 1000.0
+    nf, mag_mean = shard_frames(args, world), 1000.0
     devs = [torch.device("cuda", 0 if rehearse else d) for d in range(world)]
     wd = Watchdog(0, 1, bench_timeout())      # (one process: ncclCommInitAll and the in-process gathers can hang too)
     wd.mark("uc_group_create (ncclCommInitAll over %d devices)" % world)
@@ -1038,7 +1053,7 @@ def single_process(args):
     value = world * nf * args.steps / elapsed
     out = {"metric": "chirp frames/s (2048-pt FFT demod)", "value": value, "unit": "frames/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
-           "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ramp_ms": args.ramp_ms,
+           "scaling": args.scaling if world > 1 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic", "ramp_ms": args.ramp_ms,
            "ramp_launches": ramp_launches,
            "gather_backend": "uc_group_process_batch in ONE process: ncclCommInitAll, ncclAllGather in place per device inside "
                              "one ncclGroupStart/End, called from C",
@@ -1113,6 +1128,7 @@ def main():
             sk.bind(("127.0.0.1", 0))
             os.environ["MASTER_PORT"] = str(sk.getsockname()[1])
             sk.close()
+        os.environ.setdefault("NCCL_DEBUG", "WARN")  # (also under torch.distributed.run: RCCL's own reason for a failure, on stderr)
         wd.mark("rendezvous (torch.distributed.init_process_group)")
         if rehearse:
             dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -1123,7 +1139,7 @@ def main():
 
     from uchirp import synth
     mag_mean = 1000.0
-    nf = args.frames
+    nf = shard_frames(args, world)
     hello = multi and args.variant == "rx_real"
     eng = None
     if have_gpu:
@@ -1358,6 +1374,22 @@ def main():
         alls = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(alls, mine)
         per_rank = np.array([a.cpu().numpy() for a in alls])       # [world, (kernel_ms, ms_per_step)]
+        # who ran where: the device every rank holds (name, uuid, PCI bus id, LOCAL_RANK), the peer-access row the HIP runtime
+        # reports from it to every visible device, and the clock its chip held -- so that a slow or mis-mapped rank of the first
+        # real 8-GPU run can be named from the line alone
+        topo = {"rank": rank, "local_rank": local_rank, "pid": os.getpid()}
+        if have_gpu:
+            try:
+                pr = torch.cuda.get_device_properties(device)
+                topo.update({"device": pr.name, "uuid": str(getattr(pr, "uuid", "")), "pci_bus_id": getattr(pr, "pci_bus_id", None),
+                             "multi_processor_count": pr.multi_processor_count,
+                             "can_access_peer": [bool(d == device.index or torch.cuda.can_device_access_peer(device.index, d))
+                                                 for d in range(torch.cuda.device_count())],
+                             "shader_clock_GHz_under_the_kernel": clk_live})
+            except Exception as ex:             # (diagnostics must never fail the run)
+                topo["error"] = str(ex)[:200]
+        topo_all = [None] * world
+        dist.all_gather_object(topo_all, topo)
 
     gate_failures = []
     if rank == 0:
@@ -1366,7 +1398,8 @@ def main():
         out = {
             "metric": "chirp frames/s (2048-pt FFT demod)", "value": value if have_gpu else None, "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": args.scaling if world > 1 else "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "ramp_ms": args.ramp_ms if have_gpu else 0.0, "ramp_launches": ramp_launches,
         }
@@ -1451,6 +1484,9 @@ def main():
                                        "write-after-gather wait for the buffer's previous gather is enqueued in FRONT of e0 "
                                        "(uc_group_wait_gather) since round 5 -- not comparable with kernel_ms of rounds 1-4, "
                                        "which included it; gather_ms_exposed = ms_per_step - kernel_ms carries it now")
+            out["per_rank"]["roofline_frac_by_rank"] = ([float(nf * BYTES_PER_FRAME / (v * 1e-3) / 1e9 / HBM_PEAK_GBS) if v > 0 else None
+                                                         for v in km] if have_gpu else None)
+            out["per_rank"]["ranks"] = topo_all
             out["gather_ms_exposed"] = float((sm - km).max()) if have_gpu else None
             out["gather_ms_exposed_by_rank"] = [float(v) for v in (sm - km)] if have_gpu else None
             # the world size the C group's RCCL communicator reports (n_gpus above is torch.distributed's)

@@ -35,6 +35,22 @@ def test_gpus_2_starts_two_ranks_and_decodes_hello_world():
     assert len(d["per_rank"]["kernel_ms_by_rank"]) == 2 and d["per_rank"]["ms_per_step"]["max"] > 0 and d["gates_failed"] == []
 
 
+def test_strong_scaling_line_shares_a_fixed_batch():
+    """`--scaling strong`: --frames is the batch of the whole job, every rank takes its uc_partition share (--frames / N), the
+    same gather; the line says so.  Plumbing on CPU (gloo, no kernel); a world that does not divide the batch is refused."""
+    p = _run(["--gpus", "2", "--frames", "2340", "--steps", "3", "--warmup", "1", "--scaling", "strong"],
+             {"UC_BENCH_REHEARSE": "1", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["frames_per_gpu"] == 1170
+    assert d["transmissions"] == 2340 // 117 and d["transmissions_decoded_exactly"] == d["transmissions"] and d["gates_failed"] == []
+    # who ran where rides in the N > 1 line
+    assert [r["rank"] for r in d["per_rank"]["ranks"]] == [0, 1] and all("pid" in r for r in d["per_rank"]["ranks"])
+    p = _run(["--gpus", "2", "--frames", "1171", "--steps", "2", "--warmup", "1", "--scaling", "strong"],
+             {"UC_BENCH_REHEARSE": "1", "HIP_VISIBLE_DEVICES": "", "ROCR_VISIBLE_DEVICES": ""})
+    assert p.returncode != 0 and "do not divide" in p.stderr
+
+
 def test_gpus_must_equal_world_size():
     p = _run(["--gpus", "2"], {"WORLD_SIZE": "1", "RANK": "0"})
     assert p.returncode != 0
@@ -172,3 +188,22 @@ def test_gpu_two_ranks_through_the_c_group_rehearsed_on_one_gpu(tmp_path):
     # round 5: the exposed gather per rank (kernel bracketed alone: the write-after-gather wait sits in front of it), the world
     # size the C group's communicator reports, and the statement that no curve was measured by the builder
     assert len(d["gather_ms_exposed_by_rank"]) == 2 and d["rccl_world"] == 2 and "no 1 -> 8 curve" in d["scaling_note"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_gpu_strong_scaling_rehearsed_on_one_gpu(tmp_path, world):
+    """`--gpus N --scaling strong --single-process` at world 2, 4 and 8 on the one GPU of this box (every rank on device 0, the
+    loop-back stand-in for RCCL): a FIXED batch of 8 x 117 x 35 frames shared out by uc_partition, the real kernel, the C group's
+    gather, every transmission decoded.  The first real 8-GPU run then differs by the transport alone."""
+    so = str(tmp_path / "libloopback_rccl.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-fPIC", "-shared", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                           os.path.join(ROOT, "tests", "stubs", "loopback_rccl.cpp"), "-o", so, "-L/opt/rocm/lib", "-lamdhip64", "-lrt"],
+                          stderr=subprocess.DEVNULL)
+    total = 8 * 117 * 35
+    d = _one_line(_run(["--gpus", str(world), "--single-process", "--scaling", "strong", "--frames", str(total), "--steps", "4",
+                        "--warmup", "1", "--ramp-ms", "10"],
+                       {"UC_BENCH_REHEARSE": "1", "UC_TUNING": "1", "UC_RCCL_LIB": so, "UC_GROUP_SHARE_DEVICES": "1"}))
+    assert d["n_gpus"] == world and d["scaling"] == "strong" and d["gates_failed"] == [] and "rehearsal" in d
+    assert d["config"]["frames_per_gpu"] == total // world
+    assert d["transmissions"] == total // 117 and d["transmissions_decoded_exactly"] == d["transmissions"]

@@ -12,6 +12,10 @@ iq2048_bb_f32 iq1024_fw_f32 iq1024_bb_f32 stream_d8_f32 sinc5 sinc5_streams rows
 (sinc5_streams: uc_dfsdm_sinc5_streams, one 2048-word block of every microphone per launch; rows_*: the live receivers' step,
 uc_receive_streams_next with one new block of every stream per launch = 8 new FIFO offsets per stream: the band kernel's ROWS
 build + the replay kernel)
+rows_*_f32: EVERY offset evaluated (UC_RX_NEED_FORCE = 0x1ff: what a stream in a tracking state costs at most);
+rows_*_f32_idle: noise streams with the idle masks (3 or 5 of the 8, UP only) -- the unit is still the offset INDEX;
+rows_*_f32_idle_keep: the same with uc_rx_state_keep_previous (no block is copied into the state);
+spectrum_rx_real_f32: uc_window_spectrum (the pipeline() boundary: the SPEC build, statistics + the window bins stored).
 (keys of profiles/r*_valu_insts.json; the I/Q targets run on the pass-band stream of BASELINE configs[2]).
 """
 import argparse
@@ -52,8 +56,18 @@ SPEC = {  # target -> (kernel-name substring, units, unit, algorithmic bytes per
     # cache), 8192 B kept for the next call, 8 x 8 B of records -- per NEW FIFO OFFSET (frame): 3080 B
     "rows_rx_real_f32": ("band_kernel", nf, "frame", 3080),
     "rows_sync_cplx_f32": ("band_kernel", nf, "frame", 3080),
+    "rows_rx_real_f32_idle": ("band_kernel", nf, "frame", 3080),
+    "rows_sync_cplx_f32_idle": ("band_kernel", nf, "frame", 3080),
+    # ... with uc_rx_state_keep_previous: nothing kept, 2 x 8192 B read + 64 B of records per stream -- 2056 B per offset index
+    "rows_rx_real_f32_idle_keep": ("band_kernel", nf, "frame", 2056),
+    "rows_sync_cplx_f32_idle_keep": ("band_kernel", nf, "frame", 2056),
+    # uc_window_spectrum: the frame in, 2 histories x (2 x 156 + 1) window bins out
+    "spectrum_rx_real_f32": ("band_kernel", nf, "frame", 8192 + 2 * 313 * 4),
 }
 kname, units, unit, alg = SPEC[T]
+if T in ("rows_rx_real_f32", "rows_sync_cplx_f32"):   # (pricing hook of the library, read at uc_create)
+    os.environ["UC_TUNING"] = "1"
+    os.environ["UC_RX_NEED_FORCE"] = "0x1ff"
 if args.info:
     print(json.dumps({"target": T, "kernel": kname, "units": units, "unit": unit, "alg_bytes_per_unit": alg}))
     sys.exit(0)
@@ -100,11 +114,17 @@ elif T.startswith("rows_"):
     if args.zeros:
         chunk.zero_()
     live = e.live(ns)
+    keep = T.endswith("_keep")
+    chunks = [chunk, chunk.clone()] if keep else [chunk]     # (keep_previous: a ring of two buffers, used in turn)
+    if keep:
+        live.keep_previous(True)
     text = torch.zeros((ns, 16), dtype=torch.uint8, device=dev)
     ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
+    turn = [0]
 
     def launch():
-        live.next_into(chunk, text, ntext, stream=stream.cuda_stream)
+        live.next_into(chunks[turn[0] % len(chunks)], text, ntext, stream=stream.cuda_stream)
+        turn[0] += 1
 elif T == "sinc5":
     e = uchirp.Engine(uchirp.RX_REAL)
     g = torch.Generator(device=dev)
@@ -120,7 +140,17 @@ else:
         frames.zero_()
     if T == "band_rx_real_i32":
         frames = (frames.round().to(torch.int64) * 256).to(torch.int32)
-    if T == "stream_d8_f32":
+    if T == "spectrum_rx_real_f32":
+        e = uchirp.Engine(uchirp.RX_REAL, mag_mean=1000.0)
+        import ctypes as C
+        wb = uchirp.lib().uc_window_bins(e._h)
+        spec = torch.empty((nf, e.spf, wb), dtype=torch.float32, device=dev)
+
+        def launch():
+            rc = uchirp.lib().uc_window_spectrum(e._h, C.c_void_p(frames.data_ptr()), uchirp.DTYPE_F32, nf, 0,
+                                                 C.c_void_p(spec.data_ptr()), C.c_void_p(stream.cuda_stream))
+            assert rc == 0, uchirp.lib().uc_last_error()
+    elif T == "stream_d8_f32":
         e = uchirp.Engine(uchirp.STREAM)
         xs = frames.reshape(-1)
         _, n_out, n_blocks, _ = e.stream_geometry(xs.numel())

@@ -29,7 +29,7 @@ for info_f in sorted(glob.glob(os.path.join(src, "*.info.json"))):
         continue
     avg = {k: sum(v) / len(v) for k, v in sorted(ctr.items())}
     g = avg.get
-    d = {"kernel": key, "units_per_dispatch": units, "unit": info["unit"], "alg_bytes_per_unit": info["alg_bytes_per_unit"],
+    d = {"round": tag, "kernel": key, "units_per_dispatch": units, "unit": info["unit"], "alg_bytes_per_unit": info["alg_bytes_per_unit"],
          "dispatches_averaged": {k: len(v) for k, v in sorted(ctr.items())}, "counters_per_dispatch": avg}
     if dur:
         d["ms_per_dispatch_profiled"] = sum(dur) / len(dur)
