@@ -9,6 +9,9 @@ targets="${2:-band_rx_real_f32 band_sync_cplx_f32 band_dechirp_down_f32 compress
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 out="gpurun_out/pmcall_$tag"
 mkdir -p "$out"
+# (every gpurun call starts on a fresh box: seed the summaries from the committed record, so that a run over SOME targets
+# updates it instead of replacing it -- round 6 lost a first pass that way)
+for f in "${tag}_pmc_all.json" "${tag}_valu_insts.json"; do [ -f "profiles/$f" ] && [ ! -f "$out/$f" ] && cp "profiles/$f" "$out/$f"; done
 SQ_A="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT"
 SQ_B="SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM"
 rocprofv3 -L > "$out/counter_list.txt" 2>&1

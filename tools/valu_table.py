@@ -17,14 +17,18 @@ for info_f in sorted(glob.glob(os.path.join(src, "*.info.json"))):
     info = json.load(open(info_f))
     t, key, units = info["target"], info["kernel"], info["units"]
     ctr, dur = collections.defaultdict(list), []
+    skip = int(info.get("skip_first_dispatches", 0))   # (live states: the first step runs on the power-on need word)
     for f in sorted(glob.glob(os.path.join(src, t + ".*.counters.csv"))):
-        for r in csv.DictReader(open(f)):
-            if key in r["Kernel_Name"]:
+        seen = collections.Counter()
+        rows_f = sorted((r for r in csv.DictReader(open(f)) if key in r["Kernel_Name"]), key=lambda r: int(r.get("Dispatch_Id", 0)))
+        for r in rows_f:
+            seen[r["Counter_Name"]] += 1
+            if seen[r["Counter_Name"]] > skip:
                 ctr[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for f in sorted(glob.glob(os.path.join(src, t + ".*.trace.csv"))):
-        for r in csv.DictReader(open(f)):
-            if key in r["Kernel_Name"]:
-                dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
+        rows_f = sorted((r for r in csv.DictReader(open(f)) if key in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))
+        for r in rows_f[skip:]:
+            dur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) * 1e-6)
     if not ctr:
         continue
     avg = {k: sum(v) / len(v) for k, v in sorted(ctr.items())}
