@@ -699,6 +699,10 @@ def receive_leg(args, device, torch):
             live.close()
             out["live_4096_streams"].update({"ms_per_call_back_to_back": eager_ms, "ms_per_call_graph_replay": graph_ms,
                                              "ms_per_call_back_to_back_keep_previous": keep_ms,
+                                             "contracts": "ms_per_call, ..._back_to_back and ..._graph_replay: the default contract "
+                                                          "(the state keeps a copy of every stream's newest block); "
+                                                          "..._keep_previous: uc_rx_state_keep_previous (every chunk here is a "
+                                                          "buffer of its own)",
                                              "microphones_served_in_real_time_back_to_back": int(ns * N / fs / (eager_ms * 1e-3))})
             live = eng.live(ns)
             gp = torch.Generator(device=device)
@@ -754,11 +758,15 @@ def receive_leg(args, device, torch):
     ms, ms_keep = ms_by_contract["default"], ms_by_contract["keep_previous"]
     live.close()
     eng.close()
-    out["live_idle_rx_real_65536_streams"] = {"streams": ns, "ms_per_call_back_to_back": ms,
-                                              "ms_per_call_back_to_back_keep_previous": ms_keep,
+    out["live_idle_rx_real_65536_streams"] = {"streams": ns, "ms_per_call_back_to_back": ms_keep,
+                                              "contract": "uc_rx_state_keep_previous (this loop's ring of three chunk buffers keeps "
+                                                          "it); the default contract -- the library copies every stream's newest "
+                                                          "block into the state, what rounds 4-5 measured -- is "
+                                                          "ms_per_call_back_to_back_default_contract",
+                                              "ms_per_call_back_to_back_default_contract": ms,
                                               "real_time_ms_per_call": N / fs * 1e3,
-                                              "microphones_served_in_real_time": int(ns * N / fs / (ms * 1e-3)),
-                                              "microphones_served_in_real_time_keep_previous": int(ns * N / fs / (ms_keep * 1e-3)),
+                                              "microphones_served_in_real_time": int(ns * N / fs / (ms_keep * 1e-3)),
+                                              "microphones_served_in_real_time_default_contract": int(ns * N / fs / (ms * 1e-3)),
                                               "what": "uc_receive_streams_next, one new block of each of 65 536 silent microphones "
                                                       "per call (IDLE streams: 3 or 5 of the 8 new FIFO offsets are evaluated, the "
                                                       "others cost nothing); keep_previous = uc_rx_state_keep_previous: the caller's "
