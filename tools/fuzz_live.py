@@ -3,7 +3,9 @@
 n_streams, blocks per call, row pitch (incl. pitches that are not multiples of 256 samples), busy masks, dtype (float32 / int32 DFSDM
 words / PDM bit streams), host or device buffers, both receivers.  For every draw the chunked LIVE run (uc_receive_streams_next, chunk
 sizes drawn per call) must give, bit for bit, the texts and traces of ONE call over the whole streams (uc_receive_streams), and that
-call must equal uc_receive_stream[_isr] stream by stream on a sample of the streams.
+call must equal uc_receive_stream[_isr] stream by stream on a sample of the streams.  Round 6: four draws in ten run the live
+state under uc_rx_state_keep_previous (device chunks are then held for two calls: the promise; host / PDM / busy-masked calls mix
+in as they are drawn).
 Usage: python tools/fuzz_live.py [cases=60] [seed=1]"""
 import ctypes as C
 import os
@@ -23,6 +25,7 @@ rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 L = uchirp.lib()
 dev = torch.device("cuda:0")
 bad = 0
+HELD = []
 
 
 def streams(ns, blocks):
@@ -49,6 +52,8 @@ def call(eng, state, buf, dt, ns, nsmp, pitch, busy, cap, trace_cap, device):
     keep = None
     if device:
         keep = torch.from_numpy(buf).to(dev)
+        HELD.append(keep)            # (uc_rx_state_keep_previous: a device chunk stays alive and unchanged for the next call too)
+        del HELD[:-3]
         ptr = C.c_void_p(keep.data_ptr())
     else:
         ptr = buf.ctypes.data_as(C.c_void_p)
@@ -86,6 +91,9 @@ for case in range(cases):
     w_t, w_tr = call(eng, None, whole, dt, ns, blocks * N, blocks * N + pad, busy, 32, blocks, device)
     # live, in chunks of random sizes
     live = eng.live(ns)
+    kept = bool(rng.random() < 0.4)
+    if kept:
+        live.keep_previous(True)
     texts, traces, b0 = [b""] * ns, [[] for _ in range(ns)], 0
     while b0 < blocks:
         nb = int(min(blocks - b0, rng.choice([1, 1, 1, 2, 3, 5, 8, 13])))
@@ -103,7 +111,7 @@ for case in range(cases):
         got = np.concatenate(traces[s]) if traces[s] else np.zeros(0, uchirp.RX_EVENT_DTYPE)
         if texts[s] != w_t[s] or not np.array_equal(got.view(np.uint8), w_tr[s].view(np.uint8)):
             ok = False
-            print("FAIL case %d (variant %d, %s, %d streams, busy %s): live chunks differ from the whole call at stream %d" % (case, variant, kind, ns, busy is not None, s), flush=True)
+            print("FAIL case %d (variant %d, %s, %d streams, busy %s, kept %s): live chunks differ from the whole call at stream %d" % (case, variant, kind, ns, busy is not None, kept, s), flush=True)
             break
     # the whole call against one stream at a time (the host replay), on a sample
     if ok and kind != "pdm":

@@ -2,7 +2,8 @@
 """A long live run: 96 microphones, 2400 blocks each (63 s of signal per microphone: transmissions with random gaps, noise),
 through (a) ONE uc_receive_streams call over the whole recording, (b) uc_receive_streams_next one block per call, eager,
 (c) the same step replayed 2400 times from ONE captured hipGraph, (d) chunks of random sizes with a busy mask against the
-recorded call with the same mask.  Texts and every trace record must be equal, bit for bit; the hand-out counters must be zero.
+recorded call with the same mask; round 6: (e) one block per call under uc_rx_state_keep_previous, two chunk buffers in turn, eager,
+(f) the same as TWO captured graphs replayed in turn.  Texts and every trace record must be equal, bit for bit; the hand-out counters must be zero.
 Usage: python tools/soak_live.py [variant=sync_cplx] [blocks=2400] [streams=96]"""
 import os
 import sys
@@ -43,13 +44,33 @@ print("%s: %d streams x %d blocks, %d transmissions sent, %d messages ended in t
 
 def run_live(mode):
     live = eng.live(ns)
-    chunk = torch.zeros((ns, N), dtype=torch.float32, device=dev)
+    keep = mode.startswith("keep")
+    if keep:
+        live.keep_previous(True)
+    ring = [torch.zeros((ns, N), dtype=torch.float32, device=dev) for _ in range(2 if keep else 1)]
+    chunk = ring[0]
     text = torch.zeros((ns, 8), dtype=torch.uint8, device=dev)
     ntext = torch.zeros(ns, dtype=torch.int32, device=dev)
     trace = torch.zeros((ns, 1, uchirp.RX_EVENT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
     ntrace = torch.zeros(ns, dtype=torch.int32, device=dev)
     st = torch.cuda.Stream()
     g = None
+    graphs = None
+    first_block = 0
+    if mode == "keep_graph":
+        # block 0 eagerly (it sizes the scratch; in front of it: the state's power-on FIFO), then one captured step per buffer
+        ring[0].copy_(xd[:, :N])
+        live.next_into(ring[0], text, ntext, trace=trace, n_trace=ntrace)
+        torch.cuda.synchronize()
+        first_block = 1
+        graphs = []
+        st.wait_stream(torch.cuda.current_stream())
+        for k in (1, 0):
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(st):
+                with torch.cuda.graph(gk, stream=st):
+                    live.next_into(ring[k], text, ntext, trace=trace, n_trace=ntrace, stream=st.cuda_stream)
+            graphs.append(gk)      # graphs[0]: ring[1] behind ring[0]; graphs[1]: ring[0] behind ring[1]
     if mode == "graph":
         live.next_into(chunk, text, ntext, trace=trace, n_trace=ntrace)
         live.reset()
@@ -65,9 +86,18 @@ def run_live(mode):
     all_text = torch.zeros((blocks, ns, 8), dtype=torch.uint8, device=dev)
     all_nt = torch.zeros((blocks, ns), dtype=torch.int32, device=dev)
     all_tr = torch.zeros((blocks, ns, uchirp.RX_EVENT_DTYPE.itemsize), dtype=torch.uint8, device=dev)
-    for b in range(blocks):
+    if first_block:
+        all_text[0].copy_(text)
+        all_nt[0].copy_(ntext)
+        all_tr[0].copy_(trace[:, 0])
+    for b in range(first_block, blocks):
+        chunk = ring[b % len(ring)]
         chunk.copy_(xd[:, b * N:(b + 1) * N])
-        if g is not None:
+        if graphs is not None:
+            torch.cuda.current_stream().synchronize()
+            graphs[(b + 1) % 2].replay()
+            st.synchronize()
+        elif g is not None:
             torch.cuda.current_stream().synchronize()
             g.replay()
             st.synchronize()
@@ -87,7 +117,7 @@ def run_live(mode):
 
 
 bad = 0
-for mode in ("eager", "graph"):
+for mode in ("eager", "graph", "keep", "keep_graph"):
     t, tr = run_live(mode)
     for s in range(ns):
         if t[s] != w_text[s] or not np.array_equal(tr[s].view(np.uint8), w_trace[s].view(np.uint8)):
