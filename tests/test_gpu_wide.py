@@ -199,3 +199,57 @@ def test_receive_stream_at_41_7_khz(uchirp, variant):
     assert text_g == text_o == "Hi!\n"
     for fld in ("state_after", "sync_position", "bit"):
         assert np.array_equal(trace_g[fld], trace_o[fld]), fld
+
+
+@pytest.mark.parametrize("variant", ["rx_real", "sync_cplx"])
+def test_live_receivers_with_wide_windows(uchirp, variant, monkeypatch):
+    """The ROWS build of the band kernel in its WIDE form (bandwidth2 = 294 at the 41.7 kHz DFSDM setting: three pruned rounds, the
+    generic window search, its own finaliser branch): many recorded streams in one call == one stream at a time (uc_receive_stream),
+    and live receivers fed one block per call -- the masked walk, under the poison switch, default contract and kept chunks, int32
+    and float32 words -- == the recorded call, texts and traces bit for bit."""
+    import torch
+    from uchirp import tx
+    monkeypatch.setenv("UC_TUNING", "1")
+    monkeypatch.setenv("UC_RX_POISON", "1")
+    fs = 125000.0 / 3.0
+    up, down = synth.chirp_pair(fs=fs, amp=2000.0)
+    sym = {1: up, 0: down, -1: np.zeros(2048)}
+    rng = np.random.default_rng(17)
+    ns, blocks = 11, 110
+    x = np.zeros((ns, blocks * 2048), np.float32)
+    msgs = []
+    for s in range(ns):
+        msg = "".join(chr(int(c)) for c in rng.integers(48, 123, size=int(rng.integers(1, 4))))
+        tone = np.concatenate([sym[int(v)] for v in tx.symbol_sequence(msg)])
+        lead = int(rng.integers(26, 40)) * 2048 + int(rng.integers(0, 2048))
+        row = rng.normal(0.0, 50.0, size=blocks * 2048)
+        row[lead:lead + tone.size] += tone
+        x[s] = row.astype(np.float32)
+        msgs.append(msg)
+    kw = dict(fs=fs, time_frame=2048.0 / fs)
+    e = uchirp.Engine(VAR[variant], **kw)
+    assert e.bandwidth2 == 294
+    for data in (x, (np.round(x).astype(np.int64) * 256).astype(np.int32)):
+        whole_t, whole_tr = e.receive_many(data)
+        for s in (0, 5, 10):                                     # == one stream at a time (the batch build over stride 256)
+            t1, tr1 = e.receive(data[s])
+            assert t1 == whole_t[s] and np.array_equal(tr1.view(np.uint8), whole_tr[s].view(np.uint8)), s
+        xd = torch.from_numpy(data).to("cuda:0")
+        for kept in (False, True):
+            live = e.live(ns)
+            live.keep_previous(kept)
+            ring = [torch.zeros((ns, 2048), dtype=xd.dtype, device="cuda:0") for _ in range(2)]
+            texts, traces = [""] * ns, [[] for _ in range(ns)]
+            for b in range(blocks):
+                ring[b % 2].copy_(xd[:, b * 2048:(b + 1) * 2048])
+                t, tr = live.next(ring[b % 2])
+                for s in range(ns):
+                    texts[s] += t[s]
+                    traces[s].append(tr[s])
+            for s in range(ns):
+                assert texts[s] == whole_t[s], (kept, s)
+                assert np.array_equal(np.concatenate(traces[s]).view(np.uint8), whole_tr[s].view(np.uint8)), (kept, s)
+            live.close()
+    if variant == "sync_cplx":
+        assert sum(m in t for m, t in zip(msgs, whole_t)) >= 8
+    e.close()

@@ -1091,20 +1091,22 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             if (kReal) {
               const v2f sa = pk_add_conj(zl, zh);  // 2 A[k]
               const v2f sb = pk_sub_conj(zl, zh);  // 2j B[k]
-              float ma = sa.x * sa.x + sa.y * sa.y, mb = sb.x * sb.x + sb.y * sb.y;
+              // (|.|^2 as ONE product and ONE fused multiply-add, spelled out: left to the compiler's contraction the batch and the
+              // ROWS instantiation of this branch rounded differently in the last bit -- round 6, tests/test_gpu_wide.py)
+              float ma = __builtin_fmaf(sa.x, sa.x, sa.y * sa.y), mb = __builtin_fmaf(sb.x, sb.x, sb.y * sb.y);
               if (r == 0 && i == 0) {  // Q2, as in the default build below
                 ma = sa.x * sa.x;
                 mb = sb.y * sb.y;
                 if (!p.true_dc) {
-                  ma += 4.0f * (zn.x * zn.x);
-                  mb += 4.0f * (zn.y * zn.y);
+                  ma = __builtin_fmaf(4.0f * zn.x, zn.x, ma);
+                  mb = __builtin_fmaf(4.0f * zn.y, zn.y, mb);
                 }
               }
               qa[r] = ma;
               qb[r] = mb;
             } else {
-              qa[r] = zl.x * zl.x + zl.y * zl.y;
-              qb[r] = zh.x * zh.x + zh.y * zh.y;
+              qa[r] = __builtin_fmaf(zl.x, zl.x, zl.y * zl.y);
+              qb[r] = __builtin_fmaf(zh.x, zh.x, zh.y * zh.y);
             }
             if (p.spectrum) store_spectrum(f, run, i, qa[r], qb[r]);
           }
@@ -1198,6 +1200,9 @@ __global__ __launch_bounds__(T, WAVES) void band_kernel(const BandParams p) {
             // Window search on q = 4 |X|^2 (monotonic in |X|); the finaliser takes the
             // square root of the four winners only: |X| = 0.5 sqrt(q).
             float ma = 0.f, mb = 0.f;
+            // (plain expressions: which product the compiler fuses is its choice -- today the SAME one in the batch, overlap, SPEC
+            // and ROWS instantiations of this branch, which tests/test_gpu_k6.py, test_gpu_receive_many.py and test_gpu_decision.py
+            // hold bit for bit against each other; the WIDE branch above had to spell it out)
             if (do_a) ma = sa.x * sa.x + sa.y * sa.y;
             if (do_b) mb = sb.x * sb.x + sb.y * sb.y;
             if (r == 0 && i == 0) {

@@ -156,7 +156,8 @@ def lib():
     L.uc_rx_state_destroy.argtypes = [C.c_void_p]
     L.uc_rx_state_destroy.restype = None
     L.uc_rx_state_streams.argtypes = [C.c_void_p]
-    L.uc_rx_state_keep_previous.argtypes = [C.c_void_p, C.c_int]
+    if hasattr(L, "uc_rx_state_keep_previous"):     # (UCHIRP_LIB may name an older diagnostic build)
+        L.uc_rx_state_keep_previous.argtypes = [C.c_void_p, C.c_int]
     L.uc_rx_state_streams.restype = C.c_size_t
     VPP = C.POINTER(C.c_void_p)
     L.uc_group_receive_streams.argtypes = [C.c_void_p, VPP, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, VPP, VPP, C.c_size_t,
