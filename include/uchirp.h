@@ -305,6 +305,10 @@ int uc_receive_stream_isr(uc_ctx* ctx, const void* samples, int dtype, size_t n_
  * Every pointer may be host or device memory; with device pointers only, the call is asynchronous on hip_stream.
  * dtype: UC_DTYPE_I32 / UC_DTYPE_F32 samples, or UC_DTYPE_PDM (the microphones' bit streams, one 32-bit word per sample: the
  * DFSDM runs on the device first; device buffers 16-byte aligned, the stride a multiple of 4 words).
+ * From 1024 streams (UC_SYNC_CPLX) / 8192 streams (UC_RX_REAL) on, a call of several blocks without a busy mask is served block
+ * by block -- as many one-block steps of the live form, back to back on hip_stream: each evaluates only the offsets the switch
+ * can still look at once the block before has gone through it (an idle stream 3 or 5 of 8, UP only), where one launch over all
+ * blocks must evaluate everything; same texts and traces, bit for bit (4096 recorded streams of 176 blocks: 21.7 -> 14.6 ms).
  * 8 bytes per 256 samples of statistics are parked in the context between the kernels of a call.  That scratch serves one
  * call at a time: calls of one context on DIFFERENT streams are ordered by the library (the later one waits, on the device,
  * for the earlier one's kernels) -- use one context per stream, or live states, for calls that should overlap.

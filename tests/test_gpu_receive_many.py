@@ -557,6 +557,92 @@ def test_refused_live_calls_leave_the_state_as_it_was(uchirp):
     e.close()
 
 
+@pytest.mark.parametrize("variant", [uco.SYNC_CPLX, uco.RX_REAL])
+def test_calls_of_several_blocks_served_block_by_block(uchirp, monkeypatch, variant):
+    """A call of several blocks without a busy mask is served as one-block steps of the live form when a step fills the chip
+    (from 1024 / 8192 streams on; here forced for few streams: UC_TUNING=1 UC_RX_STEP_MIN=1): every step evaluates only what the
+    switch can still look at, the block in front of step b is block b - 1 of the same buffer.  Texts and traces equal the one-launch
+    call (which evaluates everything) and one stream at a time, bit for bit: recorded calls (float32 / int32 / PDM words, host and
+    device memory, row strides larger than the stream), live chunks of any sizes with and without kept chunks, busy-masked calls
+    (served in one launch as ever) mixed in -- all under the poison switch."""
+    import torch
+    dev = torch.device("cuda:0")
+    blocks = 140
+    x, busy, msgs = _transmissions(19, seed=321 + variant, blocks=blocks)
+    ns = x.shape[0]
+    plain = uchirp.Engine(variant)                                   # one launch per call (19 streams: below every threshold)
+    monkeypatch.setenv("UC_TUNING", "1")
+    monkeypatch.setenv("UC_RX_STEP_MIN", "1")
+    monkeypatch.setenv("UC_RX_POISON", "1")
+    e = uchirp.Engine(variant)                                       # block by block
+    xi = (np.round(x).astype(np.int64) * 256).astype(np.int32)
+    for data in (x, xi):
+        want_t, want_tr = plain.receive_many(data)
+        for arg in (data, torch.from_numpy(data).to(dev)):
+            got_t, got_tr = e.receive_many(arg)
+            assert got_t == want_t
+            assert all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(got_tr, want_tr))
+        # a row stride larger than the stream
+        wide = torch.full((ns, blocks * N + 96), 3, dtype=torch.from_numpy(data).dtype, device=dev)
+        wide[:, :blocks * N] = torch.from_numpy(data).to(dev)
+        got_t, got_tr = e.receive_many(wide[:, :blocks * N])
+        assert got_t == want_t and all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(got_tr, want_tr))
+        for s_ in (0, 7, 18):                                        # == uc_receive_stream of the stream alone
+            t1, tr1 = e.receive(data[s_])
+            assert t1 == want_t[s_] and np.array_equal(tr1.view(np.uint8), want_tr[s_].view(np.uint8)), s_
+    assert sum(m in t for m, t in zip(msgs, want_t)) >= (5 if variant == uco.SYNC_CPLX else 0)
+    # PDM words: the DFSDM first, then the steps over its words
+    rng = np.random.default_rng(8)
+    bits = rng.integers(-(1 << 31), (1 << 31) - 1, size=(ns, 20 * N), dtype=np.int64).astype(np.int32)
+    w_t, w_tr = plain.receive_many(bits, pdm=True)
+    g_t, g_tr = e.receive_many(bits, pdm=True)
+    assert g_t == w_t and all(np.array_equal(a.view(np.uint8), b.view(np.uint8)) for a, b in zip(g_tr, w_tr))
+    # live states: chunks of several blocks are stepped too; kept chunks; busy-masked chunks in between (one launch each)
+    want_t, want_tr = plain.receive_many(x, busy=busy)
+    xd = torch.from_numpy(x).to(dev)
+    for kept in (False, True):
+        live = e.live(ns)
+        live.keep_previous(kept)
+        sizes = [3, 1, 8, 2, 1, 16, 5, 1, 1, 40, 7, 9, 2, 44]
+        assert sum(sizes) == blocks
+        ring = [torch.zeros((ns, 44 * N), dtype=torch.float32, device=dev) for _ in range(2)]
+        texts, traces, b0 = [""] * ns, [[] for _ in range(ns)], 0
+        for k, nb in enumerate(sizes):
+            buf = ring[k % 2]
+            buf[:, :nb * N].copy_(xd[:, b0 * N:(b0 + nb) * N])
+            bz = np.ascontiguousarray(busy[:, b0:b0 + nb])
+            t, tr = live.next(buf[:, :nb * N], busy=bz)              # (a mask of zeros is still a mask: the one-launch path)
+            for s_ in range(ns):
+                texts[s_] += t[s_]
+                traces[s_].append(tr[s_])
+            b0 += nb
+        for s_ in range(ns):
+            assert texts[s_] == want_t[s_], (kept, s_)
+            assert np.array_equal(np.concatenate(traces[s_]).view(np.uint8), want_tr[s_].view(np.uint8)), (kept, s_)
+        live.close()
+    want_t, want_tr = plain.receive_many(x)
+    for kept in (False, True):
+        live = e.live(ns)
+        live.keep_previous(kept)
+        sizes = [3, 1, 8, 2, 1, 16, 5, 1, 1, 40, 7, 9, 2, 44]
+        ring = [torch.zeros((ns, 44 * N), dtype=torch.float32, device=dev) for _ in range(2)]
+        texts, traces, b0 = [""] * ns, [[] for _ in range(ns)], 0
+        for k, nb in enumerate(sizes):
+            buf = ring[k % 2]
+            buf[:, :nb * N].copy_(xd[:, b0 * N:(b0 + nb) * N])
+            t, tr = live.next(buf[:, :nb * N])
+            for s_ in range(ns):
+                texts[s_] += t[s_]
+                traces[s_].append(tr[s_])
+            b0 += nb
+        for s_ in range(ns):
+            assert texts[s_] == want_t[s_], (kept, s_)
+            assert np.array_equal(np.concatenate(traces[s_]).view(np.uint8), want_tr[s_].view(np.uint8)), (kept, s_)
+        live.close()
+    e.close()
+    plain.close()
+
+
 def test_plain_c_host_runs_live_microphones(tmp_path):
     """tests/c/host_live.c (C99 -pedantic -Werror, libuchirp.so only): three synthetic microphones, one new block each per
     call of uc_receive_streams_next -- the firmware's own loop -- print the characters as they complete; every stream

@@ -208,6 +208,7 @@ int uc_create(const uc_config* cfg, uc_ctx** out) {
     }
     if (const char* g = getenv("UC_GRID")) c->grid_override = atoi(g);
     if (const char* g = getenv("UC_RX_POISON")) c->rx_poison = atoi(g) != 0;
+    if (const char* g = getenv("UC_RX_STEP_MIN")) c->rx_step_min = atol(g);
     if (const char* g = getenv("UC_RX_NEED_FORCE")) c->rx_need_force = (uint32_t)strtoul(g, nullptr, 0) | 0x80000000u;
     if (const char* g = getenv("UC_BAND_GROUP")) {
       const int v = atoi(g);

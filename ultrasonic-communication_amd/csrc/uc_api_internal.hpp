@@ -71,8 +71,13 @@ bool is_device_ptr(const void* p);
 struct RxScratch {
   DevBuf in, busy, acc, na, pad, rec, text, ntext, trace, ntrace;
   DevBuf pcm, hist;  // UC_DTYPE_PDM: the DFSDM words of the call's blocks; the filter history of streams without a state
+  // a call served block by block (uc_api_rx.cpp: receive_steps): the characters every stream has been given so far in the call;
+  // for streams WITHOUT a state also what a state would carry from step to step -- the 9 surviving records, main()'s locals, the
+  // need words
+  DevBuf fill, carry, loop, need;
   void release() {
-    for (DevBuf* b : {&in, &busy, &acc, &na, &pad, &rec, &text, &ntext, &trace, &ntrace, &pcm, &hist}) b->release();
+    for (DevBuf* b : {&in, &busy, &acc, &na, &pad, &rec, &text, &ntext, &trace, &ntrace, &pcm, &hist, &fill, &carry, &loop, &need})
+      b->release();
   }
 };
 
@@ -136,6 +141,7 @@ struct uc_ctx {
   int grid_override = 0;
   int band_group = 32;    // frames per group handed to a workgroup at a time
   bool static_deal = false;
+  long rx_step_min = -1;       // (env UC_RX_STEP_MIN) streams from which a call of several blocks is served block by block: -1 = by variant
   uint32_t rx_need_force = 0;  // (env UC_RX_NEED_FORCE=0x1..: pricing runs only) every stream's need word is this one: WRONG results
   bool rx_poison = false;   // (env UC_RX_POISON=1, tests) the statistics the live receivers pass over are huge instead of zero
   int compress_chunk = 8;   // (env UC_COMPRESS_CHUNK) frame pairs per hand-out chunk of the compress kernel: a power of two >= 2

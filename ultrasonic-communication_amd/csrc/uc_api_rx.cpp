@@ -164,6 +164,94 @@ int uc::receive_streams_check(uc_ctx* c, uc_rx_state* st, bool live, const void*
   return 0;
 }
 
+// A call of SEVERAL blocks served block by block: nb one-block steps of the live form, back to back on the stream -- every step
+// evaluates only the FIFO offsets main()'s switch can still look at (the need words its predecessor left: 3 or 5 of the 8 new
+// offsets of an idle stream, the UP reference only; 5 or 6 around a locked sync_position: receiver/Src/main.c:447-453, 491-550)
+// where ONE launch over all nb x 8 offsets must evaluate everything, because what the switch will look at in block k is only
+// known once block k - 1 has gone through it.  "The block in front" of step b >= 1 is block b - 1 of the SAME buffer (nothing is
+// copied); a live state's newest block is handed over by the last step alone.  Texts and traces are the one-launch call's, bit
+// for bit (tests/test_gpu_receive_many.py).  Worth it when a step fills enough of the chip (profiles/r06_steps_ab.txt, 176-block
+// streams with one transmission each): the complex receiver from 1024 streams on (5.8 -> 5.2 ms; 4096 streams 21.7 -> 14.6 ms,
+// 16 384 streams 86 -> 52 ms), RX_REAL from 8192 (19.2 -> 16.8 ms; 32 768 streams 75 -> 58 ms); below that one launch wins.
+static int receive_steps(uc_ctx* c, uc_rx_state* st, RxScratch& sc, const void* d_in, int dtype, size_t n_streams, size_t nb,
+                         size_t stride, bool keep_next, char* d_text, size_t text_cap, uint32_t* d_ntext, uc_rx_event* d_trace,
+                         size_t trace_cap, uint32_t* d_ntrace, hipStream_t stream) {
+  const uint32_t n = c->cfg.n, per_block = n / 256;
+  float2* d_carry = st ? st->d_carry : (float2*)sc.carry.p;
+  uint32_t* d_loop = st ? st->d_loop : (uint32_t*)sc.loop.p;
+  uint32_t* d_need = st ? st->d_need : (uint32_t*)sc.need.p;
+  hipError_t e = hipMemsetAsync(sc.fill.p, 0, n_streams * sizeof(uint32_t), stream);
+  if (!st) {  // streams that start with this call: every receiver at power-on (uc_rx_state_reset does the same for a state)
+    if (e == hipSuccess) e = hipMemsetAsync(d_carry, 0, n_streams * (size_t)(per_block + 1) * sizeof(float2), stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)d_need, (int)uc::need_word(UC_STATE_IDLE, 0, 0), n_streams, stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stepped receivers)");
+    const int lrc = uc::launch_rx_state_init(d_loop, n_streams, n, c->cfg.snr_threshold, stream);
+    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx state init kernel launch");
+  }
+  if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(stepped receivers)");
+  for (size_t b = 0; b < nb; b++) {
+    const bool last = b + 1 == nb;
+    uc::BandParams bp;
+    memset(&bp, 0, sizeof(bp));
+    bp.frames = (const char*)d_in + b * (size_t)n * 4;
+    bp.n_frames = n_streams * per_block;
+    bp.magmax = (float2*)sc.rec.p;
+    bp.row_pitch = stride;
+    bp.row_blocks = 1;
+    uc::rows_divisor(1u, &bp.div_magic, &bp.div_shift);
+    bp.need = d_need;
+    bp.poison = c->rx_poison ? 1u : 0u;
+    if (b == 0) {  // in front of the call's first block: what the state holds (or a kept chunk), zeros for streams that start
+      bp.prev = st ? (const void*)st->d_last : (const void*)c->d_zero_block;
+      bp.prev_pitch = st ? (size_t)n : 0;
+      bp.prev_half = st ? n_streams * (size_t)n : 0;
+      bp.parity = st ? st->d_parity : nullptr;
+      if (st && st->kept) {
+        bp.prev = st->kept;
+        bp.prev_pitch = st->kept_pitch;
+        bp.prev_half = 0;
+      }
+    } else {       // ... of every other block: the block before it, where it lies
+      bp.prev = (const char*)bp.frames - (size_t)n * 4;
+      bp.prev_pitch = stride;
+      bp.prev_half = 0;
+      bp.parity = st ? st->d_parity : nullptr;
+    }
+    if (st && last && !keep_next) {  // the state's newest block: handed over by the last step (its m = 7 or 8 frames)
+      bp.save = 1u;
+      bp.save_to = st->d_last;
+      bp.save_half = n_streams * (size_t)n;
+    }
+    if (int rc = band_launch(c, bp, dtype, stream)) return rc;
+    uc::RxParams rp;
+    memset(&rp, 0, sizeof(rp));
+    rp.rec = (const float2*)sc.rec.p;
+    rp.rec_pitch = per_block;
+    rp.carry = d_carry;
+    rp.carry_pitch = per_block + 1;
+    rp.carry_out = d_carry;
+    rp.n_streams = n_streams;
+    rp.n = n;
+    rp.nb = 1;
+    rp.snr_threshold = c->cfg.snr_threshold;
+    rp.text = d_text;
+    rp.text_cap = (uint32_t)text_cap;
+    rp.n_text = d_ntext;
+    rp.trace = d_trace;
+    rp.trace_cap = (uint32_t)trace_cap;
+    rp.n_trace = d_ntrace;
+    rp.loop_state = d_loop;
+    rp.parity = (st && last) ? st->d_parity : nullptr;  // (one flip per call, behind the step that filled the other half)
+    rp.need = d_need;
+    rp.need_force = c->rx_need_force;
+    rp.fill = (uint32_t*)sc.fill.p;
+    rp.trace_start = (uint32_t)b;
+    const int lrc = uc::launch_rx_replay(rp, stream);
+    if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
+  }
+  return 0;
+}
+
 static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples, int dtype, size_t n_streams, size_t n_samples,
                                 size_t stream_stride_elems, const uint8_t* busy, char* text, size_t text_cap,
                                 uint32_t* n_text, uc_rx_event* trace, size_t trace_cap, uint32_t* n_trace,
@@ -241,6 +329,16 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     // (every scratch buffer of the call is sized before its first launch: a call that cannot be served -- out of memory, or a
     // capture that would have to allocate -- has enqueued nothing)
     if (int rc = sc.rec.ensure(n_frames * sizeof(float2))) return rc;
+    // a call of several blocks without a busy mask is served block by block when a step fills the chip (receive_steps)
+    const size_t step_min = c->rx_step_min >= 0 ? (size_t)c->rx_step_min : (c->cfg.variant == UC_SYNC_CPLX ? 1024u : 8192u);
+    const bool stepped = !busy && nb > 1 && n_streams >= step_min && !capturing;
+    if (stepped) {
+      int rc = sc.fill.ensure(n_streams * sizeof(uint32_t));
+      if (!rc && !st) rc = sc.carry.ensure(n_streams * (size_t)(per_block + 1) * sizeof(float2));
+      if (!rc && !st) rc = sc.loop.ensure(n_streams * (size_t)uc::rx_loop_words() * 4);
+      if (!rc && !st) rc = sc.need.ensure(n_streams * sizeof(uint32_t));
+      if (rc) return rc;
+    }
     if (pdm)
       if (int rc = sc.pcm.ensure(n_streams * nb * (size_t)n * 4)) return rc;
     if (busy) {
@@ -322,6 +420,11 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
       rows = sc.pad.p;
       row_pitch = nb * (size_t)n;
     }
+    if (stepped) {
+      if (int rc = receive_steps(c, st, sc, rows, dtype, n_streams, nb, row_pitch, keep_next, d_text, text_cap, d_ntext, d_trace,
+                                 trace_cap, d_ntrace, stream))
+        return rc;
+    } else {
     if (int rc = sc.rec.ensure(n_frames * sizeof(float2))) return rc;
     // dsp() at the 8 FIFO offsets every accepted block ADDS (the other 9 of its FIFO were evaluated when the block before
     // it arrived, main.c:662): frame (s, k, m) = the last n - 256 m samples of the block in front of the stream's k-th
@@ -388,6 +491,7 @@ static int receive_streams_impl(uc_ctx* c, uc_rx_state* st, const void* samples,
     }
     lrc = uc::launch_rx_replay(rp, stream);
     if (lrc != (int)hipSuccess) return hip_fail((hipError_t)lrc, "rx replay kernel launch");
+    }
     if (st) {
       st->blocks_seen += nb;
       st->dtype = dtype_in;

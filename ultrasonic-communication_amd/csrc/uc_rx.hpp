@@ -78,6 +78,11 @@ struct RxParams {
   // step a block), the acquisition set the stream would use if it fell back to IDLE, and k = 16 when ks <= 3; both references:
   // 5 or 6 of the 8.  (uc_rx_kernel.hip: need_word.)  nullptr: none.
   uint32_t* need;
+  // a call served as a SEQUENCE of one-block steps (uc_api_rx.cpp: receive_steps): the characters a stream has been given so far
+  // in this call ([n_streams], in and out: the step appends behind them; nullptr: none) and the trace records every stream has
+  // been given so far (one per block)
+  uint32_t* fill;
+  uint32_t trace_start;
   uint32_t need_force;   // pricing runs only (UC_TUNING=1 UC_RX_NEED_FORCE): bit 31 set = every stream's word is the low 9 bits of this
 };
 

@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   SeqLoop& loop = *__builtin_launder(reinterpret_cast<SeqLoop*>(mine));
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
-  uint32_t ntext = 0, nt = 0;
+  uint32_t ntext = p.fill ? p.fill[s] : 0u, nt = p.trace_start;
   auto put = [&](char ch) {
     if (ntext + 1 < p.text_cap) text[ntext++] = ch;
   };
@@ -141,6 +141,7 @@ __global__ __launch_bounds__(64) void replay_kernel(const RxParams p) {
   }
   text[ntext] = '\0';
   if (p.n_text) p.n_text[s] = ntext;
+  if (p.fill) p.fill[s] = ntext;
   if (p.n_trace) p.n_trace[s] = nt;
   asm volatile("" ::: "memory");
   if (p.loop_state) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
   const uint32_t block_base = loop_mem[kStateWords];
   char* text = p.text + s * p.text_cap;
   uc_rx_event* trace = p.trace ? p.trace + s * p.trace_cap : nullptr;
-  uint32_t ntext = 0, nt = 0;
+  uint32_t ntext = (p.fill && lane == 0) ? p.fill[s] : 0u, nt = p.trace_start;
   auto put = [&](char ch) {
     if (ntext + 1 < p.text_cap) text[ntext++] = ch;
   };
@@ -253,6 +254,7 @@ __global__ __launch_bounds__(64) void replay_wave_kernel(const RxParams p) {
   if (lane == 0) {
     text[ntext] = '\0';
     if (p.n_text) p.n_text[s] = ntext;
+    if (p.fill) p.fill[s] = ntext;
     if (p.n_trace) p.n_trace[s] = nt;
     loop_mem[kStateWords] = block_base + p.nb;
     if (p.parity && s == 0) *p.parity ^= 1u;  // (nothing of this launch reads it)
