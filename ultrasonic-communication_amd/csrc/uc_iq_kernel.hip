@@ -133,6 +133,14 @@ static_assert(kRingFrBb * kRingStBb <= kRingFr * kRingSt, "the base-band ring fi
 // BB: 0 = the firmware's windows, 1 = UC_FLAG_IQ_BASEBAND, 2 = base band with windows of at most 64 bins each (61 at
 // BASELINE configs[2]'s constants): wave 0 owns the left window's bins, wave 1 the right window's -- ONE pruned round,
 // one wave reduction per dechirp run and wave.
+// wave priority, as in the band kernel: low while a wave issues a burst of LDS stores, raised otherwise, highest for the
+// pruned pass that ends a run (UC_IQ_PRIO_OFF: the A/B switch of round 6)
+#ifdef UC_IQ_PRIO_OFF
+#define UC_IQ_PRIO(n) do { } while (0)
+#else
+#define UC_IQ_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+
 template <int DTYPE, int BB>
 __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
   UC_CLOCK_BEGIN();  // diagnostic build only (uc_dev.hpp)
@@ -305,11 +313,13 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     asm volatile("" : "+v"(s1v));
 
     // ---- stage 0: carrier mix into the padded image (iq_modem.c:60-61) ------------------------
+    UC_IQ_PRIO(0);
 #pragma unroll
     for (int u = 0; u < 17; u++) {
       const float x = cvt1<DTYPE>(xn[u]);
       lds_st(img, mix_idx(j + T * u), (UC_IQ_KNOCK & 1) ? mkv(x, x) : mkv(x * cs[u].x, x * cs[u].y));
     }
+    UC_IQ_PRIO(2);
     if (has_next) load_frame(fnext);
     __syncthreads();  // B1: image complete; the previous frame's pruned-pass reads of the tile are done
     if (ring_n > 0 && (f & gmask) == 0) {  // a new group starts: drain the last one
@@ -340,8 +350,10 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
 #pragma unroll
       for (int k = 1; k < kFirTapsDev; k += 2)
         pk_tap8x2(accB, &w[8 + kHalo - k - 1], taps[k >> 1], taps[(k >> 1) + 1]);
+      UC_IQ_PRIO(0);
 #pragma unroll
       for (int u = 0; u < 16; u++) lds_st(tile, wr1 + (u ^ s1v), u < 8 ? accA[u & 7] : accB[u & 7]);
+      UC_IQ_PRIO(2);
     }
     __syncthreads();  // B2: filtered frame in the tile; every window read of the image is done
     if (dyn && ((f + 2) & gmask) == 0 && j == 0) fetched = atomicAdd(p.work_ctr, 1u);  // (+ gridDim.x where it is read)
@@ -375,8 +387,10 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
     }
     pk_dft16(v, K, H);
     // (run 1: every pass-2 read of the image area by run 0 sits in front of run 0's B4)
+    UC_IQ_PRIO(0);
 #pragma unroll
     for (int t = 0; t < 16; t++) lds_st(img, wr1 + (t ^ s1v), v[pk_slot16(t)]);
+    UC_IQ_PRIO(2);
     __syncthreads();  // B3: every read of the tile (vr; run 0's pruned pass) is done
 
     // ---- FFT pass 2 -----------------------------------------------------------------------
@@ -387,9 +401,12 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
 #pragma unroll
     for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2l, tw2o + 16 * t));
     pk_dft16(v, K, H);
+    UC_IQ_PRIO(0);
 #pragma unroll
     for (int t = 0; t < 16; t++) lds_st(dst2, wr2 + 16 * t, v[pk_slot16(t)]);
+    UC_IQ_PRIO(2);
     __syncthreads();  // B4
+    UC_IQ_PRIO(3);  // the pruned pass and the window search end the run: first in line
 
     if (BB == 2) {
       // ---- FFT pass 3, pruned to ONE bin per thread; this wave's window maximum and its first attaining bin --------
@@ -463,6 +480,7 @@ __global__ __launch_bounds__(T, 2) void iq_kernel(const IqParams p) {
       }
     }
     }
+    UC_IQ_PRIO(2);
     }  // run
     ring_n++;
     if (!has_next) break;

@@ -16,6 +16,14 @@
 #include "uc_dev.hpp"
 #include "uc_kernels.hpp"
 
+// wave priority, as in the band kernel: low while a wave issues a burst of LDS stores, raised otherwise (UC_XF_PRIO_OFF: the
+// A/B switch of round 6)
+#ifdef UC_XF_PRIO_OFF
+#define UC_XF_PRIO(n) do { } while (0)
+#else
+#define UC_XF_PRIO(n) __builtin_amdgcn_s_setprio(n)
+#endif
+
 namespace uc {
 
 constexpr int kXfThreads = 128;
@@ -62,8 +70,10 @@ __device__ __forceinline__ void xf_fill_twiddle_tables(float* tw2t, float* twBt,
 
 // forward pass-1 outputs (pk_dft16 slot order) -> exchange 1
 __device__ __forceinline__ void xf_store1(float* dst, const XfAddr& a, int s1v, const v2f (&v)[16]) {
+  UC_XF_PRIO(0);
 #pragma unroll
   for (int t = 0; t < 16; t++) lds_st(dst, a.wr1 + (t ^ s1v), v[pk_slot16(t)]);
+  UC_XF_PRIO(2);
 }
 
 // forward pass 2: radix-16, twiddles W_256^(t k), k = j & 15
@@ -76,8 +86,10 @@ __device__ __forceinline__ void xf_fwd2(const float* src, float* dst, const floa
 #pragma unroll
   for (int t = 1; t < 16; t++) v[t] = pk_cmul(v[t], lds_ld(tw2t, 16 * t + (j & 15)));
   pk_dft16(v, K, H);
+  UC_XF_PRIO(0);
 #pragma unroll
   for (int t = 0; t < 16; t++) lds_st(dst, a.wr2 + 16 * t, v[pk_slot16(t)]);
+  UC_XF_PRIO(2);
 }
 
 // pass-3 twiddles W_2048^(t (j + 128 h)), t = 1..7, from the three resident powers t3a/b/c = W_2048^j, ^2j, ^4j
@@ -141,8 +153,10 @@ __device__ __forceinline__ void xf_fwd3_h_invA(const float* src, float* dst, con
     for (int t = 0; t < 8; t++) g[t] = u[pk_slot8(t)];
     pk_dft8(g, H);
     // IDFT8[t] = DFT8[(8 - t) & 7]; inverse exchange A: element 8 b + t, swizzled phys = o ^ ((o >> 4) & 7)
+    UC_XF_PRIO(0);
 #pragma unroll
     for (int t = 0; t < 8; t++) lds_st(dst, 8 * b + (t ^ ((b >> 1) & 7)), g[pk_slot8((8 - t) & 7)]);
+    UC_XF_PRIO(2);
   }
 }
 
@@ -157,8 +171,10 @@ __device__ __forceinline__ void xf_invB(const float* src, float* dst, const floa
   for (int t = 1; t < 16; t++) v[t] = pk_cmulc(v[t], lds_ld(twBt, 8 * t + (j & 7)));
   pk_dft16(v, K, H);
   // output t of the inverse = forward output (16 - t) & 15
+  UC_XF_PRIO(0);
 #pragma unroll
   for (int t = 0; t < 16; t++) lds_st(dst, ((t & 1) ? a.wrBo : a.wrBe) + 8 * t, v[pk_slot16((16 - t) & 15)]);
+  UC_XF_PRIO(2);
 }
 
 // inverse pass C: radix-16, Ns = 128, conj twiddles W_2048^(t j); y[t] = output sample j + 128 t
