@@ -220,6 +220,38 @@ def run_receive(variant, world, ns, blocks=150, cap=24):
     for s in states:
         if s is not None:
             g.rx_state_destroy(s)
+    # the same live run with every rank's state under uc_rx_state_keep_previous (round 6): the chunks of a call stay alive and
+    # unchanged until the next call has completed (held for two calls here), busy-masked calls mixed in
+    states = [g.rx_state(r, c) if c else None for r, (f, c) in enumerate(shares)]
+    for st_ in states:
+        if st_ is not None:
+            uchirp._check(uchirp.lib().uc_rx_state_keep_previous(st_._h, 1), "uc_rx_state_keep_previous")
+    acc, at, held = [""] * ns, 0, []
+    for k, nb in enumerate((3, 1, 40, 1, 1, blocks - 46)):
+        ch = [torch.from_numpy(np.ascontiguousarray(x[f:f + c, at * N:(at + nb) * N])).to(dev) for f, c in shares]
+        held.append(ch)
+        del held[:-2]
+        bz = [torch.from_numpy(np.ascontiguousarray(busy[f:f + c, at:at + nb])).to(dev) for f, c in shares] if k % 2 else None
+        g.receive_streams(ch, ns, nb * N, text, cap, n_text=cnt, busy=bz, states=states)
+        g.synchronize()
+        t, c = text[world - 1].cpu().numpy(), cnt[world - 1].cpu().numpy()
+        acc = [a + bytes(t[i, :c[i]]).decode("latin-1") for i, a in enumerate(acc)]
+        at += nb
+    # (the calls without a mask accepted every block: compare with the recorded call under the mask they add up to)
+    mask2 = busy.copy()
+    at = 0
+    for k, nb in enumerate((3, 1, 40, 1, 1, blocks - 46)):
+        if k % 2 == 0:
+            mask2[:, at:at + nb] = 0
+        at += nb
+    eng = uchirp.Engine(variant)
+    want2, _ = eng.receive_many(x, busy=mask2, text_cap=cap, want_trace=False)
+    eng.close()
+    assert acc == want2, (variant, world, ns, "kept chunks")
+    checks += 1
+    for s in states:
+        if s is not None:
+            g.rx_state_destroy(s)
     g.close()
     return sum(m in t for m, t in zip(msgs, want))
 
