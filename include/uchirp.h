@@ -359,7 +359,8 @@ size_t uc_rx_state_streams(const uc_rx_state* st);                          /* h
  * the library copies that block into the state on its way through the kernel (8 KiB read once more + 8 KiB written per stream
  * and call) because the caller may overwrite `samples` as soon as the call has been enqueued.  A caller that receives into a
  * ring of two or more chunk buffers -- what a DMA engine fills anyway -- can promise instead that the `samples` of every call
- * stay where they are, UNCHANGED, until the NEXT uc_receive_streams_next on the state has completed on the device: the next
+ * stay where they are, UNCHANGED, until the NEXT uc_receive_streams_next on the state that brings at least one block has
+ * completed on the device (a call of zero blocks reads nothing and releases nothing): the next
  * call then reads "the block in front" from where the previous call's samples lie, and nothing is copied.  Results are the
  * same bit for bit.  The promise covers calls on device memory without a busy mask; a call on host memory (the library stages
  * it), from UC_DTYPE_PDM bits (the DFSDM words are the library's) or with a busy mask is served as ever -- such calls may

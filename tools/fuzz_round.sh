@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 echo "Round ${UC_ROUND:-5} (commit $(git rev-parse --short HEAD 2>/dev/null)); every tool runs the suite's bars against the oracle on random draws (new seeds):"
-for cmd in "tools/fuzz_parity.py 600 41" "tools/fuzz_strides.py 400 43" "tools/fuzz_receive.py 800 45" "tools/fuzz_live.py 400 55" "tools/fuzz_iq.py 300 47" "tools/fuzz_stream.py 160 49" "tools/fuzz_spectrum.py 300 51"; do
+for cmd in "tools/fuzz_parity.py 600 ${UC_SEED:-41}" "tools/fuzz_strides.py 400 $((${UC_SEED:-41}+2))" "tools/fuzz_receive.py 800 $((${UC_SEED:-41}+4))" "tools/fuzz_live.py 400 $((${UC_SEED:-41}+14))" "tools/fuzz_iq.py 300 $((${UC_SEED:-41}+6))" "tools/fuzz_stream.py 160 $((${UC_SEED:-41}+8))" "tools/fuzz_spectrum.py 300 $((${UC_SEED:-41}+10))" "tools/fuzz_dfsdm.py 200 $((${UC_SEED:-41}+12))"; do
   echo "== python $cmd"
   timeout -k 10 900 python $cmd 2>&1 | tail -1
 done
