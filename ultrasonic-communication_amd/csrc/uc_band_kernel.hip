@@ -342,9 +342,11 @@ __device__ __forceinline__ v2f ld_tw(const float2* tw, int idx) {
 // row_pitch ...): every frame is the tail of one block followed by the head of the next, two base addresses, the split a
 // multiple of 256 samples -- which is a whole number of this kernel's 128-sample load instructions, so each load takes one
 // of two buffer resources by a SCALAR select and nothing is ever copied together.  The m = 8 frame of a row's last block IS
-// that block and stores it for the next call on its way through (p.save); one-block calls of live receivers pass over the
-// offsets an IDLE stream's switch cannot look at (p.need: 3 or 5 of the 8, main.c:447-453).  A separate instantiation again:
-// the batch builds carry none of it.
+// that block and stores it for the next call on its way through (p.save) -- or its m = 7 frame does, with the block's last 256
+// samples in two registers more, where the switch cannot look at the m = 8 frame; one-block calls of live receivers WALK the
+// offsets the switch can still look at (p.need: 3 or 5 of the 8 of an IDLE stream, main.c:447-453; round 6: what is passed over
+// costs nothing -- the walk below).  A separate instantiation again: the batch builds carry none of it (their machine code is
+// recorded: tests/golden/kernel_digests.json).
 // FRAMES = 2 (OVERLAP): the batch addressing over frames that OVERLAP (stride < n: the reference's own FIFO reads, main.c:447-451,
 // 256 or 512 samples apart): the same loads with the default cache policy instead of `nt` -- with `nt` a frame's bytes are
 // fetched again by each of the up to 8 frames that share them (6384 instead of 1025 B of HBM traffic per frame at stride 256),
